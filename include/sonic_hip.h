@@ -1,0 +1,140 @@
+/* sonic_hip.h -- C ABI of libsonic_hip.so, the MI355X-native Sonic prover hot path.
+ *
+ * The reference (sdiehl/sonic, Haskell) has no FFI: its public surface is the exposed modules of
+ * sonic.cabal:31-37.  Each entry point below names the Haskell function it stands in for; a
+ * `foreign import ccall` shim over these symbols re-creates Sonic.SRS /
+ * Sonic.CommitmentScheme / Sonic.Protocol 1:1.
+ *
+ * Value encodings (standard form, never Montgomery):
+ *   Fr  : 32 bytes little-endian integer < r
+ *   G1  : 96 bytes  x || y, each 48 bytes little-endian < q; the point at infinity (`mempty`) is
+ *         96 zero bytes ((0,0) is not on y^2 = x^3 + 4)
+ *   sparse Laurent polynomial (poly's VLaurent as `GHC.Exts.toList` yields it,
+ *         CommitmentScheme.hs:33,48): n_terms exponents (int64) + n_terms Fr coefficients;
+ *         exponents need not be sorted, repeated exponents are summed, zero coefficients allowed
+ *   gate weights wL, wR, wO (Bulletproofs GateWeights, lists of Q rows of n): dense Q x n
+ *         row-major Fr
+ *   transcript: the prover's `rnd` draws made explicit, in draw order (Protocol.hs:58,66,76,
+ *         84-85; Signature.hs:48,60):  c_{n+1..n+4}, y, z, y_1..y_Q, z_1..z_Q, u, v  = 8 + 2Q Fr
+ *   proof: record order of `Proof` (Protocol.hs:28-38) then `HscProof` (Signature.hs:22-29):
+ *         R, T, a, Wa, b, Wb, Wt, s, [S_j, s_j, W_j]_j, [s'_j, W'_j, Q_j]_j, Qv, C, u, v
+ *         = (7+4Q)*96 + (5+2Q)*32 bytes
+ *
+ * Errors: the reference panics (Protocol.hs:55, CommitmentScheme.hs:70-73) or hits `fromJust`
+ * (CommitmentScheme.hs:44); here every function returns a status and never aborts the process.
+ * sonic_last_error() gives the thread's last message.  There is no CPU fallback: without a HIP
+ * device every call returns SONIC_ERR_NO_DEVICE.
+ *
+ * Threading: an SRS handle is immutable after construction and may be shared; a prover handle
+ * owns its stream and workspace and serves one call at a time.
+ */
+#ifndef SONIC_HIP_H
+#define SONIC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SONIC_OK = 0,
+  SONIC_ERR_D_TOO_SMALL = 1,      /* Protocol.hs:54-55  "Parameter d is not large enough" */
+  SONIC_ERR_SRS_INDEX = 2,        /* CommitmentScheme.hs:70-73 "... is not long enough", incl. the
+                                     e' = 0 hole of the alpha basis (index -1) */
+  SONIC_ERR_BAD_ENCODING = 3,     /* non-canonical Fr / Fq, point not on the curve */
+  SONIC_ERR_INEXACT_DIVISION = 4, /* CommitmentScheme.hs:44 fromJust; also z = 0 with negative exponents */
+  SONIC_ERR_HIP = 5,
+  SONIC_ERR_NO_DEVICE = 6,
+  SONIC_ERR_INVALID_ARG = 7
+};
+
+#define SONIC_FR_BYTES 32
+#define SONIC_G1_BYTES 96
+#define SONIC_G1_PARTIAL_BYTES 144   /* un-normalised XYZZ accumulator exchanged between ranks */
+
+typedef struct sonic_srs sonic_srs_t;
+typedef struct sonic_prover sonic_prover_t;
+
+/* ---- library ---- */
+int sonic_init(int device_ordinal);                 /* select the GPU; idempotent */
+int sonic_last_error(char* buf, size_t cap);        /* copies the calling thread's last message */
+int sonic_device_sync(void);
+
+/* ---- Sonic.SRS ---- */
+/* SRS.new :: Int -> Fr -> Fr -> SRS  (SRS.hs:27-43).  Generates, on the GPU, the G1 halves the
+ * prover reads: basis 0 = g^{x^e}, basis 1 = g^{alpha x^e}, e in [-d, d]; slot e = 0 of basis 1 is
+ * empty (g^alpha is not shared, SRS.hs:38).  gNegativeX[k] = basis0[-(k+1)], gPositiveX[k] =
+ * basis0[k], gNegativeAlphaX[k] = basis1[-(k+1)], gPositiveAlphaX[k] = basis1[k+1]. */
+int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out);
+/* the record constructor `SRS{..}`: caller-supplied points, (2d+1) * 96 bytes per basis */
+int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out);
+void sonic_srs_free(sonic_srs_t* srs);
+int64_t sonic_srs_d(const sonic_srs_t* srs);        /* srsD */
+int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out);
+
+/* ---- Sonic.CommitmentScheme ---- */
+/* commitPoly :: SRS -> Int -> VLaurent Fr -> G1  (CommitmentScheme.hs:20-33) */
+int sonic_commit_poly(const sonic_srs_t* srs, int64_t max, int64_t n_terms, const int64_t* exps,
+                      const uint8_t* coeffs, uint8_t out_g1[96]);
+/* openPoly :: SRS -> Fr -> VLaurent Fr -> (Fr, G1)  (CommitmentScheme.hs:36-48) */
+int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms, const int64_t* exps,
+                    const uint8_t* coeffs, uint8_t out_fz[32], uint8_t out_g1[96]);
+
+/* ---- the kernels behind them, exposed for parity tests and the MSM benchmark ---- */
+/* foldl' (\acc (P, v) -> acc <> P `mul` v) mempty  (the fold at CommitmentScheme.hs:26-29, 45-48) */
+int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]);
+/* same over an SRS slice e0 .. e0+n-1 of one basis; scalars on the host */
+int sonic_msm_g1_srs(const sonic_srs_t* srs, int basis, int64_t e0, const uint8_t* scalars, int64_t n,
+                     uint8_t out_g1[96]);
+/* scalars already resident in HBM (canonical 32-byte Fr, device pointer) */
+int sonic_msm_g1_srs_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
+                         uint8_t out_g1[96]);
+/* one rank's share of a range-sharded MSM: the un-normalised partial sum */
+int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars,
+                                 int64_t n, uint8_t out_partial[144]);
+/* curve addition of k partials (RCCL has no such reduction op) + normalisation */
+int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]);
+/* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n) */
+int sonic_ntt_fr(uint8_t* data, int log2n, int inverse);
+/* dense product of two coefficient arrays (the `*` at Constraints.hs:61): out has na+nb-1 Fr */
+int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out);
+/* MSM tuning knob for tests: window bits (0 = automatic) */
+int sonic_msm_set_window(int c);
+
+/* ---- Sonic.Protocol / Sonic.Signature ---- */
+size_t sonic_proof_size(int64_t Q);
+/* prove :: SRS -> Assignment Fr -> ArithCircuit Fr -> m (Proof, RndOracle)  (Protocol.hs:47-109),
+ * including hscProve (Signature.hs:38-72).  n = length aL, Q = length wL. */
+int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR,
+                const uint8_t* wO, const uint8_t* cs, const uint8_t* aL, const uint8_t* aR,
+                const uint8_t* aO, const uint8_t* transcript, uint8_t* out_proof);
+/* the same split so that circuit and assignment stay resident in HBM across proofs */
+int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR,
+                     const uint8_t* wO, const uint8_t* cs, sonic_prover_t** out);
+int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO);
+int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_proof);
+void sonic_prover_free(sonic_prover_t* p);
+
+/* ---- device memory for callers without a HIP binding ---- */
+int sonic_dev_alloc(size_t bytes, void** out);
+int sonic_dev_free(void* p);
+int sonic_dev_upload(void* dst, const void* src, size_t bytes);
+int sonic_dev_download(void* dst, const void* src, size_t bytes);
+
+/* ---- per-kernel HIP-event timing (bench.py's roofline leg) ---- */
+int sonic_profile_enable(int on);
+int sonic_profile_reset(void);
+int sonic_profile_get(const char* kernel, double* total_ms, int64_t* launches);
+int sonic_profile_names(char* buf, size_t cap);     /* newline-separated kernel names seen so far */
+
+#ifdef __cplusplus
+}
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#endif

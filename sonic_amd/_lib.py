@@ -1,0 +1,111 @@
+"""ctypes loader for sonic_amd/csrc/libsonic_hip.so (the C ABI of include/sonic_hip.h).
+
+There is no fallback of any kind: if the HIP extension has not been built, importing the
+product API fails with an ImportError that says how to build it; if no GPU is present every
+entry point returns SONIC_ERR_NO_DEVICE and the Python layer raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsonic_hip.so")
+
+ERR_NAMES = {
+    1: "D_TOO_SMALL", 2: "SRS_INDEX_OUT_OF_RANGE", 3: "BAD_ENCODING", 4: "INEXACT_DIVISION",
+    5: "HIP_ERROR", 6: "NO_DEVICE", 7: "INVALID_ARG",
+}
+
+
+class SonicError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.message = message
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C sonic_amd/csrc). "
+            "sonic_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, cp, i64, i32 = C.c_void_p, C.c_char_p, C.c_int64, C.c_int
+    sig = {
+        "sonic_init": [i32],
+        "sonic_last_error": [cp, C.c_size_t],
+        "sonic_device_sync": [],
+        "sonic_srs_new": [i64, cp, cp, C.POINTER(vp)],
+        "sonic_srs_from_points": [i64, vp, vp, C.POINTER(vp)],
+        "sonic_srs_get_points": [vp, i32, i64, i64, vp],
+        "sonic_commit_poly": [vp, i64, i64, vp, vp, vp],
+        "sonic_open_poly": [vp, cp, i64, vp, vp, vp, vp],
+        "sonic_msm_g1": [vp, vp, i64, vp],
+        "sonic_msm_g1_srs": [vp, i32, i64, vp, i64, vp],
+        "sonic_msm_g1_srs_dev": [vp, i32, i64, vp, i64, vp],
+        "sonic_msm_g1_srs_partial_dev": [vp, i32, i64, vp, i64, vp],
+        "sonic_g1_sum_partials": [vp, i32, vp],
+        "sonic_ntt_fr": [vp, i32, i32],
+        "sonic_poly_mul_fr": [vp, i64, vp, i64, vp],
+        "sonic_msm_set_window": [i32],
+        "sonic_prove": [vp, i64, i64] + [vp] * 9,
+        "sonic_prover_new": [vp, i64, i64, vp, vp, vp, vp, C.POINTER(vp)],
+        "sonic_prover_set_assignment": [vp, vp, vp, vp],
+        "sonic_prover_prove": [vp, vp, vp],
+        "sonic_dev_alloc": [C.c_size_t, C.POINTER(vp)],
+        "sonic_dev_free": [vp],
+        "sonic_dev_upload": [vp, vp, C.c_size_t],
+        "sonic_dev_download": [vp, vp, C.c_size_t],
+        "sonic_profile_enable": [i32],
+        "sonic_profile_reset": [],
+        "sonic_profile_get": [cp, C.POINTER(C.c_double), C.POINTER(i64)],
+        "sonic_profile_names": [cp, C.c_size_t],
+    }
+    missing = [n for n in EXPORTED if not hasattr(L, n)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export {missing}: stale build, rebuild it")
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i32
+    L.sonic_srs_free.argtypes = [vp]
+    L.sonic_srs_free.restype = None
+    L.sonic_prover_free.argtypes = [vp]
+    L.sonic_prover_free.restype = None
+    L.sonic_srs_d.argtypes = [vp]
+    L.sonic_srs_d.restype = i64
+    L.sonic_proof_size.argtypes = [i64]
+    L.sonic_proof_size.restype = C.c_size_t
+    _lib = L
+    return L
+
+
+EXPORTED = [
+    "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_srs_new", "sonic_srs_from_points",
+    "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_commit_poly", "sonic_open_poly",
+    "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
+    "sonic_g1_sum_partials", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window",
+    "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
+    "sonic_prover_prove", "sonic_prover_free", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
+    "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",
+    "sonic_profile_names",
+]
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().sonic_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise SonicError(rc, last_error())

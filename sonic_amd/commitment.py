@@ -1,0 +1,53 @@
+"""Sonic.CommitmentScheme (src/Sonic/CommitmentScheme.hs): commitPoly / openPoly over the GPU MSM."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .encoding import fr_array, fr_to_bytes, g1_from_bytes
+from .srs import SRS
+
+
+def _sparse(poly):
+    """VLaurent Fr as {exponent: coeff}, [(exponent, coeff)], or (int64 exps, uint8 coeffs[k,32])."""
+    if isinstance(poly, tuple) and len(poly) == 2 and isinstance(poly[0], np.ndarray):
+        return np.ascontiguousarray(poly[0], np.int64), fr_array(poly[1])
+    items = sorted(poly.items()) if isinstance(poly, dict) else list(poly)
+    exps = np.array([e for e, _ in items], dtype=np.int64)
+    return exps, fr_array([c for _, c in items])
+
+
+def commit_poly(srs: SRS, maxm: int, poly):
+    """commitPoly :: SRS -> Int -> VLaurent Fr -> G1 (CommitmentScheme.hs:20-33)."""
+    exps, coeffs = _sparse(poly)
+    out = C.create_string_buffer(96)
+    _lib.check(_lib.lib().sonic_commit_poly(srs._h, maxm, len(exps), exps.ctypes.data, coeffs.ctypes.data, out))
+    return g1_from_bytes(out.raw)
+
+
+def open_poly(srs: SRS, z: int, poly):
+    """openPoly :: SRS -> Fr -> VLaurent Fr -> (Fr, G1) (CommitmentScheme.hs:36-48)."""
+    exps, coeffs = _sparse(poly)
+    out = C.create_string_buffer(96)
+    fz = C.create_string_buffer(32)
+    _lib.check(_lib.lib().sonic_open_poly(srs._h, fr_to_bytes(z), len(exps), exps.ctypes.data, coeffs.ctypes.data, fz, out))
+    return int.from_bytes(fz.raw, "little"), g1_from_bytes(out.raw)
+
+
+def msm_g1(points: np.ndarray, scalars) -> bytes:
+    """The fold inside commitPoly/openPoly on caller-supplied points: sum scalars[i] * points[i].
+    points: uint8 [n, 96]; scalars: ints or uint8 [n, 32].  Returns the 96 canonical bytes."""
+    pts = np.ascontiguousarray(points, np.uint8)
+    sc = fr_array(scalars)
+    out = C.create_string_buffer(96)
+    _lib.check(_lib.lib().sonic_msm_g1(pts.ctypes.data, sc.ctypes.data, sc.shape[0], out))
+    return out.raw
+
+
+def msm_g1_srs(srs: SRS, basis: int, e0: int, scalars) -> bytes:
+    sc = fr_array(scalars)
+    out = C.create_string_buffer(96)
+    _lib.check(_lib.lib().sonic_msm_g1_srs(srs._h, basis, e0, sc.ctypes.data, sc.shape[0], out))
+    return out.raw

@@ -1,0 +1,310 @@
+// C ABI of libsonic_hip.so (include/sonic_hip.h): library state, encodings at the boundary,
+// the SRS handle and the standalone MSM / NTT entry points.  prove lives in prove.hip.
+#include <stdarg.h>
+#include <string.h>
+#include "internal.hpp"
+
+namespace sonic {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+Profiler& profiler() { static Profiler p; return p; }
+void Profiler::collect() {
+  std::lock_guard<std::mutex> g(mu);
+  for (auto& kv : recs) {
+    auto& tot = totals[kv.first];
+    for (auto& r : kv.second) {
+      hipEventSynchronize(r.b);
+      float ms = 0;
+      hipEventElapsedTime(&ms, r.a, r.b);
+      tot.first += ms; tot.second += 1;
+      hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    kv.second.clear();
+  }
+}
+void Profiler::reset() { collect(); std::lock_guard<std::mutex> g(mu); totals.clear(); }
+
+static std::mutex g_init_mu;
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static std::mutex g_call_mu;            // standalone entry points share one workspace
+static MsmWorkspace* g_msm_ws = nullptr;
+
+void require_device() {
+  std::lock_guard<std::mutex> g(g_init_mu);
+  if (g_device >= 0) { HIP_OK(hipSetDevice(g_device)); return; }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device available (%s): libsonic_hip has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    throw HipFail{SONIC_ERR_NO_DEVICE};
+  }
+  int dev = 0;
+  const char* lr = getenv("LOCAL_RANK");
+  if (lr) dev = atoi(lr) % n;
+  HIP_OK(hipSetDevice(dev));
+  HIP_OK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_device = dev;
+}
+hipStream_t default_stream() { return g_stream; }
+MsmWorkspace& shared_msm_ws() { if (!g_msm_ws) g_msm_ws = new MsmWorkspace(); return *g_msm_ws; }
+std::mutex& call_mutex() { return g_call_mu; }
+
+// ---- encodings ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, long n, int* err) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(in + 96 * i);
+  G1Affine p;
+  for (int k = 0; k < 12; k++) { p.x.l[k] = w[k]; p.y.l[k] = w[12 + k]; }
+  if (p.is_inf()) { out[i] = p; return; }
+  if (!fp_is_canonical(p.x) || !fp_is_canonical(p.y)) { atomicOr(err, 1); out[i] = G1Affine::inf(); return; }
+  p.x = fp_to_mont(p.x); p.y = fp_to_mont(p.y);
+  Fq four = fp_dbl(fp_dbl(Fq::one()));
+  if (fp_sqr(p.y) != fp_add(fp_mul(fp_sqr(p.x), p.x), four)) { atomicOr(err, 2); out[i] = G1Affine::inf(); return; }
+  out[i] = p;
+}
+__global__ __launch_bounds__(256) void k_points_to_bytes(const G1Affine* __restrict__ in, uint8_t* __restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p = in[i];
+  uint32_t* w = reinterpret_cast<uint32_t*>(out + 96 * i);
+  if (p.is_inf()) { for (int k = 0; k < 24; k++) w[k] = 0; return; }
+  Fq x = fp_from_mont(p.x), y = fp_from_mont(p.y);
+  for (int k = 0; k < 12; k++) { w[k] = x.l[k]; w[12 + k] = y.l[k]; }
+}
+__global__ __launch_bounds__(256) void k_fr_check(const Fr* __restrict__ in, long n, int* err) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr a = in[i];
+  if (!fp_is_canonical(a)) atomicOr(err, 1);
+}
+__global__ __launch_bounds__(256) void k_fr_to_mont(Fr* __restrict__ a, long n, int* err) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr v = a[i];
+  if (!fp_is_canonical(v)) { atomicOr(err, 1); return; }
+  a[i] = fp_to_mont(v);
+}
+__global__ __launch_bounds__(256) void k_fr_from_mont(Fr* __restrict__ a, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  a[i] = fp_from_mont(a[i]);
+}
+
+void fr_to_mont_enqueue(hipStream_t st, Fr* d, long n, int* d_err) { if (n > 0) LAUNCH(k_fr_to_mont, ceil_div(n, 256), 256, 0, st, d, n, d_err); }
+void fr_from_mont_enqueue(hipStream_t st, Fr* d, long n) { if (n > 0) LAUNCH(k_fr_from_mont, ceil_div(n, 256), 256, 0, st, d, n); }
+void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err) { if (n > 0) LAUNCH(k_fr_check, ceil_div(n, 256), 256, 0, st, d, n, d_err); }
+
+// one MSM, finished and normalised, result on the host
+void msm_blocking(hipStream_t st, MsmWorkspace& ws, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
+                  uint8_t* out96, uint8_t* out_partial144) {
+  MsmPlan pl = msm_plan(n > 0 ? n : 1);
+  DevBuf slot(sizeof(MsmSlot));
+  msm_enqueue(st, ws, pl, d_pts, d_sc, n, mont, slot.as<MsmSlot>());
+  MsmSlot h;
+  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof(int) * 4 + sizeof(G1XYZZ) * pl.W, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  G1XYZZ sum = msm_finish_host(h);
+  if (out96) g1_canonical_bytes_host(sum, out96);
+  if (out_partial144) memcpy(out_partial144, &sum, sizeof sum);
+}
+
+}  // namespace sonic
+
+using namespace sonic;
+
+#define API_BEGIN try { require_device();
+#define API_END                                                        \
+  } catch (const HipFail& f) { return f.code; }                        \
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; } \
+  return SONIC_OK;
+
+struct sonic_srs {
+  int64_t d;
+  DevBuf g, ga;      // G1Affine[2d+1]: slot e + d holds the point for exponent e
+  const G1Affine* basis(int b) const { return (b ? ga : g).as<G1Affine>(); }
+};
+
+namespace sonic {
+const G1Affine* srs_basis(const sonic_srs* s, int b) { return s->basis(b); }
+int64_t srs_d(const sonic_srs* s) { return s->d; }
+sonic_srs* srs_alloc(int64_t d) {
+  sonic_srs* s = new sonic_srs();
+  s->d = d;
+  s->g.alloc(sizeof(G1Affine) * (2 * d + 1));
+  s->ga.alloc(sizeof(G1Affine) * (2 * d + 1));
+  return s;
+}
+G1Affine* srs_basis_mut(sonic_srs* s, int b) { return (b ? s->ga : s->g).as<G1Affine>(); }
+}  // namespace sonic
+
+extern "C" {
+
+int sonic_init(int device_ordinal) {
+  try {
+    {
+      std::lock_guard<std::mutex> g(g_init_mu);
+      if (g_device < 0 && device_ordinal >= 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) { set_error("no HIP device available: libsonic_hip has no CPU fallback"); return SONIC_ERR_NO_DEVICE; }
+        if (device_ordinal >= n) { set_error("device %d out of range (%d devices)", device_ordinal, n); return SONIC_ERR_INVALID_ARG; }
+        HIP_OK(hipSetDevice(device_ordinal));
+        HIP_OK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        g_device = device_ordinal;
+      }
+    }
+    require_device();
+  } catch (const HipFail& f) { return f.code; }
+  return SONIC_OK;
+}
+
+int sonic_last_error(char* buf, size_t cap) {
+  if (!buf || cap == 0) return SONIC_ERR_INVALID_ARG;
+  strncpy(buf, g_err, cap - 1);
+  buf[cap - 1] = 0;
+  return SONIC_OK;
+}
+
+int sonic_device_sync(void) { API_BEGIN HIP_OK(hipStreamSynchronize(default_stream())); HIP_OK(hipDeviceSynchronize()); API_END }
+
+int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out) {
+  API_BEGIN
+  if (d < 1 || !basis0 || !basis1 || !out) { set_error("sonic_srs_from_points: bad argument"); return SONIC_ERR_INVALID_ARG; }
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  const long n = 2 * d + 1;
+  sonic_srs* s = srs_alloc(d);
+  DevBuf raw(96 * n), err(4);
+  HIP_OK(hipMemsetAsync(err.p, 0, 4, st));
+  for (int b = 0; b < 2; b++) {
+    HIP_OK(hipMemcpyAsync(raw.p, b ? basis1 : basis0, 96 * n, hipMemcpyHostToDevice, st));
+    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), srs_basis_mut(s, b), n, err.as<int>());
+  }
+  int herr = 0;
+  HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  if (herr) { delete s; set_error("sonic_srs_from_points: %s", (herr & 1) ? "non-canonical coordinate" : "point not on curve"); return SONIC_ERR_BAD_ENCODING; }
+  *out = s;
+  API_END
+}
+
+void sonic_srs_free(sonic_srs_t* srs) { delete srs; }
+int64_t sonic_srs_d(const sonic_srs_t* srs) { return srs ? srs->d : -1; }
+
+int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out) {
+  API_BEGIN
+  if (!srs || !out || n < 0) return SONIC_ERR_INVALID_ARG;
+  if (e0 < -srs->d || e0 + n - 1 > srs->d) { set_error("sonic_srs_get_points: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
+  if (n == 0) return SONIC_OK;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  DevBuf raw(96 * n);
+  LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs->basis(basis) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
+  HIP_OK(hipMemcpyAsync(out, raw.p, 96 * n, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  API_END
+}
+
+int sonic_msm_set_window(int c) { msm_set_window_override(c); return SONIC_OK; }
+
+int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]) {
+  API_BEGIN
+  if (n < 0 || !out_g1 || (n > 0 && (!points || !scalars))) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  const long m = n > 0 ? n : 1;
+  DevBuf raw(96 * m), pts(sizeof(G1Affine) * m), sc(32 * m), err(4);
+  HIP_OK(hipMemsetAsync(err.p, 0, 4, st));
+  if (n > 0) {
+    HIP_OK(hipMemcpyAsync(raw.p, points, 96 * n, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(sc.p, scalars, 32 * n, hipMemcpyHostToDevice, st));
+    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), pts.as<G1Affine>(), (long)n, err.as<int>());
+    fr_check_enqueue(st, sc.as<Fr>(), n, err.as<int>());
+  }
+  int herr = 0;
+  HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  if (herr) { set_error("sonic_msm_g1: non-canonical input or point not on curve"); return SONIC_ERR_BAD_ENCODING; }
+  msm_blocking(st, shared_msm_ws(), pts.as<G1Affine>(), sc.as<Fr>(), n, false, out_g1, nullptr);
+  API_END
+}
+
+static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, const uint8_t* h_scalars,
+                          int64_t n, uint8_t* out96, uint8_t* out144) {
+  API_BEGIN
+  if (!srs || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
+  if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  DevBuf sc, err(4);
+  const Fr* dsc = static_cast<const Fr*>(d_scalars);
+  HIP_OK(hipMemsetAsync(err.p, 0, 4, st));
+  if (h_scalars && n > 0) {
+    sc.alloc(32 * n);
+    HIP_OK(hipMemcpyAsync(sc.p, h_scalars, 32 * n, hipMemcpyHostToDevice, st));
+    dsc = sc.as<Fr>();
+  }
+  fr_check_enqueue(st, dsc, n, err.as<int>());
+  int herr = 0;
+  HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  if (herr) { set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
+  msm_blocking(st, shared_msm_ws(), srs->basis(basis) + (e0 + srs->d), dsc, n, false, out96, out144);
+  API_END
+}
+
+int sonic_msm_g1_srs(const sonic_srs_t* srs, int basis, int64_t e0, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]) {
+  return msm_srs_common(srs, basis, e0, nullptr, scalars, n, out_g1, nullptr);
+}
+int sonic_msm_g1_srs_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, uint8_t out_g1[96]) {
+  return msm_srs_common(srs, basis, e0, d_scalars, nullptr, n, out_g1, nullptr);
+}
+int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, uint8_t out_partial[144]) {
+  return msm_srs_common(srs, basis, e0, d_scalars, nullptr, n, nullptr, out_partial);
+}
+
+int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]) {
+  if (!partials || k < 1 || !out_g1) return SONIC_ERR_INVALID_ARG;
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int i = 0; i < k; i++) { G1XYZZ p; memcpy(&p, partials + sizeof(G1XYZZ) * i, sizeof p); acc = g1_add(acc, p); }
+  g1_canonical_bytes_host(acc, out_g1);
+  return SONIC_OK;
+}
+
+int sonic_dev_alloc(size_t bytes, void** out) { API_BEGIN if (!out) return SONIC_ERR_INVALID_ARG; HIP_OK(hipMalloc(out, bytes ? bytes : 16)); API_END }
+int sonic_dev_free(void* p) { API_BEGIN HIP_OK(hipFree(p)); API_END }
+int sonic_dev_upload(void* dst, const void* src, size_t bytes) { API_BEGIN HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); API_END }
+int sonic_dev_download(void* dst, const void* src, size_t bytes) { API_BEGIN HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); API_END }
+
+int sonic_profile_enable(int on) { profiler().on = on != 0; return SONIC_OK; }
+int sonic_profile_reset(void) { profiler().reset(); return SONIC_OK; }
+int sonic_profile_get(const char* kernel, double* total_ms, int64_t* launches) {
+  if (!kernel) return SONIC_ERR_INVALID_ARG;
+  profiler().collect();
+  std::lock_guard<std::mutex> g(profiler().mu);
+  auto it = profiler().totals.find(kernel);
+  if (total_ms) *total_ms = it == profiler().totals.end() ? 0.0 : it->second.first;
+  if (launches) *launches = it == profiler().totals.end() ? 0 : it->second.second;
+  return SONIC_OK;
+}
+int sonic_profile_names(char* buf, size_t cap) {
+  if (!buf || cap == 0) return SONIC_ERR_INVALID_ARG;
+  profiler().collect();
+  std::lock_guard<std::mutex> g(profiler().mu);
+  std::string s;
+  for (auto& kv : profiler().totals) { s += kv.first; s += "\n"; }
+  strncpy(buf, s.c_str(), cap - 1);
+  buf[cap - 1] = 0;
+  return SONIC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Cross-translation-unit declarations inside libsonic_hip.so.
+#pragma once
+#include "common.hpp"
+#include "g1.hpp"
+#include "msm.hpp"
+
+struct sonic_srs;
+
+namespace sonic {
+
+hipStream_t default_stream();
+MsmWorkspace& shared_msm_ws();
+std::mutex& call_mutex();
+
+// SRS handle internals (api.hip)
+const G1Affine* srs_basis(const sonic_srs* s, int b);
+G1Affine* srs_basis_mut(sonic_srs* s, int b);
+int64_t srs_d(const sonic_srs* s);
+sonic_srs* srs_alloc(int64_t d);
+
+// encodings (api.hip)
+void fr_to_mont_enqueue(hipStream_t st, Fr* d, long n, int* d_err);
+void fr_from_mont_enqueue(hipStream_t st, Fr* d, long n);
+void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err);
+void msm_blocking(hipStream_t st, MsmWorkspace& ws, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
+                  uint8_t* out96, uint8_t* out_partial144);
+
+// SRS generation (srs.hip): fills both bases of `s` from x, alpha (standard-form Fr on the host)
+void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha_std);
+
+// NTT (ntt.hip).  Data in Montgomery form, in place.  forward: natural -> bit-reversed;
+// inverse: bit-reversed -> natural, scaled by 1/n.
+struct NttTables {
+  int log2n = 0;
+  DevBuf fwd, inv;    // n/2 twiddles each: w^k, w^-k (Montgomery)
+  DevBuf ninv;        // (2^k)^-1, k = 0..32
+  void ensure(hipStream_t st, int log2n);
+};
+void ntt_forward_enqueue(hipStream_t st, const NttTables& tw, Fr* d, int log2n);
+void ntt_inverse_enqueue(hipStream_t st, const NttTables& tw, Fr* d, int log2n);
+void fr_pointwise_mul_enqueue(hipStream_t st, Fr* a, const Fr* b, long n);
+void fr_scale_enqueue(hipStream_t st, Fr* a, long n, const Fr* d_s);
+void fr_bitrev_permute_enqueue(hipStream_t st, Fr* d, int log2n);
+
+// polynomial kernels (poly.hip); all Fr arrays Montgomery, dense over an exponent range
+// out[i] = in[i] * x^(e0 + i)
+void poly_scale_powers_enqueue(hipStream_t st, const Fr* in, Fr* out, long n, long e0, const Fr* d_x, const Fr* d_xinv);
+// inclusive prefix sums in Fr, in place; tmp >= ceil(n/1024)+1 Fr
+void poly_prefix_sum_enqueue(hipStream_t st, Fr* d, long n, DevBuf& tmp);
+// quotient of (f - f(z)) / (X - z) from d = f_e z^e and its prefix sums P (see poly.hip)
+void poly_quotient_enqueue(hipStream_t st, const Fr* prefix, Fr* q, long n, long lo, const Fr* d_z, const Fr* d_zinv);
+
+}  // namespace sonic

@@ -1,0 +1,340 @@
+// G1 multi-scalar multiplication for gfx950: the kernel behind commitPoly / openPoly.
+//
+// Reference: the two folds  foldl' (\acc (e,v) -> acc <> (B[e] `mul` v)) mempty  at
+// src/Sonic/CommitmentScheme.hs:25-29 (alpha basis) and :45-48 (plain basis): per-term 255-bit
+// double-and-add.  Here: Pippenger's bucket method, laid out for one MI355X.
+//
+//   1. k_msm_digits    one thread per scalar: fold s into [0,(r-1)/2] (negating the point
+//                      instead), signed base-2^c digits, histogram per (window, |digit|) with the
+//                      atomic's return value kept as the entry's rank inside its bucket
+//   2. scan            exclusive scan of the W * 2^(c-1) bucket sizes
+//   3. k_msm_scatter   counting-sort scatter: entries[off[bucket] + rank] = point index | sign
+//   4. k_bucket_accum  one thread per bucket walks its entries: affine point gathered from HBM
+//                      (96 B contiguous), XYZZ mixed addition.  Buckets far above the mean (the
+//                      protocol produces them: s(X,y) has n equal coefficients when a weight row
+//                      is all ones, test/Test/Reference.hs:143-145) are split into 4096-entry
+//                      items, each reduced by a whole workgroup through LDS (k_heavy_accum)
+//   5. k_bucket_segments / k_window_sum   sum_b b*B_b per window by running sums over K-bucket
+//                      segments, then an LDS tree per window
+//   6. host tail       Horner over the W window sums + normalisation to the canonical affine
+//                      bytes (msm_finish_host): O(W) sequential work, deferred by the caller
+//
+// Algorithmic traffic: 96 B point + 32 B scalar per term read once from HBM per window pass;
+// the kernel is integer-issue bound (v_mad_u64_u32), not HBM bound -- see DESIGN.md.
+#include <string.h>
+#include "msm.hpp"
+
+namespace sonic {
+
+static int g_window_override = 0;
+int msm_window_override() { return g_window_override; }
+void msm_set_window_override(int c) { g_window_override = c; }
+
+static constexpr uint32_t HEAVY_SEG = 4096;   // entries per heavy work item
+static constexpr int HEAVY_GRID = 1024;
+
+struct HeavyMeta { uint32_t n_items, n_heavy; };
+struct HeavyRec { uint32_t bucket, base, nseg; };
+struct HeavyItem { uint32_t bucket, seg; };
+
+MsmPlan msm_plan(long n) {
+  MsmPlan p;
+  int lg = 0;
+  while ((1L << (lg + 1)) <= n) lg++;
+  int c = lg - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  if (g_window_override >= 4 && g_window_override <= 16) c = g_window_override;
+  p.c = c;
+  p.W = (255 + c - 1) / c;
+  p.NB = 1 << (c - 1);
+  p.K = p.NB < 16 ? p.NB : 16;
+  p.nseg = p.NB / p.K;
+  long mean = n / p.NB;
+  long t = 8 * mean;
+  if (t < 256) t = 256;
+  p.heavy_threshold = (uint32_t)t;
+  return p;
+}
+
+void MsmWorkspace::reserve(long n, const MsmPlan& pl) {
+  size_t M = (size_t)pl.W * pl.NB;
+  size_t NW = (size_t)n * pl.W;
+  count.ensure((M + 1) * 4);
+  off.ensure((M + 1) * 4);
+  digits.ensure(NW * 4);
+  rank.ensure(NW * 4);
+  entries.ensure(NW * 4);
+  buckets.ensure(M * sizeof(G1XYZZ));
+  segres.ensure((size_t)pl.W * pl.nseg * sizeof(G1XYZZ));
+  scan_tmp.ensure((M / 2048 + 2) * 4);
+  size_t max_heavy = NW / pl.heavy_threshold + 1;
+  size_t max_items = NW / HEAVY_SEG + max_heavy + 1;
+  heavy_meta.ensure(sizeof(HeavyMeta) + max_heavy * sizeof(HeavyRec));
+  heavy_items.ensure(max_items * sizeof(HeavyItem));
+  heavy_partial.ensure(max_items * sizeof(G1XYZZ));
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fr_gt_half(const Fr& s) {
+  constexpr uint32_t half[8] = FR_HALF;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    if (s.l[i] > half[i]) return true;
+    if (s.l[i] < half[i]) return false;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, long n, int c, int W, int NB, int mont,
+                                                    uint32_t* __restrict__ count, uint32_t* __restrict__ digits,
+                                                    uint32_t* __restrict__ rank) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = sc[i];
+  if (mont) s = fp_from_mont(s);
+  const bool neg = fr_gt_half(s);
+  if (neg) s = fp_neg(s);            // r - s, still standard form
+  const uint32_t mask = (1u << c) - 1;
+  const uint32_t half = 1u << (c - 1);
+  uint32_t carry = 0;
+  for (int w = 0; w < W; w++) {
+    uint32_t d = (s.l[0] & mask) + carry;
+    // shift the scalar right by c bits (static limb indices keep it in registers)
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));
+    s.l[7] >>= c;
+    uint32_t sign = neg ? 1u : 0u;
+    if (d > half) { d = (1u << c) - d; carry = 1; sign ^= 1u; } else carry = 0;
+    uint32_t out = 0, rk = 0;
+    if (d) {
+      rk = atomicAdd(&count[(size_t)w * NB + d - 1], 1u);
+      out = d | (sign << 31);
+    }
+    digits[(size_t)w * n + i] = out;
+    rank[(size_t)w * n + i] = rk;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_msm_scatter(long n, int W, int NB, const uint32_t* __restrict__ digits,
+                                                     const uint32_t* __restrict__ rank, const uint32_t* __restrict__ off,
+                                                     uint32_t* __restrict__ entries) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int w = 0; w < W; w++) {
+    uint32_t dg = digits[(size_t)w * n + i];
+    if (!dg) continue;
+    uint32_t key = (uint32_t)w * NB + (dg & 0x7fffffffu) - 1;
+    entries[off[key] + rank[(size_t)w * n + i]] = (uint32_t)i | (dg & 0x80000000u);
+  }
+}
+
+// ---- exclusive scan of u32 (three small kernels; tile = 2048) -------------------------------
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sh, uint32_t* total) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    uint32_t x = t >= o ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  uint32_t incl = sh[t];
+  if (total) *total = sh[255];
+  __syncthreads();
+  return incl - v;
+}
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* in, size_t m, uint32_t* tile_sums) {
+  __shared__ uint32_t sh[256];
+  size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x * 8;
+  uint32_t s = 0;
+  for (int k = 0; k < 8; k++) if (base + k < m) s += in[base + k];
+  uint32_t tot;
+  block_exclusive_scan_256(s, sh, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_scan_top(uint32_t* tile_sums, int ntiles, uint32_t* total_out) {
+  __shared__ uint32_t sh[256];
+  __shared__ uint32_t carry_sh;
+  if (threadIdx.x == 0) carry_sh = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 256) {
+    int idx = base + threadIdx.x;
+    uint32_t v = idx < ntiles ? tile_sums[idx] : 0, tot;
+    uint32_t ex = block_exclusive_scan_256(v, sh, &tot);
+    uint32_t carry = carry_sh;
+    if (idx < ntiles) tile_sums[idx] = ex + carry;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_sh = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry_sh;
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, size_t m, const uint32_t* tile_sums, uint32_t* out) {
+  __shared__ uint32_t sh[256];
+  size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x * 8;
+  uint32_t v[8], s = 0;
+  for (int k = 0; k < 8; k++) { v[k] = base + k < m ? in[base + k] : 0; s += v[k]; }
+  uint32_t ex = block_exclusive_scan_256(s, sh, nullptr) + tile_sums[blockIdx.x];
+  for (int k = 0; k < 8; k++) { if (base + k < m) out[base + k] = ex; ex += v[k]; }
+}
+
+// ---- bucket accumulation ---------------------------------------------------------------------
+__device__ __forceinline__ G1Affine load_point_signed(const G1Affine* __restrict__ pts, uint32_t e) {
+  G1Affine p = pts[e & 0x7fffffffu];
+  if (e >> 31) p.y = fp_neg(p.y);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void k_bucket_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
+                                                      const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t heavy_t,
+                                                      G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs,
+                                                      HeavyItem* items) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const uint32_t beg = off[b], end = off[b + 1];
+  const uint32_t cnt = end - beg;
+  if (cnt > heavy_t) {
+    uint32_t ns = (cnt + HEAVY_SEG - 1) / HEAVY_SEG;
+    uint32_t base = atomicAdd(&hm->n_items, ns);
+    uint32_t h = atomicAdd(&hm->n_heavy, 1u);
+    hrecs[h] = HeavyRec{b, base, ns};
+    for (uint32_t k = 0; k < ns; k++) items[base + k] = HeavyItem{b, k};
+    return;
+  }
+  G1XYZZ acc = G1XYZZ::inf();
+  for (uint32_t e = beg; e < end; e++) acc = g1_add_mixed(acc, load_point_signed(pts, entries[e]));
+  buckets[b] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_heavy_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
+                                                     const uint32_t* __restrict__ off, const HeavyMeta* hm,
+                                                     const HeavyItem* items, G1XYZZ* __restrict__ partial) {
+  __shared__ G1XYZZ sh[256];
+  const uint32_t n_items = hm->n_items;
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const HeavyItem item = items[it];
+    const uint32_t beg = off[item.bucket] + item.seg * HEAVY_SEG;
+    uint32_t end = beg + HEAVY_SEG;
+    const uint32_t bend = off[item.bucket + 1];
+    if (end > bend) end = bend;
+    G1XYZZ acc = G1XYZZ::inf();
+    for (uint32_t e = beg + threadIdx.x; e < end; e += 256) acc = g1_add_mixed(acc, load_point_signed(pts, entries[e]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+      if ((int)threadIdx.x < s) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[it] = sh[0];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void k_heavy_finish(const HeavyMeta* hm, const HeavyRec* hrecs, const G1XYZZ* __restrict__ partial,
+                                                     G1XYZZ* __restrict__ buckets) {
+  const uint32_t n_heavy = hm->n_heavy;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heavy; h += gridDim.x * blockDim.x) {
+    HeavyRec r = hrecs[h];
+    G1XYZZ acc = G1XYZZ::inf();
+    for (uint32_t k = 0; k < r.nseg; k++) acc = g1_add(acc, partial[r.base + k]);
+    buckets[r.bucket] = acc;
+  }
+}
+
+// ---- bucket reduction: sum_b (b+1) * B_b per window -----------------------------------------
+__global__ __launch_bounds__(64) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg,
+                                                        G1XYZZ* __restrict__ segres) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= W * nseg) return;
+  const int w = t / nseg, sg = t % nseg;
+  const int k0 = sg * K;
+  const G1XYZZ* B = buckets + (size_t)w * NB + k0;
+  G1XYZZ run = G1XYZZ::inf(), tot = G1XYZZ::inf();
+  for (int j = K - 1; j >= 0; j--) {
+    run = g1_add(run, B[j]);
+    tot = g1_add(tot, run);          // ends as sum_j (j+1) B[j]
+  }
+  if (k0) tot = g1_add(tot, g1_mul_small(run, (uint32_t)k0));
+  segres[t] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_window_sum(const G1XYZZ* __restrict__ segres, int W, int c, int nseg, MsmSlot* slot) {
+  __shared__ G1XYZZ sh[256];
+  const int w = blockIdx.x;
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int s = threadIdx.x; s < nseg; s += 256) acc = g1_add(acc, segres[(size_t)w * nseg + s]);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    slot->win[w] = sh[0];
+    if (w == 0) { slot->W = W; slot->c = c; }
+  }
+}
+
+// ---- tail (host) -----------------------------------------------------------------------------
+// What is left of an MSM after the bulk kernels is W <= 64 window sums: Horner over the windows
+// (255 dependent doublings) and one Fq inversion for the canonical affine form.  That is ~2600
+// strictly sequential Fq products -- ~10 ms on one GPU lane (measured), ~0.5 ms on a host core --
+// so the host layer finishes it, with the same limb code (g1.hpp compiles for both sides).
+G1XYZZ msm_finish_host(const MsmSlot& s) {
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int w = s.W - 1; w >= 0; w--) {
+    for (int j = 0; j < s.c; j++) acc = g1_dbl(acc);
+    acc = g1_add(acc, s.win[w]);
+  }
+  return acc;
+}
+void g1_canonical_bytes_host(const G1XYZZ& p, uint8_t* out) {
+  G1Affine a = g1_to_affine(p);
+  uint32_t w[24];
+  if (a.is_inf()) { for (int i = 0; i < 24; i++) w[i] = 0; }
+  else {
+    Fq x = fp_from_mont(a.x), y = fp_from_mont(a.y);
+    for (int i = 0; i < 12; i++) { w[i] = x.l[i]; w[12 + i] = y.l[i]; }
+  }
+  memcpy(out, w, 96);
+}
+
+// ---------------------------------------------------------------------------------------------
+void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points, const Fr* d_scalars,
+                 long n, bool scalars_mont, MsmSlot* d_slot) {
+  ws.reserve(n > 0 ? n : 1, pl);
+  const size_t M = (size_t)pl.W * pl.NB;
+  uint32_t* count = ws.count.as<uint32_t>();
+  uint32_t* off = ws.off.as<uint32_t>();
+  HeavyMeta* hm = ws.heavy_meta.as<HeavyMeta>();
+  HeavyRec* hrecs = reinterpret_cast<HeavyRec*>(hm + 1);
+  HIP_OK(hipMemsetAsync(count, 0, (M + 1) * 4, st));
+  HIP_OK(hipMemsetAsync(hm, 0, sizeof(HeavyMeta), st));
+  if (n > 0) {
+    LAUNCH(k_msm_digits, ceil_div(n, 256), 256, 0, st, d_scalars, n, pl.c, pl.W, pl.NB, (int)scalars_mont, count,
+           ws.digits.as<uint32_t>(), ws.rank.as<uint32_t>());
+  }
+  const int ntiles = ceil_div((long)M + 1, 2048);
+  uint32_t* tiles = ws.scan_tmp.as<uint32_t>();
+  LAUNCH(k_scan_tile_sums, ntiles, 256, 0, st, (const uint32_t*)count, M + 1, tiles);
+  LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ntiles, tiles + ntiles);
+  LAUNCH(k_scan_apply, ntiles, 256, 0, st, (const uint32_t*)count, M + 1, (const uint32_t*)tiles, off);
+  if (n > 0) {
+    LAUNCH(k_msm_scatter, ceil_div(n, 256), 256, 0, st, n, pl.W, pl.NB, (const uint32_t*)ws.digits.as<uint32_t>(),
+           (const uint32_t*)ws.rank.as<uint32_t>(), (const uint32_t*)off, ws.entries.as<uint32_t>());
+  }
+  LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(),
+         (const uint32_t*)off, (uint32_t)M, pl.heavy_threshold, ws.buckets.as<G1XYZZ>(), hm, hrecs,
+         ws.heavy_items.as<HeavyItem>());
+  LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
+         (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
+  LAUNCH(k_heavy_finish, 64, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
+         (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), ws.buckets.as<G1XYZZ>());
+  LAUNCH(k_bucket_segments, ceil_div((long)pl.W * pl.nseg, 64), 64, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), pl.W,
+         pl.NB, pl.K, pl.nseg, ws.segres.as<G1XYZZ>());
+  LAUNCH(k_window_sum, pl.W, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), pl.W, pl.c, pl.nseg, d_slot);
+}
+
+}  // namespace sonic

@@ -1,0 +1,45 @@
+// Internal interface of the G1 multi-scalar multiplication (msm.hip).
+#pragma once
+#include "common.hpp"
+#include "g1.hpp"
+
+namespace sonic {
+
+struct MsmPlan {
+  int c;        // window bits
+  int W;        // windows: ceil(255 / c) (scalars are first folded into [0, (r-1)/2])
+  int NB;       // buckets per window: digit magnitudes 1 .. 2^(c-1)
+  int K;        // buckets per running-sum segment
+  int nseg;     // segments per window
+  uint32_t heavy_threshold;
+};
+MsmPlan msm_plan(long n);
+
+constexpr int MSM_MAX_WINDOWS = 64;
+
+// Per-MSM hand-off between the bulk kernels and the (deferred, batched) tail: the per-window sums.
+struct MsmSlot {
+  int W, c, pad0, pad1;
+  G1XYZZ win[MSM_MAX_WINDOWS];
+};
+
+struct MsmWorkspace {
+  DevBuf count, off, digits, rank, entries, buckets, segres, scan_tmp, heavy_meta, heavy_items, heavy_partial;
+  void reserve(long n, const MsmPlan& pl);
+};
+
+// Queues one MSM on `st`: sum_i scalars[i] * points[i].  `scalars_mont` tells whether the Fr
+// values are in Montgomery form (polynomial coefficient arrays are) or standard form (ABI inputs).
+// Writes the W per-window sums into *d_slot.
+void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points,
+                 const Fr* d_scalars, long n, bool scalars_mont, MsmSlot* d_slot);
+
+// Host tail: Horner over the slot's window sums -> un-normalised XYZZ sum.
+G1XYZZ msm_finish_host(const MsmSlot& s);
+// canonical 96-byte encoding (one Fq inversion), on the host
+void g1_canonical_bytes_host(const G1XYZZ& p, uint8_t* out96);
+
+int msm_window_override();
+void msm_set_window_override(int c);
+
+}  // namespace sonic

@@ -1,0 +1,271 @@
+// Laurent-polynomial kernels of the prover, on dense Fr coefficient arrays (Montgomery form) over
+// an exponent range [lo, lo + n).  The reference works on sparse (exponent, coeff) lists
+// (poly-0.4.0.0); every operation here is result-exact, zeros simply stay in the array.
+//
+//   scale by powers     c_e <- c_e x^e        evalY on the diagonal r(X,Y) (src/Sonic/Utils.hs:20-21
+//                                              with Constraints.hs:23-31), and the first half of eval
+//   prefix sums         P_j = sum_{e<=j} c_e z^e   -> f(z) = P_hi         (`eval`, CommitmentScheme.hs:43)
+//   quotient            w_j = z^{-1-j} (f(z) - P_j)  (j >= 0),  -z^{-1-j} P_j  (j < 0)
+//                       = (f(X) - f(z)) / (X - z)                          (`divide`, CommitmentScheme.hs:44)
+//   s(X,y), s(u,Y)      evalY / evalX of sPoly (Constraints.hs:34-53, Utils.hs:17-21)
+//
+// Quotient identity: for e > 0, (X^e - z^e)/(X - z) = sum_{k<e} X^k z^{e-1-k}; for e < 0,
+// (X^e - z^e)/(X - z) = -sum_{m=1..|e|} X^{-m} z^{e+m-1}.  Collecting the coefficient of X^j gives
+// the two prefix-sum forms above, so openPoly is one elementwise pass, one additive scan and one
+// more elementwise pass -- no sequential Horner chain.
+#include "internal.hpp"
+#include "poly.hpp"
+
+namespace sonic {
+
+// out[i] = v(i) * x^(e0 + i); v(i) depends on mode:
+//   0: in[i]                     1: 1 (pure power table)
+//   2: quotient numerator: j = lo_q + i >= 0 ? F - P[i] : -P[i], with F = in[nF-1] (the last prefix)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scale_powers(const Fr* __restrict__ in, Fr* __restrict__ out, long n, long e0,
+                                                      const Fr* __restrict__ px, const Fr* __restrict__ pxinv, long lo_q, long nF) {
+  constexpr int PER = 8;                       // elements per thread, strided by the block size
+  const long base = (long)blockIdx.x * (256 * PER) + threadIdx.x;
+  if (base >= n) return;
+  const Fr x = *px, xinv = *pxinv;
+  const long e = e0 + base;
+  Fr p = e >= 0 ? fp_pow_u64(x, (uint64_t)e) : fp_pow_u64(xinv, (uint64_t)(-e));
+  const Fr step = fp_pow_u64(x, 256);
+  Fr F;
+  if (MODE == 2) F = in[nF - 1];
+#pragma unroll 1
+  for (int k = 0; k < PER; k++) {
+    const long i = base + (long)k * 256;
+    if (i >= n) break;
+    Fr v;
+    if (MODE == 0) v = fp_mul(in[i], p);
+    else if (MODE == 1) v = p;
+    else { Fr P = in[i]; v = fp_mul((lo_q + i >= 0) ? fp_sub(F, P) : fp_neg(P), p); }
+    out[i] = v;
+    p = fp_mul(p, step);
+  }
+}
+
+void poly_scale_powers_enqueue(hipStream_t st, const Fr* in, Fr* out, long n, long e0, const Fr* d_x, const Fr* d_xinv) {
+  if (n <= 0) return;
+  if (in) LAUNCH(k_scale_powers<0>, ceil_div(n, 2048), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
+  else LAUNCH(k_scale_powers<1>, ceil_div(n, 2048), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
+}
+
+// q[i] (exponent lo + i, i < n - 1) from the prefix sums P (n entries, exponents lo .. lo + n - 1)
+void poly_quotient_enqueue(hipStream_t st, const Fr* prefix, Fr* q, long n, long lo, const Fr* d_z, const Fr* d_zinv) {
+  if (n <= 1) return;
+  // z^{-1-j} = (z^-1)^{1+j}: base z^-1 (inverse base z), first exponent 1 + lo
+  LAUNCH(k_scale_powers<2>, ceil_div(n - 1, 2048), 256, 0, st, prefix, q, n - 1, 1 + lo, d_zinv, d_z, lo, n);
+}
+
+// ---- inclusive prefix sums in Fr (tile = 1024) -----------------------------------------------
+__device__ __forceinline__ Fr block_inclusive_scan_fr(Fr v, Fr* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    Fr x = t >= o ? sh[t - o] : Fr::zero();
+    __syncthreads();
+    sh[t] = fp_add(sh[t], x);
+    __syncthreads();
+  }
+  Fr r = sh[t];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void k_prefix_tiles(Fr* __restrict__ d, long n, Fr* __restrict__ tile_sums) {
+  __shared__ Fr sh[256];
+  const long base = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+  Fr v[4], s = Fr::zero();
+  for (int k = 0; k < 4; k++) { v[k] = base + k < n ? d[base + k] : Fr::zero(); s = fp_add(s, v[k]); v[k] = s; }
+  Fr incl = block_inclusive_scan_fr(s, sh);
+  Fr excl = fp_sub(incl, s);
+  for (int k = 0; k < 4; k++) if (base + k < n) d[base + k] = fp_add(v[k], excl);
+  if (threadIdx.x == 255) tile_sums[blockIdx.x] = incl;
+}
+__global__ __launch_bounds__(256) void k_prefix_top(Fr* __restrict__ tile_sums, long ntiles) {
+  __shared__ Fr sh[256];
+  __shared__ Fr carry_sh;
+  if (threadIdx.x == 0) carry_sh = Fr::zero();
+  __syncthreads();
+  for (long base = 0; base < ntiles; base += 256) {
+    long idx = base + threadIdx.x;
+    Fr v = idx < ntiles ? tile_sums[idx] : Fr::zero();
+    Fr incl = block_inclusive_scan_fr(v, sh);
+    Fr carry = carry_sh;
+    if (idx < ntiles) tile_sums[idx] = fp_add(fp_sub(incl, v), carry);   // exclusive
+    __syncthreads();
+    if (threadIdx.x == 255) carry_sh = fp_add(carry, incl);
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_prefix_apply(Fr* __restrict__ d, long n, const Fr* __restrict__ tile_sums) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long tile = i >> 10;
+  if (tile == 0) return;
+  d[i] = fp_add(d[i], tile_sums[tile]);
+}
+void poly_prefix_sum_enqueue(hipStream_t st, Fr* d, long n, DevBuf& tmp) {
+  if (n <= 0) return;
+  const long ntiles = (n + 1023) / 1024;
+  tmp.ensure(sizeof(Fr) * (ntiles + 1));
+  LAUNCH(k_prefix_tiles, (int)ntiles, 256, 0, st, d, n, tmp.as<Fr>());
+  if (ntiles > 1) {
+    LAUNCH(k_prefix_top, 1, 256, 0, st, tmp.as<Fr>(), ntiles);
+    LAUNCH(k_prefix_apply, ceil_div(n, 256), 256, 0, st, d, n, (const Fr*)tmp.as<Fr>());
+  }
+}
+
+// ---- prover-specific builders ----------------------------------------------------------------
+// r'(X,1) over [-2n-4, n]: aL at X^i, aR at X^-i, aO at X^{-i-n}, c_{n+i} at X^{-2n-i}
+// (Constraints.hs:23-31, Protocol.hs:58-62).  Inputs Montgomery.
+__global__ __launch_bounds__(256) void k_build_r1(const Fr* __restrict__ aL, const Fr* __restrict__ aR, const Fr* __restrict__ aO,
+                                                  const Fr* __restrict__ cns, long n, Fr* __restrict__ r1) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into [-2n-4, n]
+  const long len = 3 * n + 5;
+  if (i >= len) return;
+  const long e = i - (2 * n + 4);
+  Fr v = Fr::zero();
+  if (e > 0) v = aL[e - 1];
+  else if (e < 0 && e >= -n) v = aR[-e - 1];
+  else if (e < -n && e >= -2 * n) v = aO[-e - n - 1];
+  else if (e < -2 * n) v = cns[-e - 2 * n - 1];
+  r1[i] = v;
+}
+void build_r1_enqueue(hipStream_t st, const Fr* aL, const Fr* aR, const Fr* aO, const Fr* cns, long n, Fr* r1) {
+  LAUNCH(k_build_r1, ceil_div(3 * n + 5, 256), 256, 0, st, aL, aR, aO, cns, n, r1);
+}
+
+// s(X,y) over [-n, 2n] given ypow[e + n] = y^e for e in [-n, n + Q]:
+//   X^-i: sum_q wL[q][i] y^{n+q};  X^i: sum_q wR[q][i] y^{n+q};
+//   X^{i+n}: -y^i - y^-i + sum_q wO[q][i] y^{n+q}        (Constraints.hs:39-49, q = 1..Q)
+__global__ __launch_bounds__(256) void k_s_of_y(const Fr* __restrict__ wL, const Fr* __restrict__ wR, const Fr* __restrict__ wO,
+                                                const Fr* __restrict__ ypow, long n, long Q, Fr* __restrict__ s) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x + 1;   // 1..n
+  if (i > n) { if (i == n + 1) s[n] = Fr::zero(); return; }  // X^0 slot
+  Fr u = Fr::zero(), v = Fr::zero(), w = Fr::zero();
+  for (long q = 0; q < Q; q++) {
+    const Fr yq = ypow[2 * n + 1 + q];                       // y^{n+q+1}
+    u = fp_add(u, fp_mul(wL[q * n + i - 1], yq));
+    v = fp_add(v, fp_mul(wR[q * n + i - 1], yq));
+    w = fp_add(w, fp_mul(wO[q * n + i - 1], yq));
+  }
+  w = fp_sub(fp_sub(w, ypow[n + i]), ypow[n - i]);
+  s[n - i] = u;
+  s[n + i] = v;
+  s[2 * n + i] = w;
+}
+void s_of_y_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* ypow, long n, long Q, Fr* s) {
+  LAUNCH(k_s_of_y, ceil_div(n + 1, 256), 256, 0, st, wL, wR, wO, ypow, n, Q, s);
+}
+
+// s(u,Y) over [-n, n+Q] given upow[e + n] = u^e for e in [-n, 2n]:
+//   Y^{+-i}: -u^{i+n};  Y^{n+q}: sum_i u^-i wL[q][i] + u^i wR[q][i] + u^{i+n} wO[q][i]   (Utils.hs:17-18)
+__global__ __launch_bounds__(256) void k_s_of_u_diag(const Fr* __restrict__ upow, long n, Fr* __restrict__ s) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x + 1;
+  if (i > n) { if (i == n + 1) s[n] = Fr::zero(); return; }
+  const Fr v = fp_neg(upow[2 * n + i]);
+  s[n - i] = v;
+  s[n + i] = v;
+}
+// grid (blocks, Q): partial[q * nblk + blk] = sum over the block's i
+__global__ __launch_bounds__(256) void k_s_of_u_rows(const Fr* __restrict__ wL, const Fr* __restrict__ wR, const Fr* __restrict__ wO,
+                                                     const Fr* __restrict__ upow, long n, Fr* __restrict__ partial) {
+  __shared__ Fr sh[256];
+  const long q = blockIdx.y;
+  Fr acc = Fr::zero();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x + 1; i <= n; i += (long)gridDim.x * 256) {
+    acc = fp_add(acc, fp_mul(upow[n - i], wL[q * n + i - 1]));
+    acc = fp_add(acc, fp_mul(upow[n + i], wR[q * n + i - 1]));
+    acc = fp_add(acc, fp_mul(upow[2 * n + i], wO[q * n + i - 1]));
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fp_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[q * gridDim.x + blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(64) void k_s_of_u_finish(const Fr* __restrict__ partial, int nblk, long n, long Q, Fr* __restrict__ s) {
+  const long q = (long)blockIdx.x * 64 + threadIdx.x;
+  if (q >= Q) return;
+  Fr acc = Fr::zero();
+  for (int b = 0; b < nblk; b++) acc = fp_add(acc, partial[q * nblk + b]);
+  s[2 * n + 1 + q] = acc;
+}
+void s_of_u_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* upow, long n, long Q, Fr* s, DevBuf& tmp) {
+  LAUNCH(k_s_of_u_diag, ceil_div(n + 1, 256), 256, 0, st, upow, n, s);
+  int nblk = ceil_div(n, 256);
+  if (nblk > 256) nblk = 256;
+  tmp.ensure(sizeof(Fr) * (size_t)nblk * Q);
+  LAUNCH(k_s_of_u_rows, dim3(nblk, (unsigned)Q), 256, 0, st, wL, wR, wO, upow, n, tmp.as<Fr>());
+  LAUNCH(k_s_of_u_finish, ceil_div(Q, 64), 64, 0, st, (const Fr*)tmp.as<Fr>(), nblk, n, Q, s);
+}
+
+// dst[off + i] += src[i]
+__global__ __launch_bounds__(256) void k_add_into(Fr* __restrict__ dst, const Fr* __restrict__ src, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = fp_add(dst[i], src[i]);
+}
+void add_into_enqueue(hipStream_t st, Fr* dst, const Fr* src, long n) { if (n > 0) LAUNCH(k_add_into, ceil_div(n, 256), 256, 0, st, dst, src, n); }
+
+// *slot -= sum_q cs[q] * ypow_nq[q]   (k(y), Constraints.hs:67-68), then flags[flag_bit] if *slot != 0
+__global__ __launch_bounds__(256) void k_sub_k_of_y(Fr* __restrict__ slot, const Fr* __restrict__ cs, const Fr* __restrict__ ypow_nq, long Q, int* flags, int flag_bit) {
+  __shared__ Fr sh[256];
+  Fr acc = Fr::zero();
+  for (long q = threadIdx.x; q < Q; q += 256) acc = fp_add(acc, fp_mul(cs[q], ypow_nq[q]));
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fp_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    Fr v = fp_sub(*slot, sh[0]);
+    *slot = v;
+    if (!v.is_zero()) atomicOr(flags, flag_bit);
+  }
+}
+void sub_k_of_y_enqueue(hipStream_t st, Fr* slot, const Fr* cs, const Fr* ypow_nq, long Q, int* flags, int flag_bit) {
+  LAUNCH(k_sub_k_of_y, 1, 256, 0, st, slot, cs, ypow_nq, Q, flags, flag_bit);
+}
+
+// flags |= bit if any of a[0..n) is non-zero
+__global__ __launch_bounds__(256) void k_flag_nonzero(const Fr* __restrict__ a, long n, int* flags, int bit) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && !a[i].is_zero()) atomicOr(flags, bit);
+}
+void flag_nonzero_enqueue(hipStream_t st, const Fr* a, long n, int* flags, int bit) {
+  if (n > 0) LAUNCH(k_flag_nonzero, ceil_div(n, 256), 256, 0, st, a, n, flags, bit);
+}
+
+// small scalar prep: out = {v, v^-1} for each of k inputs (Montgomery in, Montgomery out); 0^-1 := 0
+__global__ __launch_bounds__(64) void k_fr_with_inverse(const Fr* __restrict__ in, int k, Fr* __restrict__ out) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= k) return;
+  Fr v = in[i];
+  out[2 * i] = v;
+  out[2 * i + 1] = v.is_zero() ? v : fp_inv(v);
+}
+void fr_with_inverse_enqueue(hipStream_t st, const Fr* in, int k, Fr* out) { LAUNCH(k_fr_with_inverse, ceil_div(k, 64), 64, 0, st, in, k, out); }
+
+__global__ void k_fr_mul_scalar(const Fr* a, const Fr* b, Fr* out) { *out = fp_mul(*a, *b); }
+void fr_mul_scalar_enqueue(hipStream_t st, const Fr* a, const Fr* b, Fr* out) { LAUNCH(k_fr_mul_scalar, 1, 1, 0, st, a, b, out); }
+
+// sparse (sorted by exponent) -> dense: run heads sum their run
+__global__ __launch_bounds__(256) void k_sparse_to_dense(const int64_t* __restrict__ exps, const Fr* __restrict__ coeffs, long nt, long lo, Fr* __restrict__ dense) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nt) return;
+  if (i > 0 && exps[i - 1] == exps[i]) return;
+  Fr acc = coeffs[i];
+  for (long j = i + 1; j < nt && exps[j] == exps[i]; j++) acc = fp_add(acc, coeffs[j]);
+  dense[exps[i] - lo] = acc;
+}
+void sparse_to_dense_enqueue(hipStream_t st, const int64_t* exps, const Fr* coeffs, long nt, long lo, Fr* dense) {
+  if (nt > 0) LAUNCH(k_sparse_to_dense, ceil_div(nt, 256), 256, 0, st, exps, coeffs, nt, lo, dense);
+}
+
+}  // namespace sonic

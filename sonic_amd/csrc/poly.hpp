@@ -1,0 +1,18 @@
+// Prover-specific polynomial builders (poly.hip); see internal.hpp for the generic ones.
+#pragma once
+#include "common.hpp"
+#include "field.hpp"
+
+namespace sonic {
+
+void build_r1_enqueue(hipStream_t st, const Fr* aL, const Fr* aR, const Fr* aO, const Fr* cns, long n, Fr* r1);
+void s_of_y_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* ypow, long n, long Q, Fr* s);
+void s_of_u_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* upow, long n, long Q, Fr* s, DevBuf& tmp);
+void add_into_enqueue(hipStream_t st, Fr* dst, const Fr* src, long n);
+void sub_k_of_y_enqueue(hipStream_t st, Fr* slot, const Fr* cs, const Fr* ypow_nq, long Q, int* flags, int flag_bit);
+void flag_nonzero_enqueue(hipStream_t st, const Fr* a, long n, int* flags, int bit);
+void fr_with_inverse_enqueue(hipStream_t st, const Fr* in, int k, Fr* out);
+void fr_mul_scalar_enqueue(hipStream_t st, const Fr* a, const Fr* b, Fr* out);
+void sparse_to_dense_enqueue(hipStream_t st, const int64_t* exps, const Fr* coeffs, long nt, long lo, Fr* dense);
+
+}  // namespace sonic

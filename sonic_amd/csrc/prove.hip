@@ -1,0 +1,448 @@
+// Host orchestration of the Sonic prover on one MI355X: Sonic.Protocol.prove
+// (src/Sonic/Protocol.hs:47-109) with Sonic.Signature.hscProve (src/Sonic/Signature.hs:38-72),
+// plus the C-ABI faces of Sonic.SRS.new, commitPoly and openPoly.
+//
+// Everything between "inputs in HBM" and "7+4Q window-sum slots + 3+2Q field elements in HBM" is
+// device work queued on one stream with no host synchronisation: the `rnd` draws are explicit
+// (transcript), so no step waits for a result.  The host then runs the O(W) tails of the MSMs
+// (msm_finish_host) and lays out the proof bytes.
+//
+// Each reference step is done once: the reference re-evaluates evalY 1 polyR' three times
+// (Protocol.hs:63,79,80), evalY y tXY twice (:72,81) and evalY y_j sXY twice per j
+// (Signature.hs:41,54).
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <numeric>
+#include <vector>
+#include "internal.hpp"
+#include "poly.hpp"
+
+namespace sonic {
+
+enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
+
+struct Scratch {
+  DevBuf D, q, scan, fz_discard;
+  void reserve(long len) { D.ensure(sizeof(Fr) * (len + 1)); q.ensure(sizeof(Fr) * (len + 1)); fz_discard.ensure(sizeof(Fr)); }
+};
+
+// commitPoly (CommitmentScheme.hs:20-33): F = sum_e c_e * A[e + d - max], A = alpha basis.
+// `poly` dense over exponents [lo, lo+len).  Terms whose shifted exponent leaves [-d, d] or hits the
+// e' = 0 hole are legal only if their coefficient is zero (the reference's normalised sparse form
+// would not contain them); otherwise FLAG_SRS_INDEX (`index` panics, CommitmentScheme.hs:70-73).
+static void commit_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const Fr* poly, long lo, long len, long maxm,
+                           MsmSlot* slot, int* d_flags) {
+  const long d = srs_d(srs), shift = d - maxm;
+  long i0 = -d - shift - lo, i1 = d - shift - lo + 1;     // in-range i: lo + i + shift in [-d, d]
+  if (i0 < 0) i0 = 0;
+  if (i1 > len) i1 = len;
+  if (i1 < i0) i1 = i0;
+  flag_nonzero_enqueue(st, poly, i0, d_flags, FLAG_SRS_INDEX);
+  flag_nonzero_enqueue(st, poly + i1, len - i1, d_flags, FLAG_SRS_INDEX);
+  const long ih = -shift - lo;
+  if (ih >= i0 && ih < i1) flag_nonzero_enqueue(st, poly + ih, 1, d_flags, FLAG_SRS_INDEX);
+  const long n = i1 - i0;
+  MsmPlan pl = msm_plan(n > 0 ? n : 1);
+  msm_enqueue(st, ws, pl, srs_basis(srs, 1) + (lo + i0 + shift + d), poly + i0, n, true, slot);
+}
+
+// f(z) for a dense Laurent f: D_e = c_e z^e, inclusive prefix sums, f(z) = last prefix.
+static void eval_prefix_enqueue(hipStream_t st, Scratch& sc, const Fr* poly, long lo, long len, const Fr* zpair, Fr* d_fz) {
+  sc.reserve(len);
+  poly_scale_powers_enqueue(st, poly, sc.D.as<Fr>(), len, lo, zpair, zpair + 1);
+  poly_prefix_sum_enqueue(st, sc.D.as<Fr>(), len, sc.scan);
+  HIP_OK(hipMemcpyAsync(d_fz, sc.D.as<Fr>() + (len - 1), sizeof(Fr), hipMemcpyDeviceToDevice, st));
+}
+
+// openPoly (CommitmentScheme.hs:36-48).  Requires lo <= 0 <= lo+len-1 (callers extend the range to
+// contain X^0, where `fX - monomial 0 fz` puts -f(z)).  Quotient exponents [lo, lo+len-2], plain basis.
+static void open_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, Scratch& sc, const Fr* poly, long lo, long len,
+                         const Fr* zpair, Fr* d_fz, MsmSlot* slot, int* d_flags) {
+  const long d = srs_d(srs);
+  eval_prefix_enqueue(st, sc, poly, lo, len, zpair, d_fz ? d_fz : sc.fz_discard.as<Fr>());
+  const long qn = len - 1;
+  poly_quotient_enqueue(st, sc.D.as<Fr>(), sc.q.as<Fr>(), len, lo, zpair, zpair + 1);
+  long i0 = -d - lo, i1 = d - lo + 1;
+  if (i0 < 0) i0 = 0;
+  if (i1 > qn) i1 = qn;
+  if (i1 < i0) i1 = i0;
+  const Fr* q = sc.q.as<Fr>();
+  flag_nonzero_enqueue(st, q, i0, d_flags, FLAG_SRS_INDEX);
+  flag_nonzero_enqueue(st, q + i1, qn - i1, d_flags, FLAG_SRS_INDEX);
+  const long n = i1 - i0;
+  MsmPlan pl = msm_plan(n > 0 ? n : 1);
+  msm_enqueue(st, ws, pl, srs_basis(srs, 0) + (lo + i0 + d), q + i0, n, true, slot);
+}
+
+// IN = [y, z, y*z, u, v, y_1..y_Q, z_1..z_Q] from the transcript S = [c1..c4, y, z, ys, zs, u, v]
+__global__ void k_prep_scalars(const Fr* __restrict__ S, long Q, Fr* __restrict__ IN) {
+  long t = threadIdx.x + (long)blockIdx.x * blockDim.x;
+  if (t == 0) { IN[0] = S[4]; IN[1] = S[5]; IN[2] = fp_mul(S[4], S[5]); IN[3] = S[6 + 2 * Q]; IN[4] = S[7 + 2 * Q]; }
+  if (t < 2 * Q) IN[5 + t] = S[6 + t];
+}
+
+static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
+
+}  // namespace sonic
+
+using namespace sonic;
+
+struct sonic_prover {
+  const sonic_srs* srs = nullptr;
+  long n = 0, Q = 0;
+  hipStream_t st = nullptr;
+  bool have_assignment = false;
+  DevBuf wL, wR, wO, cs, aL, aR, aO;        // Montgomery, resident across proofs
+  MsmWorkspace ws;
+  NttTables ntt;
+  Scratch sc;
+  DevBuf S, IN, PAIRS, r1, sy, su, pw, fa, fb, slots, frout, flags, tmp;
+  int log2m = 0;
+  std::mutex mu;
+  ~sonic_prover() { if (st) (void)hipStreamDestroy(st); }
+};
+
+#define API_BEGIN try { require_device();
+#define API_END                                                        \
+  } catch (const HipFail& f) { return f.code; }                        \
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; } \
+  return SONIC_OK;
+
+static int upload_fr_mont(hipStream_t st, DevBuf& dst, const uint8_t* src, long count, int* d_flags) {
+  dst.ensure(sizeof(Fr) * (count > 0 ? count : 1));
+  if (count > 0) {
+    HIP_OK(hipMemcpyAsync(dst.p, src, 32 * count, hipMemcpyHostToDevice, st));
+    fr_to_mont_enqueue(st, dst.as<Fr>(), count, d_flags);
+  }
+  return 0;
+}
+
+static int read_flags(hipStream_t st, DevBuf& flags) {
+  int h = 0;
+  HIP_OK(hipMemcpyAsync(&h, flags.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  return h;
+}
+
+static int flags_to_status(int f, const char* who) {
+  if (f & FLAG_BAD_ENCODING) { set_error("%s: non-canonical field element in input", who); return SONIC_ERR_BAD_ENCODING; }
+  if (f & FLAG_SRS_INDEX) { set_error("%s: a non-zero coefficient needs an SRS element outside [-d, d] or the omitted g^alpha (index -1)", who); return SONIC_ERR_SRS_INDEX; }
+  return SONIC_OK;
+}
+
+extern "C" {
+
+int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out) {
+  API_BEGIN
+  if (d < 1 || !x || !alpha || !out) { set_error("sonic_srs_new: bad argument"); return SONIC_ERR_INVALID_ARG; }
+  Fr xs, as;
+  memcpy(xs.l, x, 32); memcpy(as.l, alpha, 32);
+  if (!fp_is_canonical(xs) || !fp_is_canonical(as)) { set_error("sonic_srs_new: x or alpha not < r"); return SONIC_ERR_BAD_ENCODING; }
+  if (xs.is_zero()) { set_error("sonic_srs_new: x = 0 has no inverse (recip x, SRS.hs:29)"); return SONIC_ERR_INEXACT_DIVISION; }
+  std::lock_guard<std::mutex> g(call_mutex());
+  sonic_srs* s = srs_alloc(d);
+  try { srs_generate(default_stream(), s, xs, as); } catch (...) { sonic_srs_free(s); throw; }
+  *out = s;
+  API_END
+}
+
+size_t sonic_proof_size(int64_t Q) { return (size_t)((7 + 4 * Q) * 96 + (5 + 2 * Q) * 32); }
+
+int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                     const uint8_t* cs, sonic_prover_t** out) {
+  API_BEGIN
+  if (!srs || n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !out) { set_error("sonic_prover_new: bad argument (need n >= 1, Q >= 1)"); return SONIC_ERR_INVALID_ARG; }
+  if (srs_d(srs) < 7 * n) {                                                   // Protocol.hs:54-55
+    set_error("Parameter d is not large enough: %ld should be greater than %ld", (long)srs_d(srs), (long)(7 * n));
+    return SONIC_ERR_D_TOO_SMALL;
+  }
+  std::unique_ptr<sonic_prover> p(new sonic_prover());
+  p->srs = srs; p->n = n; p->Q = Q;
+  HIP_OK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+  hipStream_t st = p->st;
+  p->flags.alloc(4);
+  HIP_OK(hipMemsetAsync(p->flags.p, 0, 4, st));
+  upload_fr_mont(st, p->wL, wL, Q * n, p->flags.as<int>());
+  upload_fr_mont(st, p->wR, wR, Q * n, p->flags.as<int>());
+  upload_fr_mont(st, p->wO, wO, Q * n, p->flags.as<int>());
+  upload_fr_mont(st, p->cs, cs, Q, p->flags.as<int>());
+  int f = read_flags(st, p->flags);
+  if (f) return flags_to_status(f, "sonic_prover_new");
+  // workspaces
+  const long tlen = 7 * n + 9;
+  int lg = 0;
+  while ((1L << lg) < tlen) lg++;
+  p->log2m = lg;
+  p->ntt.ensure(st, lg);
+  const long M = 1L << lg;
+  p->fa.alloc(sizeof(Fr) * M); p->fb.alloc(sizeof(Fr) * M);
+  p->r1.alloc(sizeof(Fr) * (3 * n + 5));
+  p->sy.alloc(sizeof(Fr) * (3 * n + 1));
+  p->su.alloc(sizeof(Fr) * (2 * n + Q + 1));
+  p->pw.alloc(sizeof(Fr) * (3 * n + Q + 2));
+  p->S.alloc(sizeof(Fr) * (8 + 2 * Q)); p->IN.alloc(sizeof(Fr) * (5 + 2 * Q)); p->PAIRS.alloc(sizeof(Fr) * 2 * (5 + 2 * Q));
+  p->slots.alloc(sizeof(MsmSlot) * (7 + 4 * Q));
+  p->frout.alloc(sizeof(Fr) * (3 + 2 * Q));
+  p->sc.reserve(tlen);
+  p->ws.reserve(tlen, msm_plan(tlen));
+  HIP_OK(hipStreamSynchronize(st));
+  *out = p.release();
+  API_END
+}
+
+int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO) {
+  API_BEGIN
+  if (!p || !aL || !aR || !aO) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  hipStream_t st = p->st;
+  HIP_OK(hipMemsetAsync(p->flags.p, 0, 4, st));
+  upload_fr_mont(st, p->aL, aL, p->n, p->flags.as<int>());
+  upload_fr_mont(st, p->aR, aR, p->n, p->flags.as<int>());
+  upload_fr_mont(st, p->aO, aO, p->n, p->flags.as<int>());
+  int f = read_flags(st, p->flags);
+  if (f) return flags_to_status(f, "sonic_prover_set_assignment");
+  p->have_assignment = true;
+  API_END
+}
+
+int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_proof) {
+  API_BEGIN
+  if (!p || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
+  if (!p->have_assignment) { set_error("sonic_prover_prove: no assignment set"); return SONIC_ERR_INVALID_ARG; }
+  std::lock_guard<std::mutex> g(p->mu);
+  const long n = p->n, Q = p->Q;
+  const sonic_srs* srs = p->srs;
+  hipStream_t st = p->st;
+  // evaluation points feed `pow x e` with negative e (Utils.hs:18, poly's eval): x = 0 has no inverse
+  for (long k = 4; k < 8 + 2 * Q; k++)
+    if (bytes_are_zero(transcript + 32 * k, 32)) { set_error("prove: transcript element %ld is zero: Laurent evaluation at 0 divides by zero", k); return SONIC_ERR_INEXACT_DIVISION; }
+  int* flags = p->flags.as<int>();
+  HIP_OK(hipMemsetAsync(flags, 0, 4, st));
+  Fr* S = p->S.as<Fr>();
+  HIP_OK(hipMemcpyAsync(S, transcript, 32 * (8 + 2 * Q), hipMemcpyHostToDevice, st));
+  fr_to_mont_enqueue(st, S, 8 + 2 * Q, flags);
+  Fr* IN = p->IN.as<Fr>();
+  Fr* PR = p->PAIRS.as<Fr>();
+  LAUNCH(k_prep_scalars, ceil_div(2 * Q + 1, 64), 64, 0, st, (const Fr*)S, Q, IN);
+  fr_with_inverse_enqueue(st, IN, (int)(5 + 2 * Q), PR);
+  const Fr *pY = PR + 0, *pZ = PR + 2, *pYZ = PR + 4, *pU = PR + 6, *pV = PR + 8;
+  auto pYj = [&](long j) { return PR + 2 * (5 + j); };
+  auto pZj = [&](long j) { return PR + 2 * (5 + Q + j); };
+  MsmSlot* slots = p->slots.as<MsmSlot>();
+  Fr* frout = p->frout.as<Fr>();
+  Fr *r1 = p->r1.as<Fr>(), *sy = p->sy.as<Fr>(), *su = p->su.as<Fr>(), *pw = p->pw.as<Fr>(), *fa = p->fa.as<Fr>(), *fb = p->fb.as<Fr>();
+  const Fr *wL = p->wL.as<Fr>(), *wR = p->wR.as<Fr>(), *wO = p->wO.as<Fr>(), *cs = p->cs.as<Fr>();
+  const long d = srs_d(srs);
+  const long r_lo = -2 * n - 4, r_len = 3 * n + 5, s_lo = -n, s_len = 3 * n + 1, t_lo = -4 * n - 8, t_len = 7 * n + 9;
+  const long M = 1L << p->log2m;
+
+  // zkP_1: r'(X,1), R = Commit(n, r(X,1))                                          Protocol.hs:58-63
+  build_r1_enqueue(st, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
+  commit_enqueue(st, srs, p->ws, r1, r_lo, r_len, n, &slots[0], flags);
+  // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y)                               Protocol.hs:69-73, Constraints.hs:56-68
+  poly_scale_powers_enqueue(st, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
+  s_of_y_enqueue(st, wL, wR, wO, pw, n, Q, sy);
+  HIP_OK(hipMemsetAsync(fa, 0, sizeof(Fr) * M, st));
+  HIP_OK(hipMemsetAsync(fb, 0, sizeof(Fr) * M, st));
+  HIP_OK(hipMemcpyAsync(fa, r1, sizeof(Fr) * r_len, hipMemcpyDeviceToDevice, st));
+  poly_scale_powers_enqueue(st, r1, fb, r_len, r_lo, pY, pY + 1);                    // r(X,y): c_e y^e (diagonal)
+  add_into_enqueue(st, fb + (s_lo - r_lo), sy, s_len);
+  ntt_forward_enqueue(st, p->ntt, fa, p->log2m);
+  ntt_forward_enqueue(st, p->ntt, fb, p->log2m);
+  fr_pointwise_mul_enqueue(st, fa, fb, M);
+  ntt_inverse_enqueue(st, p->ntt, fa, p->log2m);
+  Fr* t = fa;                                                                         // exponents [t_lo, t_lo + t_len)
+  sub_k_of_y_enqueue(st, t + (0 - t_lo), cs, pw + (2 * n + 1), Q, flags, 0);
+  commit_enqueue(st, srs, p->ws, t, t_lo, t_len, d, &slots[1], flags);
+  // zkP_3: openings                                                                 Protocol.hs:79-83
+  open_enqueue(st, srs, p->ws, p->sc, r1, r_lo, r_len, pZ, &frout[0], &slots[2], flags);
+  open_enqueue(st, srs, p->ws, p->sc, r1, r_lo, r_len, pYZ, &frout[1], &slots[3], flags);
+  open_enqueue(st, srs, p->ws, p->sc, t, t_lo, t_len, pZ, nullptr, &slots[4], flags);
+  eval_prefix_enqueue(st, p->sc, sy, s_lo, s_len, pZ, &frout[2]);
+  // hscProve                                                                        Signature.hs:38-72
+  for (long j = 0; j < Q; j++) {
+    poly_scale_powers_enqueue(st, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
+    s_of_y_enqueue(st, wL, wR, wO, pw, n, Q, sy);                                    // s(X, y_j)
+    commit_enqueue(st, srs, p->ws, sy, s_lo, s_len, d, &slots[5 + 2 * j], flags);    // S_j           :42
+    open_enqueue(st, srs, p->ws, p->sc, sy, s_lo, s_len, pZj(j), &frout[3 + j], &slots[6 + 2 * j], flags);      // (s_j, W_j)  :43
+    open_enqueue(st, srs, p->ws, p->sc, sy, s_lo, s_len, pU, nullptr, &slots[5 + 2 * Q + 2 * j], flags);        // W'_j        :54
+  }
+  poly_scale_powers_enqueue(st, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);             // u^e, e in [-n, 2n]
+  const long u_lo = -n, u_len = 2 * n + Q + 1;
+  s_of_u_enqueue(st, wL, wR, wO, pw, n, Q, su, p->tmp);                              // s(u, Y)       :51
+  commit_enqueue(st, srs, p->ws, su, u_lo, u_len, d, &slots[6 + 4 * Q], flags);      // C             :52
+  for (long j = 0; j < Q; j++)
+    open_enqueue(st, srs, p->ws, p->sc, su, u_lo, u_len, pYj(j), &frout[3 + Q + j], &slots[6 + 2 * Q + 2 * j], flags);  // (s'_j, Q_j) :55
+  open_enqueue(st, srs, p->ws, p->sc, su, u_lo, u_len, pV, nullptr, &slots[5 + 4 * Q], flags);                          // Q_v         :63
+  fr_from_mont_enqueue(st, frout, 3 + 2 * Q);
+
+  const int K = (int)(7 + 4 * Q);
+  std::vector<MsmSlot> hs(K);
+  std::vector<uint8_t> hfr(32 * (3 + 2 * Q));
+  int hflags = 0;
+  HIP_OK(hipMemcpyAsync(hs.data(), slots, sizeof(MsmSlot) * K, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(hfr.data(), frout, hfr.size(), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  if (hflags) return flags_to_status(hflags, "prove");
+  std::vector<uint8_t> pts(96 * (size_t)K);
+  for (int i = 0; i < K; i++) g1_canonical_bytes_host(msm_finish_host(hs[i]), &pts[96 * (size_t)i]);
+  auto G = [&](long i) { return &pts[96 * (size_t)i]; };
+  auto F = [&](long i) { return &hfr[32 * (size_t)i]; };
+  uint8_t* o = out_proof;
+  auto putG = [&](long i) { memcpy(o, G(i), 96); o += 96; };
+  auto putF = [&](const uint8_t* s) { memcpy(o, s, 32); o += 32; };
+  putG(0); putG(1); putF(F(0)); putG(2); putF(F(1)); putG(3); putG(4); putF(F(2));      // R T a Wa b Wb Wt s
+  for (long j = 0; j < Q; j++) { putG(5 + 2 * j); putF(F(3 + j)); putG(6 + 2 * j); }     // hscS
+  for (long j = 0; j < Q; j++) { putF(F(3 + Q + j)); putG(5 + 2 * Q + 2 * j); putG(6 + 2 * Q + 2 * j); }   // hscW
+  putG(5 + 4 * Q); putG(6 + 4 * Q);                                                      // Qv, C
+  putF(transcript + 32 * (6 + 2 * Q)); putF(transcript + 32 * (7 + 2 * Q));              // u, v
+  API_END
+}
+
+void sonic_prover_free(sonic_prover_t* p) { delete p; }
+
+int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                const uint8_t* cs, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript,
+                uint8_t* out_proof) {
+  sonic_prover_t* p = nullptr;
+  int rc = sonic_prover_new(srs, n, Q, wL, wR, wO, cs, &p);
+  if (rc) return rc;
+  rc = sonic_prover_set_assignment(p, aL, aR, aO);
+  if (!rc) rc = sonic_prover_prove(p, transcript, out_proof);
+  sonic_prover_free(p);
+  return rc;
+}
+
+// ---- commitPoly / openPoly on caller-supplied sparse polynomials ------------------------------
+struct DensePoly { DevBuf c; long lo = 0, len = 0; };
+
+static int densify(hipStream_t st, const sonic_srs* srs, int64_t nt, const int64_t* exps, const uint8_t* coeffs, bool include_zero,
+                   DensePoly& out, int* d_flags) {
+  long lo = include_zero ? 0 : (nt ? exps[0] : 0), hi = lo;
+  for (int64_t i = 0; i < nt; i++) { if (exps[i] < lo) lo = exps[i]; if (exps[i] > hi) hi = exps[i]; }
+  const long d = srs_d(srs);
+  if (hi - lo + 1 > 8 * (2 * d + 1) + 64) { set_error("polynomial exponent range [%ld, %ld] is far outside the SRS", lo, hi); return SONIC_ERR_SRS_INDEX; }
+  out.lo = lo; out.len = hi - lo + 1;
+  out.c.alloc(sizeof(Fr) * out.len);
+  HIP_OK(hipMemsetAsync(out.c.p, 0, sizeof(Fr) * out.len, st));
+  if (nt == 0) return SONIC_OK;
+  std::vector<int64_t> order(nt);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return exps[a] < exps[b]; });
+  std::vector<int64_t> se(nt);
+  std::vector<uint8_t> sc(32 * (size_t)nt);
+  for (int64_t i = 0; i < nt; i++) { se[i] = exps[order[i]]; memcpy(&sc[32 * (size_t)i], coeffs + 32 * order[i], 32); }
+  DevBuf de(8 * (size_t)nt), dc(32 * (size_t)nt);
+  HIP_OK(hipMemcpyAsync(de.p, se.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(dc.p, sc.data(), 32 * (size_t)nt, hipMemcpyHostToDevice, st));
+  fr_to_mont_enqueue(st, dc.as<Fr>(), nt, d_flags);
+  sparse_to_dense_enqueue(st, de.as<int64_t>(), dc.as<Fr>(), nt, lo, out.c.as<Fr>());
+  HIP_OK(hipStreamSynchronize(st));   // host staging vectors and de/dc go out of scope
+  return SONIC_OK;
+}
+
+int sonic_commit_poly(const sonic_srs_t* srs, int64_t max, int64_t n_terms, const int64_t* exps, const uint8_t* coeffs, uint8_t out_g1[96]) {
+  API_BEGIN
+  if (!srs || n_terms < 0 || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  DevBuf flags(4), slot(sizeof(MsmSlot));
+  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
+  DensePoly f;
+  int rc = densify(st, srs, n_terms, exps, coeffs, false, f, flags.as<int>());
+  if (rc) return rc;
+  commit_enqueue(st, srs, shared_msm_ws(), f.c.as<Fr>(), f.lo, f.len, max, slot.as<MsmSlot>(), flags.as<int>());
+  MsmSlot h;
+  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));
+  int fl = read_flags(st, flags);
+  if (fl) return flags_to_status(fl, "commitPoly");
+  g1_canonical_bytes_host(msm_finish_host(h), out_g1);
+  API_END
+}
+
+int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms, const int64_t* exps, const uint8_t* coeffs,
+                    uint8_t out_fz[32], uint8_t out_g1[96]) {
+  API_BEGIN
+  if (!srs || !z || n_terms < 0 || !out_fz || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  DevBuf flags(4), slot(sizeof(MsmSlot)), zin(sizeof(Fr)), zpair(2 * sizeof(Fr)), fz(sizeof(Fr));
+  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
+  DensePoly f;
+  int rc = densify(st, srs, n_terms, exps, coeffs, true, f, flags.as<int>());
+  if (rc) return rc;
+  if (f.lo < 0 && bytes_are_zero(z, 32)) { set_error("openPoly: evaluation at z = 0 of a polynomial with negative exponents"); return SONIC_ERR_INEXACT_DIVISION; }
+  HIP_OK(hipMemcpyAsync(zin.p, z, 32, hipMemcpyHostToDevice, st));
+  fr_to_mont_enqueue(st, zin.as<Fr>(), 1, flags.as<int>());
+  fr_with_inverse_enqueue(st, zin.as<Fr>(), 1, zpair.as<Fr>());
+  Scratch sc;
+  open_enqueue(st, srs, shared_msm_ws(), sc, f.c.as<Fr>(), f.lo, f.len, zpair.as<Fr>(), fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>());
+  fr_from_mont_enqueue(st, fz.as<Fr>(), 1);
+  MsmSlot h;
+  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(out_fz, fz.p, 32, hipMemcpyDeviceToHost, st));
+  int fl = read_flags(st, flags);
+  if (fl) return flags_to_status(fl, "openPoly");
+  g1_canonical_bytes_host(msm_finish_host(h), out_g1);
+  API_END
+}
+
+// ---- NTT / dense product -----------------------------------------------------------------------
+static NttTables& shared_ntt() { static NttTables* t = new NttTables(); return *t; }
+
+int sonic_ntt_fr(uint8_t* data, int log2n, int inverse) {
+  API_BEGIN
+  if (!data || log2n < 0 || log2n > 28) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  const long n = 1L << log2n;
+  DevBuf d(sizeof(Fr) * n), flags(4);
+  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
+  HIP_OK(hipMemcpyAsync(d.p, data, 32 * n, hipMemcpyHostToDevice, st));
+  fr_to_mont_enqueue(st, d.as<Fr>(), n, flags.as<int>());
+  if (log2n > 0) {
+    shared_ntt().ensure(st, log2n);
+    if (!inverse) { ntt_forward_enqueue(st, shared_ntt(), d.as<Fr>(), log2n); fr_bitrev_permute_enqueue(st, d.as<Fr>(), log2n); }
+    else { fr_bitrev_permute_enqueue(st, d.as<Fr>(), log2n); ntt_inverse_enqueue(st, shared_ntt(), d.as<Fr>(), log2n); }
+  }
+  fr_from_mont_enqueue(st, d.as<Fr>(), n);
+  int fl = read_flags(st, flags);
+  if (fl) return flags_to_status(fl, "sonic_ntt_fr");
+  HIP_OK(hipMemcpy(data, d.p, 32 * n, hipMemcpyDeviceToHost));
+  API_END
+}
+
+int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out) {
+  API_BEGIN
+  if (!a || !b || !out || na < 1 || nb < 1) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  const long rl = na + nb - 1;
+  int lg = 0;
+  while ((1L << lg) < rl) lg++;
+  const long M = 1L << lg;
+  DevBuf fa(sizeof(Fr) * M), fb(sizeof(Fr) * M), flags(4);
+  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
+  HIP_OK(hipMemsetAsync(fa.p, 0, sizeof(Fr) * M, st));
+  HIP_OK(hipMemsetAsync(fb.p, 0, sizeof(Fr) * M, st));
+  HIP_OK(hipMemcpyAsync(fa.p, a, 32 * na, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(fb.p, b, 32 * nb, hipMemcpyHostToDevice, st));
+  fr_to_mont_enqueue(st, fa.as<Fr>(), na, flags.as<int>());
+  fr_to_mont_enqueue(st, fb.as<Fr>(), nb, flags.as<int>());
+  if (lg > 0) {
+    shared_ntt().ensure(st, lg);
+    ntt_forward_enqueue(st, shared_ntt(), fa.as<Fr>(), lg);
+    ntt_forward_enqueue(st, shared_ntt(), fb.as<Fr>(), lg);
+  }
+  fr_pointwise_mul_enqueue(st, fa.as<Fr>(), fb.as<Fr>(), M);
+  if (lg > 0) ntt_inverse_enqueue(st, shared_ntt(), fa.as<Fr>(), lg);
+  fr_from_mont_enqueue(st, fa.as<Fr>(), rl);
+  int fl = read_flags(st, flags);
+  if (fl) return flags_to_status(fl, "sonic_poly_mul_fr");
+  HIP_OK(hipMemcpy(out, fa.p, 32 * rl, hipMemcpyDeviceToHost));
+  API_END
+}
+
+}  // extern "C"

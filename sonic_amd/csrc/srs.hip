@@ -1,0 +1,111 @@
+// SRS.new on the GPU (src/Sonic/SRS.hs:27-43): the G1 vectors the prover reads,
+//   basis 0: g^{x^e}, basis 1: g^{alpha x^e},  e in [-d, d]  (basis 1 has no e = 0 entry, SRS.hs:38)
+// The reference computes every element as `mul gen (pow x i)` (a 255-bit double-and-add).  Here:
+// a 32 x 256 table of byte multiples of the generator (j * 2^(8w) * G), one thread per exponent
+// doing 2 x 32 table additions into XYZZ accumulators, then a batched (Montgomery-trick)
+// normalisation to affine, 64 points per inversion.
+#include "internal.hpp"
+
+namespace sonic {
+
+__device__ __forceinline__ G1Affine g1_generator() {
+  constexpr uint32_t gx[12] = G1_GEN_X_MONT, gy[12] = G1_GEN_Y_MONT;
+  G1Affine g;
+  for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+  return g;
+}
+
+// tab[w * 256 + j] = j * 2^(8w) * G as XYZZ; one thread per w
+__global__ __launch_bounds__(64) void k_fb_table(G1XYZZ* __restrict__ tab) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= 32) return;
+  G1XYZZ base = G1XYZZ::from_affine(g1_generator());
+  for (int i = 0; i < 8 * w; i++) base = g1_dbl(base);
+  G1XYZZ acc = G1XYZZ::inf();
+  tab[w * 256] = acc;
+  for (int j = 1; j < 256; j++) { acc = g1_add(acc, base); tab[w * 256 + j] = acc; }
+}
+__global__ __launch_bounds__(64) void k_xyzz_to_affine(const G1XYZZ* __restrict__ in, G1Affine* __restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = g1_to_affine(in[i]);
+}
+
+__device__ __forceinline__ G1XYZZ fixed_base_mul(const G1Affine* __restrict__ tab, const Fr& k_mont) {
+  Fr k = fp_from_mont(k_mont);
+  G1XYZZ acc = G1XYZZ::inf();
+#pragma unroll 1
+  for (int w = 0; w < 32; w++) {
+    uint32_t b = (k.l[w >> 2] >> (8 * (w & 3))) & 0xffu;
+    if (b) acc = g1_add_mixed(acc, tab[w * 256 + b]);
+  }
+  return acc;
+}
+
+// slab slot i <-> exponent e = i - e_origin.  out0[i] = x^e * G, out1[i] = alpha x^e * G (XYZZ)
+__global__ __launch_bounds__(256) void k_srs_points(const G1Affine* __restrict__ tab, long e_origin, long m, Fr x, Fr xinv, Fr alpha,
+                                                    G1XYZZ* __restrict__ out0, G1XYZZ* __restrict__ out1) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  long e = i - e_origin;
+  Fr p = e >= 0 ? fp_pow_u64(x, (uint64_t)e) : fp_pow_u64(xinv, (uint64_t)(-e));
+  out0[i] = fixed_base_mul(tab, p);
+  out1[i] = e == 0 ? G1XYZZ::inf() : fixed_base_mul(tab, fp_mul(p, alpha));
+}
+
+// Montgomery's trick over chunks of 64 points: one Fq inversion per chunk.
+__global__ __launch_bounds__(64) void k_batch_affine(const G1XYZZ* __restrict__ in, G1Affine* __restrict__ out, Fq* __restrict__ pref, long n) {
+  constexpr int CH = 64;
+  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long lo = c * CH, hi = lo + CH;
+  if (lo >= n) return;
+  if (hi > n) hi = n;
+  Fq acc = Fq::one();
+  for (long i = lo; i < hi; i++) {
+    pref[i] = acc;
+    G1XYZZ p = in[i];
+    if (!p.is_inf()) acc = fp_mul(acc, fp_mul(p.zz, p.zzz));
+  }
+  Fq inv = fp_inv(acc);
+  for (long i = hi - 1; i >= lo; i--) {
+    G1XYZZ p = in[i];
+    if (p.is_inf()) { out[i] = G1Affine::inf(); continue; }
+    Fq zi = fp_mul(inv, pref[i]);                 // 1 / (zz * zzz)
+    inv = fp_mul(inv, fp_mul(p.zz, p.zzz));
+    G1Affine a;
+    a.x = fp_mul(p.x, fp_mul(zi, p.zzz));
+    a.y = fp_mul(p.y, fp_mul(zi, p.zz));
+    out[i] = a;
+  }
+}
+
+__global__ void k_fr_setup_x(const Fr* in_std, Fr* out) {  // out = {x, x^-1, alpha} Montgomery
+  Fr x = fp_to_mont(in_std[0]), a = fp_to_mont(in_std[1]);
+  out[0] = x; out[1] = fp_inv(x); out[2] = a;
+}
+
+void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha_std) {
+  const long d = srs_d(s), n = 2 * d + 1;
+  DevBuf tabx(sizeof(G1XYZZ) * 8192), tab(sizeof(G1Affine) * 8192);
+  LAUNCH(k_fb_table, 1, 64, 0, st, tabx.as<G1XYZZ>());
+  LAUNCH(k_xyzz_to_affine, ceil_div(8192, 64), 64, 0, st, (const G1XYZZ*)tabx.as<G1XYZZ>(), tab.as<G1Affine>(), 8192L);
+  Fr h[2] = {x_std, alpha_std};
+  DevBuf in(sizeof h), par(sizeof(Fr) * 3);
+  HIP_OK(hipMemcpyAsync(in.p, h, sizeof h, hipMemcpyHostToDevice, st));
+  LAUNCH(k_fr_setup_x, 1, 1, 0, st, (const Fr*)in.as<Fr>(), par.as<Fr>());
+  Fr hp[3];
+  HIP_OK(hipMemcpyAsync(hp, par.p, sizeof hp, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  // process in slabs to bound the XYZZ scratch (2 x 144 B per slot)
+  const long SLAB = 1L << 20;
+  DevBuf x0(sizeof(G1XYZZ) * (n < SLAB ? n : SLAB)), x1(sizeof(G1XYZZ) * (n < SLAB ? n : SLAB)), pref(sizeof(Fq) * (n < SLAB ? n : SLAB));
+  for (long base = 0; base < n; base += SLAB) {
+    long m = n - base < SLAB ? n - base : SLAB;
+    LAUNCH(k_srs_points, ceil_div(m, 256), 256, 0, st, (const G1Affine*)tab.as<G1Affine>(), d - base, m, hp[0], hp[1], hp[2],
+           x0.as<G1XYZZ>(), x1.as<G1XYZZ>());
+    LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x0.as<G1XYZZ>(), srs_basis_mut(s, 0) + base, pref.as<Fq>(), m);
+    LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x1.as<G1XYZZ>(), srs_basis_mut(s, 1) + base, pref.as<Fq>(), m);
+  }
+  HIP_OK(hipStreamSynchronize(st));
+}
+
+}  // namespace sonic

@@ -1,0 +1,168 @@
+"""Sonic.Protocol.prove with Sonic.Signature.hscProve (src/Sonic/Protocol.hs:47-109,
+src/Sonic/Signature.hs:38-72) over the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+import secrets
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .encoding import R_MODULUS, fr_array, fr_matrix, g1_from_bytes
+from .srs import SRS
+
+
+@dataclass
+class GateWeights:           # Bulletproofs.ArithmeticCircuit.GateWeights
+    wL: list
+    wR: list
+    wO: list
+
+
+@dataclass
+class ArithCircuit:          # Bulletproofs.ArithmeticCircuit.ArithCircuit (commitmentWeights is never forced)
+    weights: GateWeights
+    cs: list
+    commitmentWeights: object = None
+
+
+@dataclass
+class Assignment:            # Bulletproofs.ArithmeticCircuit.Assignment
+    aL: list
+    aR: list
+    aO: list
+
+
+@dataclass
+class HscProof:              # Signature.hs:22-29
+    hscS: List[Tuple[object, Tuple[int, object]]]
+    hscW: List[Tuple[int, object, object]]
+    hscQv: object
+    hscC: object
+    hscU: int
+    hscV: int
+
+
+@dataclass
+class Proof:                 # Protocol.hs:28-38
+    prR: object
+    prT: object
+    prA: int
+    prWa: object
+    prB: int
+    prWb: object
+    prWt: object
+    prS: int
+    prHscProof: HscProof
+    raw: bytes = field(default=b"", repr=False, compare=False)
+
+    def to_bytes(self) -> bytes:
+        return self.raw
+
+    @classmethod
+    def from_bytes(cls, b: bytes, Q: int) -> "Proof":
+        pos = 0
+
+        def g():
+            nonlocal pos
+            v = g1_from_bytes(b[pos:pos + 96]); pos += 96
+            return v
+
+        def f():
+            nonlocal pos
+            v = int.from_bytes(b[pos:pos + 32], "little"); pos += 32
+            return v
+
+        prR, prT, prA, prWa, prB, prWb, prWt, prS = g(), g(), f(), g(), f(), g(), g(), f()
+        hscS = []
+        for _ in range(Q):
+            cm, sj, wj = g(), f(), g()
+            hscS.append((cm, (sj, wj)))
+        hscW = []
+        for _ in range(Q):
+            sjp, wjp, qj = f(), g(), g()
+            hscW.append((sjp, wjp, qj))
+        qv, c, u, v = g(), g(), f(), f()
+        assert pos == len(b)
+        return cls(prR, prT, prA, prWa, prB, prWb, prWt, prS, HscProof(hscS, hscW, qv, c, u, v), bytes(b))
+
+
+@dataclass
+class RndOracle:             # Protocol.hs:40-45
+    rndOracleY: int
+    rndOracleZ: int
+    rndOracleYZs: List[Tuple[int, int]]
+
+
+def transcript_len(Q: int) -> int:
+    return 8 + 2 * Q
+
+
+def draw_transcript(Q: int, rng=None) -> List[int]:
+    """The prover's `rnd` draws in draw order: c_{n+1..n+4}, y, z, ys, zs, then hscProve's u, v."""
+    if rng is None:
+        return [secrets.randbelow(R_MODULUS) for _ in range(transcript_len(Q))]
+    return [rng.randrange(R_MODULUS) for _ in range(transcript_len(Q))]
+
+
+class Prover:
+    """Circuit (and assignment) resident in HBM across proofs: sonic_prover_* of the C ABI."""
+
+    def __init__(self, srs: SRS, circuit: ArithCircuit):
+        w = circuit.weights
+        wL, wR, wO = fr_matrix(w.wL), fr_matrix(w.wR), fr_matrix(w.wO)
+        cs = fr_array(circuit.cs)
+        self.Q = cs.shape[0]
+        if self.Q < 1 or wL.shape[0] % self.Q:
+            raise ValueError("need Q >= 1 rectangular weight rows")
+        self.n = wL.shape[0] // self.Q
+        assert wR.shape == wL.shape and wO.shape == wL.shape
+        self._srs = srs
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().sonic_prover_new(srs._h, self.n, self.Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data,
+                                               cs.ctypes.data, C.byref(self._h)))
+
+    def set_assignment(self, assignment: Assignment):
+        aL, aR, aO = fr_array(assignment.aL), fr_array(assignment.aR), fr_array(assignment.aO)
+        assert aL.shape[0] == self.n and aR.shape[0] == self.n and aO.shape[0] == self.n
+        _lib.check(_lib.lib().sonic_prover_set_assignment(self._h, aL.ctypes.data, aR.ctypes.data, aO.ctypes.data))
+
+    def prove_bytes(self, transcript) -> bytes:
+        tr = fr_array(transcript)
+        assert tr.shape[0] == transcript_len(self.Q)
+        out = C.create_string_buffer(_lib.lib().sonic_proof_size(self.Q))
+        _lib.check(_lib.lib().sonic_prover_prove(self._h, tr.ctypes.data, out))
+        return out.raw
+
+    def close(self):
+        if self._h:
+            _lib.lib().sonic_prover_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: Optional[list] = None, rng=None):
+    """prove :: SRS -> Assignment Fr -> ArithCircuit Fr -> m (Proof, RndOracle) (Protocol.hs:47-52).
+    `transcript` makes the MonadRandom draws explicit (reproducible proofs); default: fresh draws."""
+    n = len(assignment.aL) if not isinstance(assignment.aL, np.ndarray) else fr_array(assignment.aL).shape[0]
+    Q = fr_array(circuit.cs).shape[0]
+    if srs.srsD < 7 * n:   # Protocol.hs:54-55 (checked again by the library)
+        raise _lib.SonicError(1, f"Parameter d is not large enough: {srs.srsD} should be greater than {7 * n}")
+    if transcript is None:
+        transcript = draw_transcript(Q, rng)
+    p = Prover(srs, circuit)
+    try:
+        p.set_assignment(assignment)
+        raw = p.prove_bytes(transcript)
+    finally:
+        p.close()
+    t = [int(v) % R_MODULUS for v in transcript]
+    oracle = RndOracle(t[4], t[5], list(zip(t[6:6 + Q], t[6 + Q:6 + 2 * Q])))
+    return Proof.from_bytes(raw, Q), oracle

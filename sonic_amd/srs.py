@@ -1,0 +1,70 @@
+"""Sonic.SRS (src/Sonic/SRS.hs): the structured reference string, resident in HBM."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .encoding import fr_to_bytes, g1_from_bytes
+
+
+class SRS:
+    """`data SRS` (SRS.hs:11-22), prover half.  Device layout: two arrays of 2d+1 affine points,
+    basis 0 = g^{x^e}, basis 1 = g^{alpha x^e}, slot e + d; the reference's four G1 vectors are views:
+    gNegativeX[k] = basis0[-(k+1)], gPositiveX[k] = basis0[k], gNegativeAlphaX[k] = basis1[-(k+1)],
+    gPositiveAlphaX[k] = basis1[k+1].  The G2 vectors are not held (the prover never reads them)."""
+
+    def __init__(self, handle: C.c_void_p, d: int):
+        self._h = handle
+        self.srsD = d
+
+    @classmethod
+    def new(cls, d: int, x: int, alpha: int) -> "SRS":
+        """SRS.new :: Int -> Fr -> Fr -> SRS (SRS.hs:27-43), generated on the GPU."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sonic_srs_new(d, fr_to_bytes(x), fr_to_bytes(alpha), C.byref(h)))
+        return cls(h, d)
+
+    @classmethod
+    def from_points(cls, d: int, basis0: np.ndarray, basis1: np.ndarray) -> "SRS":
+        """The record constructor: caller-supplied points, uint8 [(2d+1), 96] per basis."""
+        b0 = np.ascontiguousarray(basis0, np.uint8)
+        b1 = np.ascontiguousarray(basis1, np.uint8)
+        assert b0.size == 96 * (2 * d + 1) and b1.size == 96 * (2 * d + 1)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sonic_srs_from_points(d, b0.ctypes.data, b1.ctypes.data, C.byref(h)))
+        return cls(h, d)
+
+    def points(self, basis: int, e0: int, n: int) -> np.ndarray:
+        out = np.zeros((n, 96), np.uint8)
+        _lib.check(_lib.lib().sonic_srs_get_points(self._h, basis, e0, n, out.ctypes.data))
+        return out
+
+    def _one(self, name, basis, e, k, length):
+        if not (0 <= k < length):   # CommitmentScheme.hs:70-73
+            raise IndexError(f"{name} is not long enough: {k} >= {length}")
+        return g1_from_bytes(self.points(basis, e, 1)[0].tobytes())
+
+    def gNegativeX(self, k):
+        return self._one("gNegativeX", 0, -(k + 1), k, self.srsD)
+
+    def gPositiveX(self, k):
+        return self._one("gPositiveX", 0, k, k, self.srsD + 1)
+
+    def gNegativeAlphaX(self, k):
+        return self._one("gNegativeAlphaX", 1, -(k + 1), k, self.srsD)
+
+    def gPositiveAlphaX(self, k):
+        return self._one("gPositiveAlphaX", 1, k + 1, k, self.srsD)
+
+    def close(self):
+        if self._h:
+            _lib.lib().sonic_srs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

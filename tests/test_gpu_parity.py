@@ -1,0 +1,239 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bit-exact (integer / byte work): every comparison is ==."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from util import NCPU, R, big_circuit, circuit_arrays, fr_bytes, rand_fr_array
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def srs_pair(sonic, orc):
+    """One SRS on both sides (d = 2^12): GPU-generated, and the oracle's."""
+    pyr = random.Random(11)
+    d = 1 << 12
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    return d, x, alpha, sonic.SRS.new(d, x, alpha), orc.SRS(d, x, alpha, threads=NCPU)
+
+
+def test_srs_new_matches_oracle(srs_pair):
+    """SRS.new (SRS.hs:27-43): every G1 element of both bases, including the omitted g^alpha slot."""
+    d, x, alpha, g, o = srs_pair
+    for basis in (0, 1):
+        assert np.array_equal(g.points(basis, -d, 2 * d + 1), o.points(basis, -d, 2 * d + 1))
+    assert g.points(1, 0, 1).tobytes() == bytes(96)
+
+
+def test_srs_index_maps(srs_pair, ref):
+    """the four reference vectors as views (SRS.hs:33-39), against the literal python restatement"""
+    d, x, alpha, g, _ = srs_pair
+    s = ref.SRS(d, x, alpha)
+    for k in (0, 1, 5, d - 1):
+        assert g.gNegativeX(k) == s.gNegativeX(k)
+        assert g.gPositiveX(k) == s.gPositiveX(k)
+        assert g.gNegativeAlphaX(k) == s.gNegativeAlphaX(k)
+        assert g.gPositiveAlphaX(k) == s.gPositiveAlphaX(k)
+    assert g.gPositiveX(d) == s.gPositiveX(d)
+    with pytest.raises(IndexError):
+        g.gPositiveAlphaX(d)
+
+
+@pytest.mark.parametrize("n,kind", [(0, "rand"), (1, "rand"), (2, "rand"), (63, "rand"), (64, "edge"), (65, "rand"),
+                                    (1000, "rand"), (1024, "same"), (4097, "edge"), (8000, "same"), (8191, "rand")])
+def test_msm_srs_slices(sonic, orc, srs_pair, n, kind):
+    """the commitPoly/openPoly fold (CommitmentScheme.hs:26-29,45-48) on SRS slices; edge scalars
+    0, 1, r-1, (r+-1)/2; n equal scalars (heavy-bucket path)."""
+    from sonic_amd.commitment import msm_g1_srs
+    d, _, _, g, o = srs_pair
+    pyr = random.Random(n * 7 + len(kind))
+    if kind == "rand":
+        vals = [pyr.randrange(R) for _ in range(n)]
+    elif kind == "edge":
+        vals = [[0, 1, R - 1, 2, R - 2, (R - 1) // 2, (R + 1) // 2][i % 7] for i in range(n)]
+    else:
+        vals = [pyr.randrange(R)] * n
+    sc = fr_bytes(vals)
+    for basis in (0, 1):
+        e0 = 1 if (basis == 1 and n <= d) else -(n // 2)
+        assert msm_g1_srs(g, basis, e0, sc) == orc.msm_srs(o, basis, e0, sc, 1, NCPU)
+
+
+@pytest.mark.parametrize("c", [4, 7, 11, 16])
+def test_msm_window_sizes(sonic, orc, srs_pair, c):
+    from sonic_amd import _lib
+    from sonic_amd.commitment import msm_g1_srs
+    d, _, _, g, o = srs_pair
+    sc = rand_fr_array(np.random.default_rng(c), 3000)
+    _lib.lib().sonic_msm_set_window(c)
+    try:
+        assert msm_g1_srs(g, 0, -1500, sc) == orc.msm_srs(o, 0, -1500, sc, 1, NCPU)
+    finally:
+        _lib.lib().sonic_msm_set_window(0)
+
+
+def test_msm_general_points(sonic, orc, srs_pair):
+    """caller-supplied points: repeated points (P+P), P and -P, infinity, x = 1 style all-equal bases
+    (bench/Main.hs:23 makes every SRS element equal g)"""
+    d, _, _, g, o = srs_pair
+    n = 500
+    pts = o.points(0, -10, n).copy()
+    pts[10] = pts[11]
+    pts[20] = 0
+    neg = pts[30].copy()
+    y = int.from_bytes(neg[48:].tobytes(), "little")
+    Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    neg[48:] = np.frombuffer((Q - y).to_bytes(48, "little"), np.uint8)
+    pts[31] = neg
+    sc = rand_fr_array(np.random.default_rng(5), n)
+    sc[31] = sc[30]          # s*P + s*(-P) = O
+    assert sonic.msm_g1(pts, sc) == orc.msm(pts, sc, 1, NCPU)
+    same = np.repeat(pts[:1], 300, axis=0)
+    sc2 = rand_fr_array(np.random.default_rng(6), 300)
+    assert sonic.msm_g1(same, sc2) == orc.msm(same, sc2, 1, NCPU)
+
+
+def test_msm_rejects_bad_encoding(sonic, srs_pair):
+    d, _, _, g, o = srs_pair
+    pts = o.points(0, 0, 4).copy()
+    sc = fr_bytes([1, 2, 3, 4])
+    bad = sc.copy(); bad[2] = 0xFF                     # >= r
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.msm_g1(pts, bad)
+    assert e.value.code == 3
+    off = pts.copy(); off[1, 0] ^= 1                   # not on the curve
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.msm_g1(off, sc)
+    assert e.value.code == 3
+
+
+@pytest.mark.parametrize("log2n", [0, 1, 3, 10, 11, 12, 14])
+def test_ntt_matches_oracle(sonic, orc, log2n):
+    from sonic_amd import _lib
+    n = 1 << log2n
+    a = rand_fr_array(np.random.default_rng(log2n), n)
+    for inverse in (0, 1):
+        got = a.copy()
+        _lib.check(_lib.lib().sonic_ntt_fr(got.ctypes.data, log2n, inverse))
+        assert np.array_equal(got, orc.ntt(a, bool(inverse)))
+    rt = a.copy()
+    _lib.check(_lib.lib().sonic_ntt_fr(rt.ctypes.data, log2n, 0))
+    _lib.check(_lib.lib().sonic_ntt_fr(rt.ctypes.data, log2n, 1))
+    assert np.array_equal(rt, a)
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (3, 5), (100, 37), (1025, 1024), (5000, 7000)])
+def test_poly_mul_matches_schoolbook(sonic, orc, na, nb):
+    """the `*` of Constraints.hs:61 as a dense product, against the oracle's schoolbook convolution"""
+    from sonic_amd import _lib
+    g = np.random.default_rng(na * 31 + nb)
+    a, b = rand_fr_array(g, na), rand_fr_array(g, nb)
+    out = np.zeros((na + nb - 1, 32), np.uint8)
+    _lib.check(_lib.lib().sonic_poly_mul_fr(a.ctypes.data, na, b.ctypes.data, nb, out.ctypes.data))
+    assert np.array_equal(out, orc.poly_mul(a, b, use_ntt=(na * nb > 4_000_000)))
+
+
+def _sparse_poly(pyr, lo, hi, density=0.7, hole=None):
+    exps = [e for e in range(lo, hi + 1) if pyr.random() < density and e != hole]
+    return {e: pyr.randrange(1, R) for e in exps}
+
+
+def test_commit_open_match_oracle(sonic, orc, srs_pair):
+    """commitPoly / openPoly on sparse Laurent polynomials: both bases, shifts (max = n and max = d),
+    duplicates summed, zero coefficients ignored"""
+    d, x, alpha, g, o = srs_pair
+    pyr = random.Random(3)
+    for (lo, hi, maxm) in [(-40, 30, d), (-200, 100, 100), (-1, 1, d), (5, 9, d), (-9, -5, d), (-3000, 2500, d)]:
+        hole = maxm - d if lo <= maxm - d <= hi else None
+        f = _sparse_poly(pyr, lo, hi, hole=0 if maxm == d else hole)
+        exps = np.array(sorted(f), np.int64)
+        co = fr_bytes([f[e] for e in sorted(f)])
+        assert sonic.g1_to_bytes(sonic.commit_poly(g, maxm, f)) == orc.commit_poly(o, maxm, exps, co)
+        z = pyr.randrange(1, R)
+        fz, W = sonic.open_poly(g, z, f)
+        ofz, oW = orc.open_poly(o, z, exps, co)
+        assert fz == ofz and sonic.g1_to_bytes(W) == oW
+    # repeated exponents are summed, explicit zeros are harmless
+    f = [(3, 5), (3, R - 5), (2, 7), (-4, 0), (1, 9)]
+    assert sonic.commit_poly(g, d, f) == sonic.commit_poly(g, d, {2: 7, 1: 9})
+
+
+def test_commit_error_contract(sonic, srs_pair):
+    """`index` panics (CommitmentScheme.hs:70-73): exponent past the vector end, and the e' = 0 hole"""
+    d, _, _, g, _ = srs_pair
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.commit_poly(g, d, {0: 5, 1: 1})
+    assert e.value.code == 2
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.commit_poly(g, d, {d + 1: 5})
+    assert e.value.code == 2
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.open_poly(g, 7, {d + 2: 5, 0: 1})
+    assert e.value.code == 2
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.open_poly(g, 0, {-2: 5, 1: 1})
+    assert e.value.code == 4
+
+
+@pytest.mark.parametrize("n,Q", [(1, 1), (2, 2), (3, 1), (8, 2), (20, 5), (64, 3), (257, 2)])
+def test_prove_matches_oracle(sonic, orc, ref, srs_pair, n, Q):
+    """prove (Protocol.hs:47-109 + Signature.hs:38-72): proof bytes equal the oracle's on the same
+    circuit, SRS and transcript; rndCircuit generator of test/Test/Reference.hs:125-169"""
+    d, x, alpha, g, o = srs_pair
+    pyr = random.Random(n * 100 + Q)
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+    want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], fr_bytes(tr))
+    circuit = sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3])
+    proof, oracle = sonic.prove(g, sonic.Assignment(*asg), circuit, transcript=tr)
+    assert proof.to_bytes() == want
+    assert oracle.rndOracleY == tr[4] and oracle.rndOracleZ == tr[5]
+    assert proof.prHscProof.hscU == tr[6 + 2 * Q] and proof.prHscProof.hscV == tr[7 + 2 * Q]
+
+
+def test_prove_example_circuits(sonic, ref, srs_pair):
+    """arithCircuitExample1/2 (test/Test/Reference.hs:38-90, examples/Main.hs:38-63) against the literal
+    python restatement, plus the reference's own acceptance test (verify . prove) through the trapdoor"""
+    d, x, alpha, g, _ = srs_pair
+    s = ref.SRS(d, x, alpha)
+    pyr = random.Random(99)
+    for circ, asg in (ref.arith_circuit_example1(), ref.arith_circuit_example2(12)):
+        Q = len(circ[0])
+        tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+        proof, _ = sonic.prove(g, sonic.Assignment(*asg), sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3]), transcript=tr)
+        want, _ = ref.prove(s, asg, circ, tr)
+        assert proof.to_bytes() == ref.proof_to_bytes(want)
+        assert ref.verify_exponent(s, circ, asg, tr, want)
+
+
+def test_prove_error_contract(sonic, ref, srs_pair):
+    d, x, alpha, g, _ = srs_pair
+    pyr = random.Random(5)
+    n = d // 7 + 1                                      # d < 7n  -> Protocol.hs:54-55
+    circ, asg = ref.rnd_circuit(pyr, n, 1)
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.prove(g, sonic.Assignment(*asg), sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3]))
+    assert e.value.code == 1
+    # unsatisfied constraint system: t(X,y) has a constant term -> commitPoly indexes -1
+    circ, asg = ref.rnd_circuit(pyr, 4, 2)
+    bad_cs = list(circ[3]); bad_cs[0] = (bad_cs[0] + 1) % R
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.prove(g, sonic.Assignment(*asg), sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), bad_cs))
+    assert e.value.code == 2
+
+
+def test_prover_handle_reuse(sonic, orc, ref, srs_pair):
+    """circuit resident in HBM, several assignments / transcripts through one handle"""
+    d, x, alpha, g, o = srs_pair
+    pyr = random.Random(8)
+    n, Q = 33, 2
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    p = sonic.Prover(g, sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3]))
+    p.set_assignment(sonic.Assignment(*asg))
+    for _ in range(3):
+        tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+        want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+        assert p.prove_bytes(tr) == want

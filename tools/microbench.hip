@@ -1,0 +1,109 @@
+// Microbenchmarks that size the integer roofline of the MSM on one MI355X:
+//   mad     v_mad_u64_u32 issue rate (independent chains, all CUs)
+//   fqmul   Montgomery products / s (the library's fp_mul<Fq>)
+//   madd    XYZZ mixed additions / s
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I sonic_amd/csrc tools/microbench.hip -o tools/microbench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "g1.hpp"
+using namespace sonic;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ void k_mad(uint64_t* out, uint32_t a, uint32_t b, int iters) {
+  uint64_t acc[8];
+  for (int k = 0; k < 8; k++) acc[k] = threadIdx.x + k;
+  uint32_t x = a + threadIdx.x, y = b;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = (uint64_t)x * y + acc[k];
+    x += 3;
+  }
+  uint64_t s = 0;
+  for (int k = 0; k < 8; k++) s ^= acc[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_mul32(uint32_t* out, uint32_t a, uint32_t b, int iters) {
+  uint32_t acc[8];
+  for (int k = 0; k < 8; k++) acc[k] = threadIdx.x + k;
+  uint32_t y = b + threadIdx.x;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = acc[k] * y + a;   // v_mad_u32_u24? no: v_mul_lo_u32 + add
+    y += 3;
+  }
+  uint32_t s = 0;
+  for (int k = 0; k < 8; k++) s ^= acc[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_fma64(double* out, double a, double b, int iters) {
+  double acc[8];
+  for (int k = 0; k < 8; k++) acc[k] = threadIdx.x + k;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = __builtin_fma(acc[k], a, b);
+  }
+  double s = 0;
+  for (int k = 0; k < 8; k++) s += acc[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_add32(uint32_t* out, uint32_t a, int iters) {
+  uint32_t acc[8];
+  for (int k = 0; k < 8; k++) acc[k] = threadIdx.x + k;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = (acc[k] + a) ^ (acc[k] >> 3);
+  }
+  uint32_t s = 0;
+  for (int k = 0; k < 8; k++) s ^= acc[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_fqmul(Fq* out, int iters) {
+  Fq a = Fq::one(), b = Fq::r2();
+  a.l[0] += threadIdx.x; b.l[1] ^= blockIdx.x;
+  for (int i = 0; i < iters; i++) { a = fp_mul(a, b); b = fp_mul(b, a); }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fp_add(a, b);
+}
+__global__ __launch_bounds__(256) void k_madd(G1XYZZ* out, const G1Affine* pts, int iters) {
+  G1XYZZ acc = G1XYZZ::inf();
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; i < iters; i++) acc = g1_add_mixed(acc, pts[(t + i * 7919) & 4095]);
+  out[t] = acc;
+}
+__global__ void k_mkpts(G1Affine* pts) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  G1Affine g; uint32_t gx[12] = G1_GEN_X_MONT, gy[12] = G1_GEN_Y_MONT;
+  for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+  G1XYZZ a = g1_mul_small(G1XYZZ::from_affine(g), (uint32_t)t + 1);
+  pts[t] = g1_to_affine(a);
+}
+
+template <class F> float time_ms(F f, int reps) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  f(); hipDeviceSynchronize();
+  hipEventRecord(a); for (int i = 0; i < reps; i++) f(); hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+
+int main() {
+  int dev = 0; CK(hipSetDevice(dev));
+  hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, dev));
+  printf("device: %s CUs=%d clock=%d kHz\n", pr.name, pr.multiProcessorCount, pr.clockRate);
+  const int blocks = pr.multiProcessorCount * 8, threads = 256;
+  void* buf; CK(hipMalloc(&buf, (size_t)blocks * threads * sizeof(G1XYZZ)));
+  G1Affine* pts; CK(hipMalloc(&pts, 4096 * sizeof(G1Affine)));
+  hipLaunchKernelGGL(k_mkpts, 16, 256, 0, 0, pts); CK(hipDeviceSynchronize());
+  const double lanes = (double)blocks * threads;
+  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_mad, blocks, threads, 0, 0, (uint64_t*)buf, 12345u, 67891u, it); }, 5);
+    printf("v_mad_u64_u32: %.3f ms -> %.3e mad/s  (%.2f lane-ops/clk/CU at 2.4GHz)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
+  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_mul32, blocks, threads, 0, 0, (uint32_t*)buf, 12345u, 67891u, it); }, 5);
+    printf("mul_lo+add:    %.3f ms -> %.3e op/s  (%.2f lane-ops/clk/CU)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
+  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_fma64, blocks, threads, 0, 0, (double*)buf, 1.0000001, 0.5, it); }, 5);
+    printf("v_fma_f64:     %.3f ms -> %.3e fma/s (%.2f lane-ops/clk/CU)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
+  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_add32, blocks, threads, 0, 0, (uint32_t*)buf, 12345u, it); }, 5);
+    printf("add+xor+shift: %.3f ms -> %.3e triple/s (%.2f lane-triples/clk/CU)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
+  { int it = 256; float ms = time_ms([&] { hipLaunchKernelGGL(k_fqmul, blocks, threads, 0, 0, (Fq*)buf, it); }, 3);
+    printf("fq_mul:        %.3f ms -> %.3e mul/s\n", ms, lanes * it * 2 / (ms * 1e-3)); }
+  { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
+    printf("g1_add_mixed:  %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
+  return 0;
+}
