@@ -54,7 +54,7 @@ enum {
 
 #define SONIC_FR_BYTES 32
 #define SONIC_G1_BYTES 96
-#define SONIC_G1_PARTIAL_BYTES 144   /* un-normalised XYZZ accumulator exchanged between ranks */
+#define SONIC_G1_PARTIAL_BYTES 192   /* un-normalised XYZZ accumulator exchanged between ranks */
 
 typedef struct sonic_srs sonic_srs_t;
 typedef struct sonic_prover sonic_prover_t;
@@ -95,7 +95,7 @@ int sonic_msm_g1_srs_dev(const sonic_srs_t* srs, int basis, int64_t e0, const vo
                          uint8_t out_g1[96]);
 /* one rank's share of a range-sharded MSM: the un-normalised partial sum */
 int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars,
-                                 int64_t n, uint8_t out_partial[144]);
+                                 int64_t n, uint8_t out_partial[192]);
 /* curve addition of k partials (RCCL has no such reduction op) + normalisation */
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]);
 /* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n) */

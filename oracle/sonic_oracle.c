@@ -196,9 +196,9 @@ typedef struct { range_fn fn; void *ctx; long lo, hi; int tid; } range_job;
 static void *range_tramp(void *p) { range_job *j = p; j->fn(j->ctx, j->lo, j->hi, j->tid); return NULL; }
 static void parallel_for(long n, int threads, range_fn fn, void *ctx) {
   if (threads < 1) threads = 1;
-  if (threads > 64) threads = 64;
+  if (threads > 512) threads = 512;
   if (threads == 1 || n < 2) { fn(ctx, 0, n, 0); return; }
-  pthread_t th[64]; range_job jobs[64];
+  pthread_t th[512]; range_job jobs[512];
   long per = (n + threads - 1) / threads;
   int used = 0;
   for (int t = 0; t < threads; t++) {
@@ -222,7 +222,7 @@ static void msm_fold(g1j_t *out, const g1a_t *pts, const fr_t *scal_mont, long n
   *out = acc;
 }
 
-typedef struct { const g1a_t *pts; const u64 *scal; long n; int c, W; g1j_t *win; } pip_ctx;
+typedef struct { const g1a_t *pts; const u64 *scal; long n; int c, W, S; g1j_t *win; } pip_ctx;
 static inline unsigned get_bits(const u64 *k, int pos, int c) {
   if (pos >= 256) return 0;
   int li = pos / 64, sh = pos % 64;
@@ -230,34 +230,45 @@ static inline unsigned get_bits(const u64 *k, int pos, int c) {
   if (sh + c > 64 && li + 1 < 4) v |= k[li + 1] << (64 - sh);
   return (unsigned)(v & (((u64)1 << c) - 1));
 }
-static void pip_windows(void *vctx, long wlo, long whi, int tid) {
+/* task t = (window w, slice s): window sum of the slice's points */
+static void pip_tasks(void *vctx, long tlo, long thi, int tid) {
   (void)tid;
   pip_ctx *x = vctx;
   long nb = (long)1 << x->c;
   g1j_t *buckets = malloc(sizeof(g1j_t) * nb);
-  for (long w = wlo; w < whi; w++) {
+  for (long t = tlo; t < thi; t++) {
+    long w = t / x->S, s = t % x->S;
+    long per = (x->n + x->S - 1) / x->S, lo = s * per, hi = lo + per > x->n ? x->n : lo + per;
     for (long b = 0; b < nb; b++) g1j_set_inf(&buckets[b]);
-    for (long i = 0; i < x->n; i++) {
+    for (long i = lo; i < hi; i++) {
       unsigned dgt = get_bits(x->scal + 4 * i, (int)w * x->c, x->c);
       if (dgt) g1j_add_affine(&buckets[dgt], &buckets[dgt], &x->pts[i]);
     }
     g1j_t run, sum; g1j_set_inf(&run); g1j_set_inf(&sum);
     for (long b = nb - 1; b >= 1; b--) { g1j_add(&run, &run, &buckets[b]); g1j_add(&sum, &sum, &run); }
-    x->win[w] = sum;
+    x->win[t] = sum;
   }
   free(buckets);
 }
 static void msm_pippenger(g1j_t *out, const g1a_t *pts, const fr_t *scal_mont, long n, int threads) {
   if (n <= 32) { msm_fold(out, pts, scal_mont, n); return; }
-  int c = 4; while ((1L << (c + 5)) < n && c < 16) c++;   /* c ~ log2(n) - 5, capped */
+  if (threads < 1) threads = 1;
+  int c0 = 4; while ((1L << (c0 + 5)) < n && c0 < 16) c0++;   /* c ~ log2(n) - 5, capped */
+  int W0 = (255 + c0 - 1) / c0;
+  int S = (threads + W0 - 1) / W0;                /* point slices per window so that W*S >= threads */
+  long per = (n + S - 1) / S;
+  int c = 4; while ((1L << (c + 5)) < per && c < 16) c++;
   int W = (255 + c - 1) / c;
   u64 *scal = malloc(32 * n);
   for (long i = 0; i < n; i++) { fr_t k; fr_from_mont(&k, &scal_mont[i]); memcpy(scal + 4 * i, k.l, 32); }
-  g1j_t *win = malloc(sizeof(g1j_t) * W);
-  pip_ctx ctx = {pts, scal, n, c, W, win};
-  parallel_for(W, threads, pip_windows, &ctx);
+  g1j_t *win = malloc(sizeof(g1j_t) * W * S);
+  pip_ctx ctx = {pts, scal, n, c, W, S, win};
+  parallel_for((long)W * S, threads, pip_tasks, &ctx);
   g1j_t acc; g1j_set_inf(&acc);
-  for (int w = W - 1; w >= 0; w--) { for (int k = 0; k < c; k++) g1j_double(&acc, &acc); g1j_add(&acc, &acc, &win[w]); }
+  for (int w = W - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) g1j_double(&acc, &acc);
+    for (int s = 0; s < S; s++) g1j_add(&acc, &acc, &win[w * S + s]);
+  }
   *out = acc; free(win); free(scal);
 }
 

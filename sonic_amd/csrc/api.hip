@@ -105,7 +105,7 @@ void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err) { if (n >
 
 // one MSM, finished and normalised, result on the host
 void msm_blocking(hipStream_t st, MsmWorkspace& ws, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
-                  uint8_t* out96, uint8_t* out_partial144) {
+                  uint8_t* out96, uint8_t* out_partial192) {
   MsmPlan pl = msm_plan(n > 0 ? n : 1);
   DevBuf slot(sizeof(MsmSlot));
   msm_enqueue(st, ws, pl, d_pts, d_sc, n, mont, slot.as<MsmSlot>());
@@ -114,7 +114,7 @@ void msm_blocking(hipStream_t st, MsmWorkspace& ws, const G1Affine* d_pts, const
   HIP_OK(hipStreamSynchronize(st));
   G1XYZZ sum = msm_finish_host(h);
   if (out96) g1_canonical_bytes_host(sum, out96);
-  if (out_partial144) memcpy(out_partial144, &sum, sizeof sum);
+  if (out_partial192) memcpy(out_partial192, &sum, sizeof sum);
 }
 
 }  // namespace sonic
@@ -239,7 +239,7 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
 }
 
 static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, const uint8_t* h_scalars,
-                          int64_t n, uint8_t* out96, uint8_t* out144) {
+                          int64_t n, uint8_t* out96, uint8_t* out192) {
   API_BEGIN
   if (!srs || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
   if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
@@ -258,7 +258,7 @@ static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const v
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) { set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
-  msm_blocking(st, shared_msm_ws(), srs->basis(basis) + (e0 + srs->d), dsc, n, false, out96, out144);
+  msm_blocking(st, shared_msm_ws(), srs->basis(basis) + (e0 + srs->d), dsc, n, false, out96, out192);
   API_END
 }
 
@@ -268,7 +268,7 @@ int sonic_msm_g1_srs(const sonic_srs_t* srs, int basis, int64_t e0, const uint8_
 int sonic_msm_g1_srs_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, uint8_t out_g1[96]) {
   return msm_srs_common(srs, basis, e0, d_scalars, nullptr, n, out_g1, nullptr);
 }
-int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, uint8_t out_partial[144]) {
+int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, uint8_t out_partial[192]) {
   return msm_srs_common(srs, basis, e0, d_scalars, nullptr, n, nullptr, out_partial);
 }
 

@@ -4,7 +4,7 @@
 //
 // Storage in HBM: affine (x, y), Montgomery form, 2 x 12 x u32 = 96 B, infinity = (0, 0)
 // ((0,0) is not on the curve).  Accumulators: extended Jacobian "XYZZ" (x = X/ZZ, y = Y/ZZZ,
-// ZZ^3 = ZZZ^2; infinity = ZZ == 0), 144 B -- the cheapest mixed addition (8M + 2S) and no
+// ZZ^3 = ZZZ^2; infinity = ZZ == 0), 192 B -- the cheapest mixed addition (8M + 2S) and no
 // inversion until the very end.  Every formula handles P+P, P+(-P) and infinity operands: they do
 // occur (bench/Main.hs:23 uses x = 1, so all SRS points coincide).
 #pragma once

@@ -23,7 +23,7 @@ void fr_to_mont_enqueue(hipStream_t st, Fr* d, long n, int* d_err);
 void fr_from_mont_enqueue(hipStream_t st, Fr* d, long n);
 void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err);
 void msm_blocking(hipStream_t st, MsmWorkspace& ws, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
-                  uint8_t* out96, uint8_t* out_partial144);
+                  uint8_t* out96, uint8_t* out_partial192);
 
 // SRS generation (srs.hip): fills both bases of `s` from x, alpha (standard-form Fr on the host)
 void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha_std);

@@ -95,7 +95,7 @@ void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha
   Fr hp[3];
   HIP_OK(hipMemcpyAsync(hp, par.p, sizeof hp, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
-  // process in slabs to bound the XYZZ scratch (2 x 144 B per slot)
+  // process in slabs to bound the XYZZ scratch (2 x 192 B per slot)
   const long SLAB = 1L << 20;
   DevBuf x0(sizeof(G1XYZZ) * (n < SLAB ? n : SLAB)), x1(sizeof(G1XYZZ) * (n < SLAB ? n : SLAB)), pref(sizeof(Fq) * (n < SLAB ? n : SLAB));
   for (long base = 0; base < n; base += SLAB) {

@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/sonic_hip.h declares; without a GPU every
+entry point refuses (no CPU fallback); the product package never imports the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "sonic_amd", "csrc"), "-s", "-j8"])
+    from sonic_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "sonic_hip.h")).read()
+    declared = set(re.findall(r"\b(sonic_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    L = C.CDLL(built.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(built.EXPORTED), declared ^ set(built.EXPORTED)
+
+
+def _have_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(_have_gpu(), reason="this box has a GPU; the refusal path needs none")
+def test_no_device_is_loud(built):
+    L = built.lib()
+    assert L.sonic_init(0) == 6
+    assert "no CPU fallback" in built.last_error()
+    out = C.create_string_buffer(96)
+    assert L.sonic_msm_g1(None, None, 0, out) == 6
+    h = C.c_void_p()
+    assert L.sonic_srs_new(16, (1).to_bytes(32, "little"), (2).to_bytes(32, "little"), C.byref(h)) == 6
+    import sonic_amd
+    with pytest.raises(sonic_amd.SonicError) as e:
+        sonic_amd.SRS.new(16, 3, 5)
+    assert e.value.code == 6
+
+
+def test_missing_extension_is_loud(monkeypatch, built):
+    monkeypatch.setattr(built, "_lib", None)
+    monkeypatch.setattr(built, "LIB_PATH", os.path.join(ROOT, "sonic_amd", "csrc", "does_not_exist.so"))
+    with pytest.raises(ImportError):
+        built.lib()
+
+
+def test_product_never_touches_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sonic_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle/", r"libsonic_oracle", r"sonic_ref", r"\borc\."):
+                    assert not re.search(pat, src), (f, pat)

@@ -1,0 +1,201 @@
+"""The oracle against itself and against the committed golden vectors (CPU, no GPU):
+  * constants (q, r, generator) checked numerically,
+  * the reference's own QuickCheck properties restated on the literal python restatement
+    (test/Test/Constraints.hs, test/Test/CommitmentScheme.hs, test/Test/Signature.hs,
+    test/Test/Protocol.hs) -- pairing checks through the known-trapdoor Fr identity,
+  * the plain-C oracle == the python restatement (goldens + fresh random cases),
+  * the error contract of prove / commitPoly.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from util import NCPU, R, circuit_arrays, fr_bytes, rand_fr_array
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _ints(xs):
+    return [int(v, 16) for v in xs]
+
+
+def _case_inputs(c):
+    wL, wR, wO = ([_ints(r) for r in c[k]] for k in ("wL", "wR", "wO"))
+    return (wL, wR, wO, _ints(c["cs"])), (_ints(c["aL"]), _ints(c["aR"]), _ints(c["aO"])), _ints(c["transcript"])
+
+
+def test_constants(ref):
+    assert ref.selfcheck()
+
+
+def test_python_oracle_reproduces_goldens(ref):
+    cases = json.load(open(os.path.join(GOLD, "prove_small.json")))["cases"]
+    for c in cases[:4]:          # the literal restatement is slow; the rest is covered through the C oracle
+        circ, asg, tr = _case_inputs(c)
+        srs = ref.SRS(c["d"], int(c["x"], 16), int(c["alpha"], 16))
+        proof, _ = ref.prove(srs, asg, circ, tr)
+        assert ref.proof_to_bytes(proof).hex() == c["proof"]
+
+
+def test_c_oracle_matches_prove_goldens(orc):
+    for c in json.load(open(os.path.join(GOLD, "prove_small.json")))["cases"]:
+        circ, asg, tr = _case_inputs(c)
+        srs = orc.SRS(c["d"], int(c["x"], 16), int(c["alpha"], 16), threads=NCPU)
+        flat = lambda m: fr_bytes([v for r_ in m for v in r_])
+        for mode in (0, 1):                   # reference-shaped fold, and Pippenger
+            for use_ntt in (False, True):     # schoolbook (the reference's sparse convolution), and NTT
+                orc.set_mode(mode, 4)
+                got = orc.prove(srs, c["n"], c["Q"], flat(circ[0]), flat(circ[1]), flat(circ[2]), fr_bytes(circ[3]),
+                                fr_bytes(asg[0]), fr_bytes(asg[1]), fr_bytes(asg[2]), fr_bytes(tr), use_ntt)
+                assert got.hex() == c["proof"], (c["name"], mode, use_ntt)
+        orc.set_mode(1, NCPU)
+
+
+def test_c_oracle_matches_commitment_goldens(orc):
+    g = json.load(open(os.path.join(GOLD, "commitment_small.json")))
+    d = g["d"]
+    srs = orc.SRS(d, int(g["x"], 16), int(g["alpha"], 16), threads=4)
+    for k, v in g["srs"]["gNegativeX"].items():
+        assert srs.points(0, -(int(k) + 1), 1)[0].tobytes().hex() == v          # SRS.hs:33
+    for k, v in g["srs"]["gPositiveX"].items():
+        assert srs.points(0, int(k), 1)[0].tobytes().hex() == v                  # SRS.hs:34
+    for k, v in g["srs"]["gNegativeAlphaX"].items():
+        assert srs.points(1, -(int(k) + 1), 1)[0].tobytes().hex() == v           # SRS.hs:37
+    for k, v in g["srs"]["gPositiveAlphaX"].items():
+        assert srs.points(1, int(k) + 1, 1)[0].tobytes().hex() == v              # SRS.hs:39
+    assert srs.points(1, 0, 1)[0].tobytes() == bytes(96)                          # g^alpha omitted, SRS.hs:38
+    for p in g["polys"]:
+        exps = np.array([e for e, _ in p["terms"]], np.int64)
+        co = fr_bytes([int(c, 16) for _, c in p["terms"]])
+        assert orc.commit_poly(srs, p["max"], exps, co).hex() == p["commit"]
+        fz, W = orc.open_poly(srs, int(p["z"], 16), exps, co)
+        assert fz == int(p["fz"], 16) and W.hex() == p["open"]
+    gen = orc.g1_gen()
+    for m in g["gen_multiples"]:
+        assert orc.g1_mul(gen, int(m["k"], 16)).hex() == m["point"]
+
+
+def test_c_oracle_matches_python_on_fresh_cases(orc, ref):
+    pyr = random.Random(1234)
+    for n, Q in [(1, 1), (2, 1), (4, 4), (6, 2)]:
+        circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+        d = max(7 * n, 4 * n + 8) + pyr.randrange(0, 4)
+        x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+        tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+        proof, _ = ref.prove(ref.SRS(d, x, alpha), asg, circ, tr)
+        got = orc.prove(orc.SRS(d, x, alpha, threads=4), n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], fr_bytes(tr))
+        assert got == ref.proof_to_bytes(proof)
+
+
+# ---- the reference's properties, restated ----------------------------------------------------
+def test_prop_linear_constraints(ref):
+    """test/Test/Constraints.hs:19-27"""
+    pyr = random.Random(1)
+    for _ in range(10):
+        n = pyr.randint(1, 20)
+        (wL, wR, wO, cs), (aL, aR, aO) = ref.rnd_circuit(pyr, n, pyr.randint(1, n))
+        dot = lambda a, b: sum(x * y for x, y in zip(a, b)) % R
+        assert all((dot(aL, wL[i]) + dot(aR, wR[i]) + dot(aO, wO[i])) % R == cs[i] for i in range(len(cs)))
+
+
+def test_prop_rpoly(ref):
+    """r(X,Y) at (x,y) == r(XY,1) at xy (test/Test/Constraints.hs:29-34): why scaling c_e by y^e is evalY"""
+    pyr = random.Random(2)
+    aL = [pyr.randrange(R) for _ in range(3)]; aR = [pyr.randrange(R) for _ in range(3)]
+    rP = ref.r_poly(aL, aR, [a * b % R for a, b in zip(aL, aR)])
+    x, y = pyr.randrange(1, R), pyr.randrange(1, R)
+    assert ref.lp_eval(ref.eval_y(y, rP), x) == ref.lp_eval(ref.eval_y(1, rP), x * y % R)
+
+
+def test_prop_zero_constant_terms(ref):
+    """test/Test/Constraints.hs:37-83: no X^0 term in r, s, r+s; X^0 coefficient of t(X,Y) is zero"""
+    pyr = random.Random(3)
+    for _ in range(4):
+        n = pyr.randint(1, 8)
+        (wL, wR, wO, cs), (aL, aR, aO) = ref.rnd_circuit(pyr, n, pyr.randint(1, n))
+        rXY, sXY = ref.r_poly(aL, aR, aO), ref.s_poly(wL, wR, wO)
+        assert 0 not in rXY and 0 not in sXY and 0 not in ref.biv_add(rXY, sXY)
+        assert 0 not in ref.t_poly(rXY, sXY, ref.k_poly(cs, n))
+
+
+def test_prop_commitment_scheme(ref):
+    """test/Test/CommitmentScheme.hs:25-96: pcV (commit, open) for t(X,y) with max = d and r(X,1) with
+    max = n at z and at yz -- the pairing equation as its Fr identity on known discrete logs"""
+    pyr = random.Random(4)
+    for _ in range(3):
+        n = pyr.randint(1, 5)
+        (wL, wR, wO, cs), (aL, aR, aO) = ref.rnd_circuit(pyr, n, pyr.randint(1, n))
+        d = {1: 12, 2: 16}.get(n, 7 * n) + pyr.randrange(3)
+        x, y, z, alpha = (pyr.randrange(1, R) for _ in range(4))
+        srs = ref.SRS(d, x, alpha)
+        rXY = ref.r_poly(aL, aR, aO)
+        for maxm, fX, zz in [(d, ref.eval_y(y, ref.t_poly(rXY, ref.s_poly(wL, wR, wO), ref.k_poly(cs, n))), z),
+                             (n, ref.eval_y(1, rXY), z), (n, ref.eval_y(1, rXY), y * z % R)]:
+            F = ref.commit_poly(srs, maxm, fX)
+            v, W = ref.open_poly(srs, zz, fX)
+            Fl, Wl = ref.commit_log(srs, maxm, fX), ref.open_log(srs, zz, fX)
+            assert F == ref.g1_mul(ref.G1_GEN, Fl) and W == ref.g1_mul(ref.G1_GEN, Wl)
+            assert ref.pcv_logs(srs, maxm, Fl, zz, v, Wl)
+            assert not ref.pcv_logs(srs, maxm, Fl, zz, (v + 1) % R, Wl)
+
+
+def test_prop_protocol_accepts(ref):
+    """test/Test/Protocol.hs:14-23 and test/Test/Signature.hs:20-36: verify (prove ...) holds"""
+    pyr = random.Random(5)
+    for n, Q in [(1, 1), (3, 2)]:
+        circ, asg = ref.rnd_circuit(pyr, n, Q)
+        d = {1: 12, 2: 16}.get(n, 7 * n) + pyr.randrange(5)
+        srs = ref.SRS(d, pyr.randrange(1, R), pyr.randrange(1, R))
+        tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+        proof, _ = ref.prove(srs, asg, circ, tr)
+        assert ref.verify_exponent(srs, circ, asg, tr, proof)
+        bad = dict(proof); bad["prA"] = (proof["prA"] + 1) % R
+        assert not ref.verify_exponent(srs, circ, asg, tr, bad)
+
+
+def test_error_contract(orc, ref):
+    """d < 7n panics (Protocol.hs:54-55); n = 1, 2 need d >= 12, 16 (test/Test/Reference.hs:97-103)
+    because t(X,y) reaches X^{-4n-8}; an unsatisfied circuit puts a constant term into t -> index -1"""
+    pyr = random.Random(6)
+    circ, asg, enc = circuit_arrays(ref, pyr, 3, 2)
+    tr = fr_bytes([pyr.randrange(1, R) for _ in range(12)])
+    args = (3, 2, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+    with pytest.raises(orc.OracleError) as e:
+        orc.prove(orc.SRS(20, 5, 7, threads=2), *args)
+    assert e.value.code == 1
+    with pytest.raises(ref.DTooSmall):
+        ref.prove(ref.SRS(20, 5, 7), asg, circ, [1] * 12)
+    c1, a1, e1 = circuit_arrays(ref, pyr, 1, 1)
+    tr1 = fr_bytes([pyr.randrange(1, R) for _ in range(10)])
+    with pytest.raises(orc.OracleError) as e:
+        orc.prove(orc.SRS(11, 5, 7, threads=2), 1, 1, e1["wL"], e1["wR"], e1["wO"], e1["cs"], e1["aL"], e1["aR"], e1["aO"], tr1)
+    assert e.value.code == 2
+    with pytest.raises(IndexError):
+        ref.prove(ref.SRS(11, 5, 7), a1, c1, [pyr.randrange(1, R) for _ in range(10)])
+    orc.prove(orc.SRS(12, 5, 7, threads=2), 1, 1, e1["wL"], e1["wR"], e1["wO"], e1["cs"], e1["aL"], e1["aR"], e1["aO"], tr1)
+    bad = enc["cs"].copy(); bad[0, 0] ^= 1
+    with pytest.raises(orc.OracleError) as e:
+        orc.prove(orc.SRS(30, 5, 7, threads=2), 3, 2, enc["wL"], enc["wR"], enc["wO"], bad, enc["aL"], enc["aR"], enc["aO"], tr)
+    assert e.value.code == 2
+
+
+def test_oracle_msm_flavours_agree(orc):
+    """reference-shaped fold == threaded Pippenger, incl. structured scalars"""
+    srs = orc.SRS(600, 3, 5, threads=4)
+    g = np.random.default_rng(0)
+    sc = rand_fr_array(g, 1000)
+    sc[100:400] = sc[100]            # many equal coefficients, as in s(X,y) with an all-ones row
+    sc[500:520] = 0
+    assert orc.msm_srs(srs, 0, -500, sc, 0, 1) == orc.msm_srs(srs, 0, -500, sc, 1, 7)
+    assert orc.msm_srs(srs, 1, 1, sc[:600], 0, 1) == orc.msm_srs(srs, 1, 1, sc[:600], 1, 32)
+
+
+def test_oracle_ntt_roundtrip_and_product(orc):
+    g = np.random.default_rng(1)
+    a = rand_fr_array(g, 256)
+    assert np.array_equal(orc.ntt(orc.ntt(a), True), a)
+    b = rand_fr_array(g, 100)
+    assert np.array_equal(orc.poly_mul(a, b, True), orc.poly_mul(a, b, False))
