@@ -134,7 +134,7 @@ HD Fp<P> fp_dbl(const Fp<P>& a) { return fp_add(a, a); }
 // Montgomery product a*b*R^-1 mod p, operand-scanning CIOS over 32-bit limbs.
 // Each inner step is one 32x32+32+32 -> 64 (fits: (2^32-1)^2 + 2(2^32-1) = 2^64-1).
 template <class P>
-HD_NOINLINE Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
+HD_NOINLINE Fp<P> fp_mul_generic(const Fp<P> a, const Fp<P> b) {
   constexpr int N = P::N;
   uint32_t t[N + 2];
 #pragma unroll
@@ -170,6 +170,22 @@ HD_NOINLINE Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
   for (int i = 0; i < N; i++) r.l[i] = t[i];
   fp_reduce_once(r);
   return r;
+}
+
+}  // namespace sonic
+#include "mont_asm.hpp"   // device only: hand-scheduled gfx950 routines (tools/gen_mont_asm.py)
+namespace sonic {
+
+// On the device the product is the generated assembly routine (private calling convention, no
+// stack, 288 MADs + ~390 other VALU for Fq); on the host, and with -DSONIC_NO_ASM_MUL, the C++ loop.
+template <class P>
+HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SONIC_NO_ASM_MUL)
+  if constexpr (P::N == FQ_LIMBS) return sonic_mont_mul_fq_call(a, b);
+  else return sonic_mont_mul_fr_call(a, b);
+#else
+  return fp_mul_generic(a, b);
+#endif
 }
 
 template <class P>

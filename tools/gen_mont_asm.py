@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generates sonic_amd/csrc/mont_asm.hpp: hand-scheduled gfx950 assembly for the Montgomery
+product over Fq (12 x u32) and Fr (8 x u32).
+
+Why assembly: hipcc lowers the C++ CIOS loop to 288 v_mad_u64_u32 plus ~950 v_mov / v_lshl_add_u64
+(it materialises every 64-bit addend), i.e. ~1250 VALU instructions per Fq product.  The routine
+below needs 288 MADs + ~380 simple VALU instructions and no stack.
+
+Algorithm (row-wise CIOS with "zero-high" accumulator pairs):
+  the running value T (N+1 limbs) lives in the LOW halves of N+1 aligned VGPR pairs whose HIGH halves
+  are permanently zero, so  Q_j = a_j * b_i + T_j  is a single v_mad_u64_u32 that cannot overflow.
+  A row is: N independent MADs, one (N+1)-link carry chain that folds  sum Q_j 2^(32j)  back into T,
+  m = T_0 * inv, N more MADs  R_j = m * p_j + T_j, and a second chain that folds and shifts down a limb.
+  gfx950 needs two wait states between a VALU write of a carry (VCC / SGPR pair) and the VALU that
+  consumes it, so a naive carry chain costs 3 issue slots per link; here the chains of consecutive
+  phases run on different carry registers and are interleaved with the MADs that produce their inputs
+  and consume their outputs (list scheduling below), so no s_nop is needed in the steady state.
+
+Calling convention (private, not the C ABI): a in v[0:N), b in v[N:2N), result in v[0:N);
+return address s[30:31]; clobbers v[2N : 8N+3), s[36:57], vcc, scc.  The C++ wrapper marshals with
+physical-register constraints and calls with s_swappc_b64.
+
+Run from the repo root:  python tools/gen_mont_asm.py
+"""
+from __future__ import annotations
+
+Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+CARRY_GAP = 2          # instructions required between a VALU carry write and its VALU read
+
+
+class Ins:
+    __slots__ = ("text", "reads", "writes", "idx", "deps", "users", "prio", "carry_reads")
+
+    def __init__(self, text, reads, writes, carry_reads=()):
+        self.text, self.reads, self.writes, self.carry_reads = text, set(reads), set(writes), set(carry_reads)
+        self.deps, self.users, self.prio = set(), set(), 0
+
+
+def build(N: int, p: int):
+    A = lambda j: j
+    B = lambda j: N + j
+    TPlo = lambda j: 2 * N + 2 * j
+    TPhi = lambda j: 2 * N + 2 * j + 1
+    QA = lambda j: 4 * N + 2 + 2 * j        # pair (lo, hi)
+    QB = lambda j: 6 * N + 2 + 2 * j
+    M = 8 * N + 2
+    SP = lambda j: 36 + j                    # modulus limbs in SGPRs
+    SINV = 36 + N
+    C1, C2, C3, JUNK = "vcc", "s[50:51]", "s[52:53]", "s[54:55]"
+    inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+
+    v = lambda r: f"v{r}"
+    vp = lambda r: f"v[{r}:{r + 1}]"
+    prog = []
+    pre = [f"s_mov_b32 s{SP(j)}, 0x{(p >> (32 * j)) & 0xFFFFFFFF:08x}" for j in range(N)] + [f"s_mov_b32 s{SINV}, 0x{inv:08x}"]
+
+    def emit(text, reads, writes, carry_reads=()):
+        prog.append(Ins(text, reads, writes, carry_reads))
+
+    def add_first(dst, c, x, y):            # dst = x + y, carry-out c
+        if c == "vcc":
+            emit(f"v_add_co_u32_e32 {v(dst)}, vcc, {v(x)}, {v(y)}", [v(x), v(y)], [v(dst), c])
+        else:
+            emit(f"v_add_co_u32_e64 {v(dst)}, {c}, {v(x)}, {v(y)}", [v(x), v(y)], [v(dst), c])
+
+    def add_carry(dst, c, x, y):            # dst = x + y + c, carry-out c
+        if c == "vcc":
+            emit(f"v_addc_co_u32_e32 {v(dst)}, vcc, {v(x)}, {v(y)}, vcc", [v(x), v(y), c], [v(dst), c], [c])
+        else:
+            emit(f"v_addc_co_u32_e64 {v(dst)}, {c}, {v(x)}, {v(y)}, {c}", [v(x), v(y), c], [v(dst), c], [c])
+
+    for j in range(N + 1):
+        emit(f"v_mov_b32_e32 {v(TPhi(j))}, 0", [], [v(TPhi(j))])
+    emit(f"v_mov_b32_e32 {v(TPlo(N))}, 0", [], [v(TPlo(N))])
+
+    for i in range(N):
+        # multiplication row: Q_j = a_j * b_i + T_j
+        for j in range(N):
+            if i == 0:
+                emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(A(j))}, {v(B(i))}, 0", [v(A(j)), v(B(i))], [v(QA(j)), v(QA(j) + 1)])
+            else:
+                emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(A(j))}, {v(B(i))}, {vp(TPlo(j))}",
+                     [v(A(j)), v(B(i)), v(TPlo(j)), v(TPhi(j))], [v(QA(j)), v(QA(j) + 1)])
+        emit(f"v_mul_lo_u32 {v(M)}, {v(QA(0))}, s{SINV}", [v(QA(0))], [v(M)])
+        emit(f"v_mov_b32_e32 {v(TPlo(0))}, {v(QA(0))}", [v(QA(0))], [v(TPlo(0))])
+        c = C1
+        for j in range(1, N):
+            (add_first if j == 1 else add_carry)(TPlo(j), c, QA(j), QA(j - 1) + 1)
+        add_carry(TPlo(N), c, TPlo(N), QA(N - 1) + 1)
+        # reduction row: R_j = m * p_j + T_j, then shift down one limb
+        for j in range(N):
+            emit(f"v_mad_u64_u32 {vp(QB(j))}, {JUNK}, {v(M)}, s{SP(j)}, {vp(TPlo(j))}",
+                 [v(M), v(TPlo(j)), v(TPhi(j))], [v(QB(j)), v(QB(j) + 1)])
+        c = C2
+        for j in range(1, N):
+            (add_first if j == 1 else add_carry)(TPlo(j - 1), c, QB(j), QB(j - 1) + 1)
+        add_carry(TPlo(N - 1), c, TPlo(N), QB(N - 1) + 1)
+        emit(f"v_addc_co_u32_e64 {v(TPlo(N))}, {c}, 0, 0, {c}", [c], [v(TPlo(N)), c], [c])
+
+    # final conditional subtraction: D = T - p; result = borrow ? T : D   (T < 2p, so T_N == 0)
+    PV = lambda j: QA(0) + j                 # modulus limbs in VGPRs (QA is dead now)
+    D = lambda j: QB(0) + j
+    for j in range(N):
+        emit(f"v_mov_b32_e32 {v(PV(j))}, s{SP(j)}", [], [v(PV(j))])
+    for j in range(N):
+        if j == 0:
+            emit(f"v_sub_co_u32_e64 {v(D(j))}, {C3}, {v(TPlo(j))}, {v(PV(j))}", [v(TPlo(j)), v(PV(j))], [v(D(j)), C3])
+        else:
+            emit(f"v_subb_co_u32_e64 {v(D(j))}, {C3}, {v(TPlo(j))}, {v(PV(j))}, {C3}", [v(TPlo(j)), v(PV(j)), C3], [v(D(j)), C3], [C3])
+    for j in range(N):
+        emit(f"v_cndmask_b32_e64 {v(A(j))}, {v(D(j))}, {v(TPlo(j))}, {C3}", [v(D(j)), v(TPlo(j)), C3], [v(A(j))], [C3])
+    return pre, prog, 8 * N + 3
+
+
+def schedule(prog):
+    """Dependence-respecting list scheduling with the carry-read wait-state constraint."""
+    last_write, readers = {}, {}
+    for k, ins in enumerate(prog):
+        ins.idx = k
+        for r in ins.reads:
+            if r in last_write:
+                ins.deps.add(last_write[r])
+        for w in ins.writes:
+            if w in last_write:
+                ins.deps.add(last_write[w])           # WAW
+            for rd in readers.get(w, ()):
+                if rd != k:
+                    ins.deps.add(rd)                 # WAR
+        for r in ins.reads:
+            readers.setdefault(r, []).append(k)
+        for w in ins.writes:
+            last_write[w] = k
+            readers[w] = []
+    for ins in prog:
+        for d in ins.deps:
+            prog[d].users.add(ins.idx)
+    for ins in reversed(prog):                        # critical-path priority
+        cost = 3 if ins.text.startswith("v_mad_u64") else 1
+        ins.prio = cost + max((prog[u].prio for u in ins.users), default=0)
+    done_at, out, remaining = {}, [], set(range(len(prog)))
+    carry_written_at = {}
+    slot = 0
+    indeg = {k: len(prog[k].deps) for k in remaining}
+    ready = {k for k in remaining if indeg[k] == 0}
+    while remaining:
+        best = None
+        for k in ready:
+            ins = prog[k]
+            if any(slot - carry_written_at.get(c, -10) <= CARRY_GAP for c in ins.carry_reads):
+                continue
+            if best is None or (ins.prio, -k) > (prog[best].prio, -best):
+                best = k
+        if best is None:
+            out.append("s_nop 0")
+            slot += 1
+            continue
+        ins = prog[best]
+        out.append(ins.text)
+        for w in ins.writes:
+            if w in ("vcc",) or w.startswith("s["):
+                carry_written_at[w] = slot
+        done_at[best] = slot
+        slot += 1
+        ready.discard(best)
+        remaining.discard(best)
+        for u in ins.users:
+            indeg[u] -= 1
+            if indeg[u] == 0:
+                ready.add(u)
+    return out
+
+
+def function_text(name: str, N: int, p: int):
+    pre, prog, nv = build(N, p)
+    body = pre + schedule(prog) + ["s_setpc_b64 s[30:31]"]
+    return body, nv
+
+
+def cxx(name: str, cls: str, N: int, p: int) -> str:
+    body, nv = function_text(name, N, p)
+    nops = sum(1 for l in body if l.startswith("s_nop"))
+    mads = sum(1 for l in body if l.startswith("v_mad_u64"))
+    lines = [f"// {name}: {len(body)} instructions ({mads} v_mad_u64_u32, {nops} s_nop), VGPRs v0..v{nv - 1}"]
+    lines.append(f'extern "C" __device__ __attribute__((naked, noinline, used)) void {name}() {{')
+    lines.append("  asm volatile(")
+    for l in body:
+        lines.append(f'      "{l}\\n\\t"')
+    lines.append("  );")
+    lines.append("}")
+    ins_out = ", ".join(f'"+{{v{j}}}"(r.l[{j}])' for j in range(N))
+    ins_in = ", ".join(f'"{{v{N + j}}}"(b.l[{j}])' for j in range(N))
+    clob = [f'"v{k}"' for k in range(2 * N, nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 58))] + ['"vcc"', '"scc"', '"memory"']
+    lines.append(f"__device__ __forceinline__ {cls} {name}_call(const {cls}& a, const {cls}& b) {{")
+    lines.append(f"  {cls} r = a;")
+    lines.append("  // the scheduler of ROCm 7.2's clang mishandles (crashes on, or misorders around) asm statements with")
+    lines.append("  // this many physical-register operands: fence the marshalling copies and the call on both sides")
+    lines.append("  __builtin_amdgcn_sched_barrier(0);")
+    lines.append("  asm volatile(")
+    lines.append('      "s_getpc_b64 s[56:57]\\n\\t"')
+    lines.append(f'      "s_add_u32 s56, s56, {name}@rel32@lo+4\\n\\t"')
+    lines.append(f'      "s_addc_u32 s57, s57, {name}@rel32@hi+12\\n\\t"')
+    lines.append('      "s_swappc_b64 s[30:31], s[56:57]"')
+    lines.append(f"      : {ins_out}")
+    lines.append(f"      : {ins_in}")
+    lines.append(f"      : {', '.join(clob[:-1])});")
+    lines.append("  __builtin_amdgcn_sched_barrier(0);")
+    lines.append("  return r;")
+    lines.append("}")
+    return "\n".join(lines)
+
+
+def main():
+    out = ["// GENERATED by tools/gen_mont_asm.py -- do not edit.",
+           "// Hand-scheduled gfx950 Montgomery products (see the generator for the algorithm and the schedule).",
+           "#pragma once",
+           "#if defined(__HIP_DEVICE_COMPILE__)",
+           "namespace sonic {",
+           cxx("sonic_mont_mul_fq", "Fp<FqParams>", 12, Q),
+           "",
+           cxx("sonic_mont_mul_fr", "Fp<FrParams>", 8, R),
+           "}  // namespace sonic",
+           "#endif", ""]
+    open("sonic_amd/csrc/mont_asm.hpp", "w").write("\n".join(out))
+    for name, N, p in (("fq", 12, Q), ("fr", 8, R)):
+        body, nv = function_text(name, N, p)
+        print(name, "instructions:", len(body), "nops:", sum(1 for l in body if l.startswith("s_nop")), "vgprs:", nv)
+
+
+if __name__ == "__main__":
+    main()

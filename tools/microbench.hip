@@ -77,6 +77,37 @@ __global__ void k_mkpts(G1Affine* pts) {
   pts[t] = g1_to_affine(a);
 }
 
+// asm product vs the C++ loop on the device, bit for bit
+template <class F>
+__global__ void k_check_mul(const F* in, int n, int* bad) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  F a = in[t], b = in[(t * 7 + 3) % n];
+  F x = fp_mul(a, b), y = fp_mul_generic(a, b);
+  if (x != y) atomicAdd(bad, 1);
+  F x2 = fp_mul(a, a), y2 = fp_mul_generic(a, a);
+  if (x2 != y2) atomicAdd(bad, 1);
+}
+template <class F> int check_mul(const char* name) {
+  const int n = 1 << 16;
+  F* h = (F*)malloc(sizeof(F) * n);
+  F pm = F::modulus();
+  uint64_t st = 0x9e3779b97f4a7c15ull;
+  for (int i = 0; i < n; i++) {
+    for (int k = 0; k < F::N; k++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; h[i].l[k] = (uint32_t)(st >> 11); }
+    h[i].l[F::N - 1] &= (F::N == 12 ? 0x0fffffffu : 0x3fffffffu);     // < p
+    if (i < 8) { for (int k = 0; k < F::N; k++) h[i].l[k] = (i & 1) ? pm.l[k] : 0; if (i & 1) h[i].l[0] -= (i >> 1) + 1; else h[i].l[0] = i >> 1; }
+    if (i >= 8 && i < 16) for (int k = 0; k < F::N; k++) h[i].l[k] = (k == F::N - 1) ? (pm.l[k] - 1) : 0xffffffffu;
+  }
+  F* d; int* bad; int hb = 0;
+  hipMalloc(&d, sizeof(F) * n); hipMalloc(&bad, 4); hipMemcpy(d, h, sizeof(F) * n, hipMemcpyHostToDevice); hipMemset(bad, 0, 4);
+  hipLaunchKernelGGL(k_check_mul<F>, n / 256, 256, 0, 0, (const F*)d, n, bad);
+  hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
+  printf("asm fp_mul<%s> vs C++ loop on %d pairs: %s (%d mismatches)\n", name, 2 * n, hb ? "FAIL" : "ok", hb);
+  free(h); hipFree(d); hipFree(bad);
+  return hb;
+}
+
 template <class F> float time_ms(F f, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -88,18 +119,19 @@ int main() {
   int dev = 0; CK(hipSetDevice(dev));
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, dev));
   printf("device: %s CUs=%d clock=%d kHz\n", pr.name, pr.multiProcessorCount, pr.clockRate);
+  if (check_mul<Fq>("Fq") | check_mul<Fr>("Fr")) return 2;
   const int blocks = pr.multiProcessorCount * 8, threads = 256;
   void* buf; CK(hipMalloc(&buf, (size_t)blocks * threads * sizeof(G1XYZZ)));
   G1Affine* pts; CK(hipMalloc(&pts, 4096 * sizeof(G1Affine)));
   hipLaunchKernelGGL(k_mkpts, 16, 256, 0, 0, pts); CK(hipDeviceSynchronize());
   const double lanes = (double)blocks * threads;
-  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_mad, blocks, threads, 0, 0, (uint64_t*)buf, 12345u, 67891u, it); }, 5);
+  { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_mad, blocks, threads, 0, 0, (uint64_t*)buf, 12345u, 67891u, it); }, 10);
     printf("v_mad_u64_u32: %.3f ms -> %.3e mad/s  (%.2f lane-ops/clk/CU at 2.4GHz)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
-  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_mul32, blocks, threads, 0, 0, (uint32_t*)buf, 12345u, 67891u, it); }, 5);
+  { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_mul32, blocks, threads, 0, 0, (uint32_t*)buf, 12345u, 67891u, it); }, 10);
     printf("mul_lo+add:    %.3f ms -> %.3e op/s  (%.2f lane-ops/clk/CU)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
-  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_fma64, blocks, threads, 0, 0, (double*)buf, 1.0000001, 0.5, it); }, 5);
+  { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_fma64, blocks, threads, 0, 0, (double*)buf, 1.0000001, 0.5, it); }, 10);
     printf("v_fma_f64:     %.3f ms -> %.3e fma/s (%.2f lane-ops/clk/CU)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
-  { int it = 4096; float ms = time_ms([&] { hipLaunchKernelGGL(k_add32, blocks, threads, 0, 0, (uint32_t*)buf, 12345u, it); }, 5);
+  { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_add32, blocks, threads, 0, 0, (uint32_t*)buf, 12345u, it); }, 10);
     printf("add+xor+shift: %.3f ms -> %.3e triple/s (%.2f lane-triples/clk/CU)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
   { int it = 256; float ms = time_ms([&] { hipLaunchKernelGGL(k_fqmul, blocks, threads, 0, 0, (Fq*)buf, it); }, 3);
     printf("fq_mul:        %.3f ms -> %.3e mul/s\n", ms, lanes * it * 2 / (ms * 1e-3)); }
