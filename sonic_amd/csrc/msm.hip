@@ -30,7 +30,7 @@ static int g_window_override = 0;
 int msm_window_override() { return g_window_override; }
 void msm_set_window_override(int c) { g_window_override = c; }
 
-static constexpr uint32_t HEAVY_SEG = 4096;   // entries per heavy work item
+static constexpr uint32_t HEAVY_SEG = 16384;  // entries per heavy work item (256 threads x 64)
 static constexpr int HEAVY_GRID = 1024;
 
 struct HeavyMeta { uint32_t n_items, n_heavy; };
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, l
                                                     uint32_t* __restrict__ count, uint32_t* __restrict__ digits,
                                                     uint32_t* __restrict__ rank) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Fr s = sc[i];
+  const bool live = i < n;
+  Fr s = live ? sc[i] : Fr::zero();
   if (mont) s = fp_from_mont(s);
   const bool neg = fr_gt_half(s);
   if (neg) s = fp_neg(s);            // r - s, still standard form
@@ -107,12 +107,32 @@ __global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, l
     uint32_t sign = neg ? 1u : 0u;
     if (d > half) { d = (1u << c) - d; carry = 1; sign ^= 1u; } else carry = 0;
     uint32_t out = 0, rk = 0;
-    if (d) {
-      rk = atomicAdd(&count[(size_t)w * NB + d - 1], 1u);
-      out = d | (sign << 31);
+    // Histogram + rank.  Runs of equal scalars are the norm in this protocol (s(X,y) carries n copies of
+    // one coefficient when a weight row is all ones), and they would serialise 2^18 atomics on one
+    // address: lanes that share the first active lane's key are counted with ONE atomic per wave.
+    const uint32_t key = d ? (uint32_t)w * NB + d - 1 : 0xffffffffu;
+    const unsigned long long act = __ballot(d != 0);
+    if (act) {
+      const int first_lane = __ffsll((long long)act) - 1;
+      const uint32_t k0 = __shfl(key, first_lane);
+      const bool same = d && key == k0;
+      const unsigned long long m = __ballot(same);
+      const int lane = threadIdx.x & 63;
+      if (__popcll(m) >= 4) {
+        uint32_t base = 0;
+        if (lane == first_lane) base = atomicAdd(&count[k0], (uint32_t)__popcll(m));
+        base = __shfl(base, first_lane);
+        if (same) rk = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        else if (d) rk = atomicAdd(&count[key], 1u);
+      } else if (d) {
+        rk = atomicAdd(&count[key], 1u);
+      }
     }
-    digits[(size_t)w * n + i] = out;
-    rank[(size_t)w * n + i] = rk;
+    if (d) out = d | (sign << 31);
+    if (live) {
+      digits[(size_t)w * n + i] = out;
+      rank[(size_t)w * n + i] = rk;
+    }
   }
 }
 
@@ -232,14 +252,23 @@ __global__ __launch_bounds__(256) void k_heavy_accum(const G1Affine* __restrict_
   }
 }
 
+// one 64-lane workgroup per heavy bucket: lanes stride over the bucket's partials, LDS tree
 __global__ __launch_bounds__(64) void k_heavy_finish(const HeavyMeta* hm, const HeavyRec* hrecs, const G1XYZZ* __restrict__ partial,
                                                      G1XYZZ* __restrict__ buckets) {
+  __shared__ G1XYZZ sh[64];
   const uint32_t n_heavy = hm->n_heavy;
-  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heavy; h += gridDim.x * blockDim.x) {
-    HeavyRec r = hrecs[h];
+  for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+    const HeavyRec r = hrecs[h];
     G1XYZZ acc = G1XYZZ::inf();
-    for (uint32_t k = 0; k < r.nseg; k++) acc = g1_add(acc, partial[r.base + k]);
-    buckets[r.bucket] = acc;
+    for (uint32_t k = threadIdx.x; k < r.nseg; k += 64) acc = g1_add(acc, partial[r.base + k]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 32; s >= 1; s >>= 1) {
+      if ((int)threadIdx.x < s && (uint32_t)(threadIdx.x + s) < r.nseg) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) buckets[r.bucket] = sh[0];
+    __syncthreads();
   }
 }
 
@@ -330,7 +359,7 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
          ws.heavy_items.as<HeavyItem>());
   LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
          (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
-  LAUNCH(k_heavy_finish, 64, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
+  LAUNCH(k_heavy_finish, 256, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), ws.buckets.as<G1XYZZ>());
   LAUNCH(k_bucket_segments, ceil_div((long)pl.W * pl.nseg, 64), 64, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), pl.W,
          pl.NB, pl.K, pl.nseg, ws.segres.as<G1XYZZ>());
