@@ -68,6 +68,8 @@ void MsmWorkspace::reserve(long n, const MsmPlan& pl) {
   buckets.ensure(M * sizeof(G1XYZZ));
   segres.ensure((size_t)pl.W * pl.nseg * sizeof(G1XYZZ));
   scan_tmp.ensure((M / 2048 + 2) * 4);
+  order.ensure((M + 1) * 4);
+  size_hist.ensure((256 * (M / 2048 + 1) + 1) * 4 * 2);
   size_t max_heavy = NW / pl.heavy_threshold + 1;
   size_t max_items = NW / HEAVY_SEG + max_heavy + 1;
   heavy_meta.ensure(sizeof(HeavyMeta) + max_heavy * sizeof(HeavyRec));
@@ -200,6 +202,35 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, size_t m
   for (int k = 0; k < 8; k++) { if (base + k < m) out[base + k] = ex; ex += v[k]; }
 }
 
+// ---- bucket order: largest buckets first -----------------------------------------------------
+// One thread walks one bucket, so a wave runs as long as its largest bucket.  Bucket sizes are
+// Poisson around N / 2^(c-1) (and 4x that in the top window): in index order a wave idles ~30 % of its
+// lanes.  A counting sort of the buckets by size (256 classes) puts equal-length walks in the same wave.
+__device__ __forceinline__ uint32_t size_class(uint32_t sz) { return 255u - (sz < 255u ? sz : 255u); }
+__global__ __launch_bounds__(256) void k_border_hist(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t nblk, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * 2048;
+  for (int k = 0; k < 8; k++) {
+    uint32_t b = base + k * 256 + threadIdx.x;
+    if (b < nbuckets) atomicAdd(&h[size_class(off[b + 1] - off[b])], 1u);
+  }
+  __syncthreads();
+  hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_border_scatter(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t nblk,
+                                                        const uint32_t* __restrict__ hist_scanned, uint32_t* __restrict__ order) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = hist_scanned[threadIdx.x * nblk + blockIdx.x];
+  __syncthreads();
+  const uint32_t base = blockIdx.x * 2048;
+  for (int k = 0; k < 8; k++) {
+    uint32_t b = base + k * 256 + threadIdx.x;
+    if (b < nbuckets) order[atomicAdd(&h[size_class(off[b + 1] - off[b])], 1u)] = b;
+  }
+}
+
 // ---- bucket accumulation ---------------------------------------------------------------------
 __device__ __forceinline__ G1Affine load_point_signed(const G1Affine* __restrict__ pts, uint32_t e) {
   G1Affine p = pts[e & 0x7fffffffu];
@@ -207,12 +238,14 @@ __device__ __forceinline__ G1Affine load_point_signed(const G1Affine* __restrict
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_bucket_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
-                                                      const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t heavy_t,
+__global__ __launch_bounds__(256, 2) void k_bucket_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
+                                                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
+                                                      uint32_t nbuckets, uint32_t heavy_t,
                                                       G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs,
                                                       HeavyItem* items) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbuckets) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  const uint32_t b = order[t];
   const uint32_t beg = off[b], end = off[b + 1];
   const uint32_t cnt = end - beg;
   if (cnt > heavy_t) {
@@ -223,12 +256,27 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const G1Affine* __restrict
     for (uint32_t k = 0; k < ns; k++) items[base + k] = HeavyItem{b, k};
     return;
   }
+  // Two-deep software pipeline: the index of entry e+2 and the point of entry e+1 are in flight while
+  // entry e is added (the gather is a dependent load pair, ~2 us of HBM latency per entry otherwise;
+  // only two waves per SIMD fit, so the hardware cannot hide it by itself).
   G1XYZZ acc = G1XYZZ::inf();
-  for (uint32_t e = beg; e < end; e++) acc = g1_add_mixed(acc, load_point_signed(pts, entries[e]));
+  if (cnt) {
+    const uint32_t last = end - 1;
+    uint32_t e_cur = entries[beg];
+    uint32_t e_nxt = entries[beg + 1 <= last ? beg + 1 : last];
+    G1Affine p_cur = pts[e_cur & 0x7fffffffu];
+    for (uint32_t e = beg; e < end; e++) {
+      const uint32_t e_nn = entries[e + 2 <= last ? e + 2 : last];
+      const G1Affine p_nxt = pts[e_nxt & 0x7fffffffu];
+      if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
+      acc = g1_add_mixed(acc, p_cur);
+      p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
+    }
+  }
   buckets[b] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_heavy_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(256, 2) void k_heavy_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                      const uint32_t* __restrict__ off, const HeavyMeta* hm,
                                                      const HeavyItem* items, G1XYZZ* __restrict__ partial) {
   __shared__ G1XYZZ sh[256];
@@ -240,7 +288,20 @@ __global__ __launch_bounds__(256) void k_heavy_accum(const G1Affine* __restrict_
     const uint32_t bend = off[item.bucket + 1];
     if (end > bend) end = bend;
     G1XYZZ acc = G1XYZZ::inf();
-    for (uint32_t e = beg + threadIdx.x; e < end; e += 256) acc = g1_add_mixed(acc, load_point_signed(pts, entries[e]));
+    if (beg + threadIdx.x < end) {
+      const uint32_t last = beg + threadIdx.x + ((end - 1 - beg - threadIdx.x) / 256) * 256;   // this lane's last entry
+      uint32_t e = beg + threadIdx.x;
+      uint32_t e_cur = entries[e];
+      uint32_t e_nxt = entries[e + 256 <= last ? e + 256 : last];
+      G1Affine p_cur = pts[e_cur & 0x7fffffffu];
+      for (; e < end; e += 256) {
+        const uint32_t e_nn = entries[e + 512 <= last ? e + 512 : last];
+        const G1Affine p_nxt = pts[e_nxt & 0x7fffffffu];
+        if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
+        acc = g1_add_mixed(acc, p_cur);
+        p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
+      }
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
@@ -253,7 +314,7 @@ __global__ __launch_bounds__(256) void k_heavy_accum(const G1Affine* __restrict_
 }
 
 // one 64-lane workgroup per heavy bucket: lanes stride over the bucket's partials, LDS tree
-__global__ __launch_bounds__(64) void k_heavy_finish(const HeavyMeta* hm, const HeavyRec* hrecs, const G1XYZZ* __restrict__ partial,
+__global__ __launch_bounds__(64, 2) void k_heavy_finish(const HeavyMeta* hm, const HeavyRec* hrecs, const G1XYZZ* __restrict__ partial,
                                                      G1XYZZ* __restrict__ buckets) {
   __shared__ G1XYZZ sh[64];
   const uint32_t n_heavy = hm->n_heavy;
@@ -273,7 +334,7 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const HeavyMeta* hm, const 
 }
 
 // ---- bucket reduction: sum_b (b+1) * B_b per window -----------------------------------------
-__global__ __launch_bounds__(64) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg,
+__global__ __launch_bounds__(64, 2) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg,
                                                         G1XYZZ* __restrict__ segres) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * nseg) return;
@@ -289,7 +350,7 @@ __global__ __launch_bounds__(64) void k_bucket_segments(const G1XYZZ* __restrict
   segres[t] = tot;
 }
 
-__global__ __launch_bounds__(256) void k_window_sum(const G1XYZZ* __restrict__ segres, int W, int c, int nseg, MsmSlot* slot) {
+__global__ __launch_bounds__(256, 2) void k_window_sum(const G1XYZZ* __restrict__ segres, int W, int c, int nseg, MsmSlot* slot) {
   __shared__ G1XYZZ sh[256];
   const int w = blockIdx.x;
   G1XYZZ acc = G1XYZZ::inf();
@@ -354,8 +415,20 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
     LAUNCH(k_msm_scatter, ceil_div(n, 256), 256, 0, st, n, pl.W, pl.NB, (const uint32_t*)ws.digits.as<uint32_t>(),
            (const uint32_t*)ws.rank.as<uint32_t>(), (const uint32_t*)off, ws.entries.as<uint32_t>());
   }
+  {
+    const uint32_t nblk = (uint32_t)ceil_div((long)M, 2048);
+    uint32_t* hist = ws.size_hist.as<uint32_t>();
+    uint32_t* hist_sc = hist + (256 * nblk + 1);
+    const size_t hn = (size_t)256 * nblk;
+    const int ht = ceil_div((long)hn + 1, 2048);
+    LAUNCH(k_border_hist, nblk, 256, 0, st, (const uint32_t*)off, (uint32_t)M, nblk, hist);
+    LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
+    LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, tiles + ht);
+    LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hist_sc);
+    LAUNCH(k_border_scatter, nblk, 256, 0, st, (const uint32_t*)off, (uint32_t)M, nblk, (const uint32_t*)hist_sc, ws.order.as<uint32_t>());
+  }
   LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(),
-         (const uint32_t*)off, (uint32_t)M, pl.heavy_threshold, ws.buckets.as<G1XYZZ>(), hm, hrecs,
+         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), (uint32_t)M, pl.heavy_threshold, ws.buckets.as<G1XYZZ>(), hm, hrecs,
          ws.heavy_items.as<HeavyItem>());
   LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
          (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());

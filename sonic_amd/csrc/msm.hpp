@@ -24,7 +24,7 @@ struct MsmSlot {
 };
 
 struct MsmWorkspace {
-  DevBuf count, off, digits, rank, entries, buckets, segres, scan_tmp, heavy_meta, heavy_items, heavy_partial;
+  DevBuf count, off, digits, rank, entries, buckets, segres, scan_tmp, order, size_hist, heavy_meta, heavy_items, heavy_partial;
   void reserve(long n, const MsmPlan& pl);
 };
 
