@@ -88,19 +88,45 @@ static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < 
 
 using namespace sonic;
 
+// One MSM "lane": its own stream, bucket workspace and opening scratch.  The 7+4Q MSMs of a proof are
+// independent once their input polynomial exists, and every MSM has latency-bound phases (bucket
+// running sums, window trees, histogram atomics) that leave most of the chip idle: three lanes let one
+// MSM's reduction overlap another's accumulation.
+struct Lane {
+  hipStream_t st = nullptr;
+  hipEvent_t done = nullptr;
+  MsmWorkspace ws;
+  Scratch sc;
+};
+constexpr int N_LANES = 3;
+
 struct sonic_prover {
   const sonic_srs* srs = nullptr;
   long n = 0, Q = 0;
   hipStream_t st = nullptr;
   bool have_assignment = false;
   DevBuf wL, wR, wO, cs, aL, aR, aO;        // Montgomery, resident across proofs
-  MsmWorkspace ws;
+  Lane lanes[N_LANES];
+  int next_lane = 0;
   NttTables ntt;
-  Scratch sc;
-  DevBuf S, IN, PAIRS, r1, sy, su, pw, fa, fb, slots, frout, flags, tmp;
+  DevBuf S, IN, PAIRS, r1, sy0, su, pw, fa, fb, slots, frout, flags, tmp;
+  std::vector<DevBuf> syj;
+  hipEvent_t ev_r1 = nullptr, ev_sy0 = nullptr, ev_t = nullptr, ev_su = nullptr;
+  std::vector<hipEvent_t> ev_syj;
   int log2m = 0;
   std::mutex mu;
-  ~sonic_prover() { if (st) (void)hipStreamDestroy(st); }
+  Lane& pick(hipEvent_t ready) {
+    Lane& l = lanes[next_lane];
+    next_lane = (next_lane + 1) % N_LANES;
+    (void)hipStreamWaitEvent(l.st, ready, 0);
+    return l;
+  }
+  ~sonic_prover() {
+    for (auto& l : lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); }
+    for (hipEvent_t e : {ev_r1, ev_sy0, ev_t, ev_su}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_syj) if (e) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+  }
 };
 
 #define API_BEGIN try { require_device();
@@ -178,14 +204,25 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   const long M = 1L << lg;
   p->fa.alloc(sizeof(Fr) * M); p->fb.alloc(sizeof(Fr) * M);
   p->r1.alloc(sizeof(Fr) * (3 * n + 5));
-  p->sy.alloc(sizeof(Fr) * (3 * n + 1));
+  p->sy0.alloc(sizeof(Fr) * (3 * n + 1));
+  p->syj.resize(Q);
+  for (auto& b : p->syj) b.alloc(sizeof(Fr) * (3 * n + 1));
   p->su.alloc(sizeof(Fr) * (2 * n + Q + 1));
   p->pw.alloc(sizeof(Fr) * (3 * n + Q + 2));
   p->S.alloc(sizeof(Fr) * (8 + 2 * Q)); p->IN.alloc(sizeof(Fr) * (5 + 2 * Q)); p->PAIRS.alloc(sizeof(Fr) * 2 * (5 + 2 * Q));
   p->slots.alloc(sizeof(MsmSlot) * (7 + 4 * Q));
   p->frout.alloc(sizeof(Fr) * (3 + 2 * Q));
-  p->sc.reserve(tlen);
-  p->ws.reserve(tlen, msm_plan(tlen));
+  auto mkev = [](hipEvent_t* e) { HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming)); };
+  mkev(&p->ev_r1); mkev(&p->ev_sy0); mkev(&p->ev_t); mkev(&p->ev_su);
+  p->ev_syj.resize(Q, nullptr);
+  for (auto& e : p->ev_syj) mkev(&e);
+  for (auto& l : p->lanes) {
+    HIP_OK(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+    mkev(&l.done);
+    l.sc.reserve(tlen);
+    l.sc.scan.ensure(sizeof(Fr) * (tlen / 1024 + 2));
+    l.ws.reserve(tlen, msm_plan(tlen));
+  }
   HIP_OK(hipStreamSynchronize(st));
   *out = p.release();
   API_END
@@ -231,51 +268,69 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   auto pZj = [&](long j) { return PR + 2 * (5 + Q + j); };
   MsmSlot* slots = p->slots.as<MsmSlot>();
   Fr* frout = p->frout.as<Fr>();
-  Fr *r1 = p->r1.as<Fr>(), *sy = p->sy.as<Fr>(), *su = p->su.as<Fr>(), *pw = p->pw.as<Fr>(), *fa = p->fa.as<Fr>(), *fb = p->fb.as<Fr>();
+  Fr *r1 = p->r1.as<Fr>(), *su = p->su.as<Fr>(), *pw = p->pw.as<Fr>(), *fa = p->fa.as<Fr>(), *fb = p->fb.as<Fr>();
   const Fr *wL = p->wL.as<Fr>(), *wR = p->wR.as<Fr>(), *wO = p->wO.as<Fr>(), *cs = p->cs.as<Fr>();
   const long d = srs_d(srs);
   const long r_lo = -2 * n - 4, r_len = 3 * n + 5, s_lo = -n, s_len = 3 * n + 1, t_lo = -4 * n - 8, t_len = 7 * n + 9;
   const long M = 1L << p->log2m;
 
+  // The main stream builds the polynomials; each commitment / opening runs on the next MSM lane as
+  // soon as its input exists (event).  Results land in disjoint slots / frout entries.
+  hipStream_t ms = st;
+  auto ready = [&](hipEvent_t e) { HIP_OK(hipEventRecord(e, ms)); };
+  auto commit = [&](hipEvent_t e, const Fr* poly, long lo, long len, long maxm, long slot) {
+    Lane& l = p->pick(e);
+    commit_enqueue(l.st, srs, l.ws, poly, lo, len, maxm, &slots[slot], flags);
+  };
+  auto open = [&](hipEvent_t e, const Fr* poly, long lo, long len, const Fr* zp, Fr* fz, long slot) {
+    Lane& l = p->pick(e);
+    open_enqueue(l.st, srs, l.ws, l.sc, poly, lo, len, zp, fz, &slots[slot], flags);
+  };
+  Fr* sy = p->sy0.as<Fr>();
   // zkP_1: r'(X,1), R = Commit(n, r(X,1))                                          Protocol.hs:58-63
-  build_r1_enqueue(st, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
-  commit_enqueue(st, srs, p->ws, r1, r_lo, r_len, n, &slots[0], flags);
+  build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
+  ready(p->ev_r1);
+  commit(p->ev_r1, r1, r_lo, r_len, n, 0);
+  open(p->ev_r1, r1, r_lo, r_len, pZ, &frout[0], 2);                                 // (a, W_a)     :79
+  open(p->ev_r1, r1, r_lo, r_len, pYZ, &frout[1], 3);                                // (b, W_b)     :80
   // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y)                               Protocol.hs:69-73, Constraints.hs:56-68
-  poly_scale_powers_enqueue(st, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
-  s_of_y_enqueue(st, wL, wR, wO, pw, n, Q, sy);
-  HIP_OK(hipMemsetAsync(fa, 0, sizeof(Fr) * M, st));
-  HIP_OK(hipMemsetAsync(fb, 0, sizeof(Fr) * M, st));
-  HIP_OK(hipMemcpyAsync(fa, r1, sizeof(Fr) * r_len, hipMemcpyDeviceToDevice, st));
-  poly_scale_powers_enqueue(st, r1, fb, r_len, r_lo, pY, pY + 1);                    // r(X,y): c_e y^e (diagonal)
-  add_into_enqueue(st, fb + (s_lo - r_lo), sy, s_len);
-  ntt_forward_enqueue(st, p->ntt, fa, p->log2m);
-  ntt_forward_enqueue(st, p->ntt, fb, p->log2m);
-  fr_pointwise_mul_enqueue(st, fa, fb, M);
-  ntt_inverse_enqueue(st, p->ntt, fa, p->log2m);
+  poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
+  s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
+  ready(p->ev_sy0);
+  { Lane& l = p->pick(p->ev_sy0); eval_prefix_enqueue(l.st, l.sc, sy, s_lo, s_len, pZ, &frout[2]); }   // s(z,y)  :83
+  HIP_OK(hipMemsetAsync(fa, 0, sizeof(Fr) * M, ms));
+  HIP_OK(hipMemsetAsync(fb, 0, sizeof(Fr) * M, ms));
+  HIP_OK(hipMemcpyAsync(fa, r1, sizeof(Fr) * r_len, hipMemcpyDeviceToDevice, ms));
+  poly_scale_powers_enqueue(ms, r1, fb, r_len, r_lo, pY, pY + 1);                    // r(X,y): c_e y^e (diagonal)
+  add_into_enqueue(ms, fb + (s_lo - r_lo), sy, s_len);
+  ntt_forward_enqueue(ms, p->ntt, fa, p->log2m);
+  ntt_forward_enqueue(ms, p->ntt, fb, p->log2m);
+  fr_pointwise_mul_enqueue(ms, fa, fb, M);
+  ntt_inverse_enqueue(ms, p->ntt, fa, p->log2m);
   Fr* t = fa;                                                                         // exponents [t_lo, t_lo + t_len)
-  sub_k_of_y_enqueue(st, t + (0 - t_lo), cs, pw + (2 * n + 1), Q, flags, 0);
-  commit_enqueue(st, srs, p->ws, t, t_lo, t_len, d, &slots[1], flags);
-  // zkP_3: openings                                                                 Protocol.hs:79-83
-  open_enqueue(st, srs, p->ws, p->sc, r1, r_lo, r_len, pZ, &frout[0], &slots[2], flags);
-  open_enqueue(st, srs, p->ws, p->sc, r1, r_lo, r_len, pYZ, &frout[1], &slots[3], flags);
-  open_enqueue(st, srs, p->ws, p->sc, t, t_lo, t_len, pZ, nullptr, &slots[4], flags);
-  eval_prefix_enqueue(st, p->sc, sy, s_lo, s_len, pZ, &frout[2]);
+  sub_k_of_y_enqueue(ms, t + (0 - t_lo), cs, pw + (2 * n + 1), Q, flags, 0);
+  ready(p->ev_t);
+  commit(p->ev_t, t, t_lo, t_len, d, 1);                                              // T            :73
+  open(p->ev_t, t, t_lo, t_len, pZ, nullptr, 4);                                      // W_t          :81
   // hscProve                                                                        Signature.hs:38-72
   for (long j = 0; j < Q; j++) {
-    poly_scale_powers_enqueue(st, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
-    s_of_y_enqueue(st, wL, wR, wO, pw, n, Q, sy);                                    // s(X, y_j)
-    commit_enqueue(st, srs, p->ws, sy, s_lo, s_len, d, &slots[5 + 2 * j], flags);    // S_j           :42
-    open_enqueue(st, srs, p->ws, p->sc, sy, s_lo, s_len, pZj(j), &frout[3 + j], &slots[6 + 2 * j], flags);      // (s_j, W_j)  :43
-    open_enqueue(st, srs, p->ws, p->sc, sy, s_lo, s_len, pU, nullptr, &slots[5 + 2 * Q + 2 * j], flags);        // W'_j        :54
+    Fr* syj = p->syj[j].as<Fr>();
+    poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
+    s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, syj);                                   // s(X, y_j)
+    ready(p->ev_syj[j]);
+    commit(p->ev_syj[j], syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j           :42
+    open(p->ev_syj[j], syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);          // (s_j, W_j)    :43
+    open(p->ev_syj[j], syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);            // W'_j          :54
   }
-  poly_scale_powers_enqueue(st, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);             // u^e, e in [-n, 2n]
+  poly_scale_powers_enqueue(ms, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);             // u^e, e in [-n, 2n]
   const long u_lo = -n, u_len = 2 * n + Q + 1;
-  s_of_u_enqueue(st, wL, wR, wO, pw, n, Q, su, p->tmp);                              // s(u, Y)       :51
-  commit_enqueue(st, srs, p->ws, su, u_lo, u_len, d, &slots[6 + 4 * Q], flags);      // C             :52
-  for (long j = 0; j < Q; j++)
-    open_enqueue(st, srs, p->ws, p->sc, su, u_lo, u_len, pYj(j), &frout[3 + Q + j], &slots[6 + 2 * Q + 2 * j], flags);  // (s'_j, Q_j) :55
-  open_enqueue(st, srs, p->ws, p->sc, su, u_lo, u_len, pV, nullptr, &slots[5 + 4 * Q], flags);                          // Q_v         :63
-  fr_from_mont_enqueue(st, frout, 3 + 2 * Q);
+  s_of_u_enqueue(ms, wL, wR, wO, pw, n, Q, su, p->tmp);                              // s(u, Y)       :51
+  ready(p->ev_su);
+  commit(p->ev_su, su, u_lo, u_len, d, 6 + 4 * Q);                                   // C             :52
+  for (long j = 0; j < Q; j++) open(p->ev_su, su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
+  open(p->ev_su, su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                           // Q_v           :63
+  for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
+  fr_from_mont_enqueue(ms, frout, 3 + 2 * Q);
 
   const int K = (int)(7 + 4 * Q);
   std::vector<MsmSlot> hs(K);
