@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=11, help="n of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel HIP-event totals to stderr")
+    ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,13 +103,18 @@ def main():
         log(f"setup: SRS.new(d=2^{args.log2n + 3}) {t_srs:.1f}s, circuit n=2^{args.log2n} Q={Q} resident")
 
     # ---------------- timed: K x prove() ----------------
-    for i in range(W):
+    if args.msm_only:
+        K_prove, W_prove = 0, 0
+    else:
+        K_prove, W_prove = K, W
+    proof = b""
+    for i in range(W_prove):
         prover.prove_bytes(transcripts[i])
     barrier()
     L.sonic_profile_reset()
     L.sonic_profile_enable(1 if args.kernel_table else 0)
     t0 = time.perf_counter()
-    for i in range(K):
+    for i in range(K_prove):
         proof = prover.prove_bytes(transcripts[W + i])
     barrier()
     dt = time.perf_counter() - t0
@@ -117,7 +123,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_prove = float(tmax.item())
-    proofs_per_s = world * K / dt_prove
+    proofs_per_s = world * K_prove / dt_prove
     if args.kernel_table and rank == 0:
         names = C.create_string_buffer(8192)
         L.sonic_profile_names(names, 8192)
@@ -136,22 +142,15 @@ def main():
     dsc = C.c_void_p()
     _lib.check(L.sonic_dev_alloc(32 * msm_n, C.byref(dsc)))
     _lib.check(L.sonic_dev_upload(dsc, sc.ctypes.data, 32 * msm_n))
-    slice_id = rank % max(1, (2 * d) // msm_n)
-    basis = (rank // max(1, (2 * d) // msm_n)) % 2
-    e0 = -d + slice_id * msm_n
-    part = np.zeros(192, np.uint8)
-    out = C.create_string_buffer(96)
+    from sonic_amd import distributed as sd
+    basis, e0 = sd.msm_shard(rank, world, d, msm_n)
+    part = np.zeros(sd.PARTIAL_BYTES, np.uint8)
+    msm_result = [b""]
 
     def msm_step():
         _lib.check(L.sonic_msm_g1_srs_partial_dev(srs._h, basis, e0, dsc, msm_n, part.ctypes.data))
-        if world > 1:
-            mine = torch.from_numpy(part).cuda()
-            allp = torch.empty(world * 192, dtype=torch.uint8, device="cuda")
-            dist.all_gather_into_tensor(allp, mine)
-            parts = allp.cpu().numpy()
-        else:
-            parts = part
-        _lib.check(L.sonic_g1_sum_partials(parts.ctypes.data, world, out))
+        parts = sd.allgather_partials(part, world, device=torch.device("cuda", local_rank))   # RCCL all-gather of 192 B
+        msm_result[0] = sd.sum_partials(parts, world)                                            # k-1 curve additions
 
     for _ in range(W):
         msm_step()

@@ -12,7 +12,9 @@
 // (Signature.hs:41,54).
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <memory>
+#include <thread>
 #include <numeric>
 #include <vector>
 #include "internal.hpp"
@@ -342,7 +344,17 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   HIP_OK(hipStreamSynchronize(st));
   if (hflags) return flags_to_status(hflags, "prove");
   std::vector<uint8_t> pts(96 * (size_t)K);
-  for (int i = 0; i < K; i++) g1_canonical_bytes_host(msm_finish_host(hs[i]), &pts[96 * (size_t)i]);
+  {
+    // host tails (Horner over <= 64 window sums + one inversion each), one task per MSM
+    const bool timing = getenv("SONIC_DEBUG_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    const int nt = K < 16 ? K : 16;
+    for (int w = 0; w < nt; w++)
+      th.emplace_back([&, w] { for (int i = w; i < K; i += nt) g1_canonical_bytes_host(msm_finish_host(hs[i]), &pts[96 * (size_t)i]); });
+    for (auto& x : th) x.join();
+    if (timing) fprintf(stderr, "[sonic] host tails of %d MSMs: %.3f ms\n", K, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
   auto G = [&](long i) { return &pts[96 * (size_t)i]; };
   auto F = [&](long i) { return &hfr[32 * (size_t)i]; };
   uint8_t* o = out_proof;

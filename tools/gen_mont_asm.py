@@ -221,6 +221,58 @@ def cxx(name: str, cls: str, N: int, p: int) -> str:
     return "\n".join(lines)
 
 
+def addsub_cxx(fname: str, cls: str, N: int, sub: bool) -> str:
+    """r = a -/+ b mod p as one asm block: two interleaved carry chains and a select.
+    sub:  d = a - b (borrow chain A), e = d + p (carry chain B, one link behind), r = borrow ? e : d
+    add:  d = a + b (carry chain A),  e = d - p (borrow chain B),                 r = borrow(e) ? d : e
+    Chain A carries in an SGPR pair, chain B in VCC; the v_mov that loads p_j is the filler that keeps two
+    instructions between a carry write and its read (gfx950 VALU-carry hazard)."""
+    opA0, opA = ("v_sub_co_u32_e64", "v_subb_co_u32_e64") if sub else ("v_add_co_u32_e64", "v_addc_co_u32_e64")
+    opB0, opB = ("v_add_co_u32_e32", "v_addc_co_u32_e32") if sub else ("v_sub_co_u32_e32", "v_subb_co_u32_e32")
+    # operand numbering: outputs r[0..N) = %0.., d[0..N) early-clobber temps, pv temps, cA (sgpr pair), then inputs a, b, p literals via "s"
+    R_ = lambda j: f"%{j}"
+    D_ = lambda j: f"%{N + j}"
+    P_ = lambda j: f"%{2 * N + j}"
+    CA = f"%{3 * N}"
+    A_ = lambda j: f"%{3 * N + 1 + j}"
+    B_ = lambda j: f"%{4 * N + 1 + j}"
+    K_ = lambda j: f"%{5 * N + 1 + j}"         # modulus limb constants ("s": SGPR holding the literal)
+    L = []
+    for j in range(N):
+        L.append(f"v_mov_b32_e32 {P_(j)}, {K_(j)}")
+        if j == 0:
+            L.append(f"{opA0} {D_(0)}, {CA}, {A_(0)}, {B_(0)}")
+        else:
+            L.append(f"{opA} {D_(j)}, {CA}, {A_(j)}, {B_(j)}, {CA}")
+        if j == 1:
+            L.append(f"{opB0} {R_(0)}, vcc, {D_(0)}, {P_(0)}")
+        elif j >= 2:
+            L.append(f"{opB} {R_(j - 1)}, vcc, {D_(j - 1)}, {P_(j - 1)}, vcc")
+        else:
+            L.append("s_nop 0")
+    # tail: last link of chain B, then selects
+    L.append("s_nop 1")
+    L.append(f"{opB} {R_(N - 1)}, vcc, {D_(N - 1)}, {P_(N - 1)}, vcc" if N > 1 else f"{opB0} {R_(0)}, vcc, {D_(0)}, {P_(0)}")
+    L.append("s_nop 1")
+    for j in range(N):
+        if sub:   # borrow of chain A set -> take e (already in r), else d
+            L.append(f"v_cndmask_b32_e64 {R_(j)}, {D_(j)}, {R_(j)}, {CA}")
+        else:     # add: carry-out of A cannot happen (a + b < 2^(32N)); borrow of chain B (vcc) set -> d < p -> take d
+            L.append(f"v_cndmask_b32_e32 {R_(j)}, {R_(j)}, {D_(j)}, vcc")
+    outs = [f'"=&v"(r.l[{j}])' for j in range(N)] + [f'"=&v"(d{j})' for j in range(N)] + [f'"=&v"(p{j})' for j in range(N)] + ['"=&s"(ca)']
+    ins = [f'"v"(a.l[{j}])' for j in range(N)] + [f'"v"(b.l[{j}])' for j in range(N)] + [f'"s"(P::p({j}))' for j in range(N)]
+    body = "\\n\\t".join(L)
+    decl = " ".join(f"uint32_t d{j}, p{j};" for j in range(N))
+    return f"""template <class P> __device__ __forceinline__ {cls} {fname}(const {cls}& a, const {cls}& b) {{
+  {cls} r; {decl} unsigned long long ca;
+  asm volatile("{body}"
+      : {', '.join(outs)}
+      : {', '.join(ins)}
+      : "vcc");
+  return r;
+}}"""
+
+
 def main():
     out = ["// GENERATED by tools/gen_mont_asm.py -- do not edit.",
            "// Hand-scheduled gfx950 Montgomery products (see the generator for the algorithm and the schedule).",
@@ -230,6 +282,9 @@ def main():
            cxx("sonic_mont_mul_fq", "Fp<FqParams>", 12, Q),
            "",
            cxx("sonic_mont_mul_fr", "Fp<FrParams>", 8, R),
+           "",
+           addsub_cxx("sonic_fq_sub_asm", "Fp<P>", 12, True),
+           addsub_cxx("sonic_fq_add_asm", "Fp<P>", 12, False),
            "}  // namespace sonic",
            "#endif", ""]
     open("sonic_amd/csrc/mont_asm.hpp", "w").write("\n".join(out))

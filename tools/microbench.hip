@@ -87,6 +87,11 @@ __global__ void k_check_mul(const F* in, int n, int* bad) {
   if (x != y) atomicAdd(bad, 1);
   F x2 = fp_mul(a, a), y2 = fp_mul_generic(a, a);
   if (x2 != y2) atomicAdd(bad, 1);
+  if (fp_add(a, b) != fp_add_generic(a, b)) atomicAdd(bad, 1);
+  if (fp_sub(a, b) != fp_sub_generic(a, b)) atomicAdd(bad, 1);
+  if (fp_sub(b, a) != fp_sub_generic(b, a)) atomicAdd(bad, 1);
+  if (fp_add(a, a) != fp_add_generic(a, a)) atomicAdd(bad, 1);
+  if (fp_sub(a, a) != fp_sub_generic(a, a)) atomicAdd(bad, 1);
 }
 template <class F> int check_mul(const char* name) {
   const int n = 1 << 16;
