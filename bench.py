@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAD_PEAK_PER_S = 2.61e13       # measured v_mad_u64_u32 issue rate, tools/microbench.hip (profiles/r01_microbench.txt)
+MAD_PEAK_PER_S = 2.79e13       # measured v_mad_u64_u32 issue rate, tools/microbench.hip (profiles/r01_microbench.txt)
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_msm.json")   # FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc)
 
 
 def log(*a):
@@ -191,8 +192,15 @@ def main():
     # scalar-mul (96 B affine point + 32 B scalar) x the terms one launch covers
     alg_bytes = 128.0 * msm_n
     achieved = alg_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    try:   # HBM bytes per launch from the separate PMC passes (same command with --msm-only), if taken for this size
+        pmc = json.load(open(PMC_FILE))
+        if pmc.get("msm_n") == msm_n:
+            traffic, traffic_src = pmc["k_bucket_accum"]["hbm_bytes_per_launch"], "profiles/r01_pmc_msm.json"
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "k_bucket_accum", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "modular-integer kernel: binding roof is v_mad_u64_u32 issue, see int_roofline"}
     # integer roof: W windows x N mixed additions x 10 Fq products x 288 MADs

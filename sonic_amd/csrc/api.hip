@@ -104,13 +104,12 @@ void fr_from_mont_enqueue(hipStream_t st, Fr* d, long n) { if (n > 0) LAUNCH(k_f
 void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err) { if (n > 0) LAUNCH(k_fr_check, ceil_div(n, 256), 256, 0, st, d, n, d_err); }
 
 // one MSM, finished and normalised, result on the host
-void msm_blocking(hipStream_t st, MsmWorkspace& ws, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
+void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
                   uint8_t* out96, uint8_t* out_partial192) {
-  MsmPlan pl = msm_plan(n > 0 ? n : 1);
   DevBuf slot(sizeof(MsmSlot));
   msm_enqueue(st, ws, pl, d_pts, d_sc, n, mont, slot.as<MsmSlot>());
   MsmSlot h;
-  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof(int) * 4 + sizeof(G1XYZZ) * pl.W, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof(int) * 4 + sizeof(G1XYZZ) * pl.Wb, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   G1XYZZ sum = msm_finish_host(h);
   if (out96) g1_canonical_bytes_host(sum, out96);
@@ -129,21 +128,50 @@ using namespace sonic;
 
 struct sonic_srs {
   int64_t d;
-  DevBuf g, ga;      // G1Affine[2d+1]: slot e + d holds the point for exponent e
+  // basis b, window table w, exponent e  ->  tab[b][w * (2d+1) + e + d] = 2^(tab_c w) * g^{(alpha^b) x^e}
+  // (w = 0 is the basis itself; tab_W = 1 when the window tables are switched off)
+  int tab_c = 0, tab_W = 1;
+  DevBuf g, ga;
   const G1Affine* basis(int b) const { return (b ? ga : g).as<G1Affine>(); }
 };
 
 namespace sonic {
 const G1Affine* srs_basis(const sonic_srs* s, int b) { return s->basis(b); }
 int64_t srs_d(const sonic_srs* s) { return s->d; }
+int srs_tab_c(const sonic_srs* s) { return s->tab_c; }
+int srs_tab_W(const sonic_srs* s) { return s->tab_W; }
+
+// Window tables trade HBM capacity (288 GB) for work: W x the SRS size buys one shared bucket set per MSM.
+// c grows with d (MSM sizes are a fraction of d); off with SONIC_MSM_TABLES=0 or when memory is short.
 sonic_srs* srs_alloc(int64_t d) {
   sonic_srs* s = new sonic_srs();
   s->d = d;
-  s->g.alloc(sizeof(G1Affine) * (2 * d + 1));
-  s->ga.alloc(sizeof(G1Affine) * (2 * d + 1));
+  const size_t n = (size_t)(2 * d + 1);
+  int lg = 0;
+  while ((2L << lg) <= d) lg++;                 // floor(log2 d)
+  int c = lg - 1;
+  if (c < 9) c = 9;
+  if (c > 20) c = 20;
+  int W = (255 + c - 1) / c;
+  const char* env = getenv("SONIC_MSM_TABLES");
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const size_t need = 2 * n * sizeof(G1Affine) * (size_t)W;
+  if ((env && atoi(env) == 0) || need > free_b / 2) { c = 0; W = 1; }
+  s->tab_c = c; s->tab_W = W;
+  s->g.alloc(sizeof(G1Affine) * n * W);
+  s->ga.alloc(sizeof(G1Affine) * n * W);
   return s;
 }
 G1Affine* srs_basis_mut(sonic_srs* s, int b) { return (b ? s->ga : s->g).as<G1Affine>(); }
+
+// plan for an MSM over n consecutive SRS points: shared-bucket plan over the window tables unless the MSM is
+// tiny compared with the bucket set, the tables are off, or a test forces a window size
+MsmPlan srs_msm_plan(const sonic_srs* s, long n) {
+  if (s->tab_W > 1 && msm_window_override() == 0 && n >= (1L << (s->tab_c - 1)) / 16)
+    return msm_plan_tables(n > 0 ? n : 1, s->tab_c, s->tab_W, 2 * s->d + 1);
+  return msm_plan(n > 0 ? n : 1);
+}
 }  // namespace sonic
 
 extern "C" {
@@ -193,6 +221,7 @@ int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) { delete s; set_error("sonic_srs_from_points: %s", (herr & 1) ? "non-canonical coordinate" : "point not on curve"); return SONIC_ERR_BAD_ENCODING; }
+  srs_build_tables(st, s);
   *out = s;
   API_END
 }
@@ -208,7 +237,10 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
   std::lock_guard<std::mutex> g(call_mutex());
   hipStream_t st = default_stream();
   DevBuf raw(96 * n);
-  LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs->basis(basis) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
+  // diagnostic: basis = b + 2 w reads window table w (2^(c w) multiples) of basis b
+  const int w = basis >> 1;
+  if (w >= srs->tab_W) { set_error("sonic_srs_get_points: no window table %d", w); return SONIC_ERR_INVALID_ARG; }
+  LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs->basis(basis & 1) + (size_t)w * (2 * srs->d + 1) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
   HIP_OK(hipMemcpyAsync(out, raw.p, 96 * n, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   API_END
@@ -234,7 +266,7 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) { set_error("sonic_msm_g1: non-canonical input or point not on curve"); return SONIC_ERR_BAD_ENCODING; }
-  msm_blocking(st, shared_msm_ws(), pts.as<G1Affine>(), sc.as<Fr>(), n, false, out_g1, nullptr);
+  msm_blocking(st, shared_msm_ws(), msm_plan(n > 0 ? n : 1), pts.as<G1Affine>(), sc.as<Fr>(), n, false, out_g1, nullptr);
   API_END
 }
 
@@ -258,7 +290,7 @@ static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const v
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) { set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
-  msm_blocking(st, shared_msm_ws(), srs->basis(basis) + (e0 + srs->d), dsc, n, false, out96, out192);
+  msm_blocking(st, shared_msm_ws(), srs_msm_plan(srs, n), srs->basis(basis) + (e0 + srs->d), dsc, n, false, out96, out192);
   API_END
 }
 

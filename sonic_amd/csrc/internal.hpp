@@ -22,8 +22,13 @@ sonic_srs* srs_alloc(int64_t d);
 void fr_to_mont_enqueue(hipStream_t st, Fr* d, long n, int* d_err);
 void fr_from_mont_enqueue(hipStream_t st, Fr* d, long n);
 void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err);
-void msm_blocking(hipStream_t st, MsmWorkspace& ws, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
+void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
                   uint8_t* out96, uint8_t* out_partial192);
+int srs_tab_c(const sonic_srs* s);
+int srs_tab_W(const sonic_srs* s);
+MsmPlan srs_msm_plan(const sonic_srs* s, long n);
+// fills window tables 1 .. W-1 of both bases from table 0 (srs.hip)
+void srs_build_tables(hipStream_t st, sonic_srs* s);
 
 // SRS generation (srs.hip): fills both bases of `s` from x, alpha (standard-form Fr on the host)
 void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha_std);

@@ -37,6 +37,16 @@ struct HeavyMeta { uint32_t n_items, n_heavy; };
 struct HeavyRec { uint32_t bucket, base, nseg; };
 struct HeavyItem { uint32_t bucket, seg; };
 
+static void plan_finish(MsmPlan& p, long n) {
+  p.NB = 1 << (p.c - 1);
+  p.K = p.NB < 16 ? p.NB : 16;
+  p.nseg = p.NB / p.K;
+  long mean = n * (long)(p.W / p.Wb) / p.NB;
+  long t = 8 * mean;
+  if (t < 256) t = 256;
+  p.heavy_threshold = (uint32_t)t;
+}
+
 MsmPlan msm_plan(long n) {
   MsmPlan p;
   int lg = 0;
@@ -47,18 +57,27 @@ MsmPlan msm_plan(long n) {
   if (g_window_override >= 4 && g_window_override <= 16) c = g_window_override;
   p.c = c;
   p.W = (255 + c - 1) / c;
-  p.NB = 1 << (c - 1);
-  p.K = p.NB < 16 ? p.NB : 16;
-  p.nseg = p.NB / p.K;
-  long mean = n / p.NB;
-  long t = 8 * mean;
-  if (t < 256) t = 256;
-  p.heavy_threshold = (uint32_t)t;
+  p.Wb = p.W;
+  p.table_stride = 0;
+  plan_finish(p, n);
+  return p;
+}
+
+// Fixed-base plan over precomputed window tables (tab[w][i] = 2^(c w) P_i): every window feeds ONE shared
+// set of 2^(c-1) buckets, so there is one running-sum reduction instead of W and no Horner tail, and c can
+// grow (fewer windows => fewer point additions) without multiplying the bucket count by W.
+MsmPlan msm_plan_tables(long n, int c, int W, long table_stride) {
+  MsmPlan p;
+  p.c = c;
+  p.W = W;
+  p.Wb = 1;
+  p.table_stride = table_stride;
+  plan_finish(p, n);
   return p;
 }
 
 void MsmWorkspace::reserve(long n, const MsmPlan& pl) {
-  size_t M = (size_t)pl.W * pl.NB;
+  size_t M = (size_t)pl.Wb * pl.NB;
   size_t NW = (size_t)n * pl.W;
   count.ensure((M + 1) * 4);
   off.ensure((M + 1) * 4);
@@ -66,7 +85,7 @@ void MsmWorkspace::reserve(long n, const MsmPlan& pl) {
   rank.ensure(NW * 4);
   entries.ensure(NW * 4);
   buckets.ensure(M * sizeof(G1XYZZ));
-  segres.ensure((size_t)pl.W * pl.nseg * sizeof(G1XYZZ));
+  segres.ensure(((size_t)pl.Wb * pl.nseg + pl.nseg / 256 + 2) * sizeof(G1XYZZ));
   scan_tmp.ensure((M / 2048 + 2) * 4);
   order.ensure((M + 1) * 4);
   size_hist.ensure((256 * (M / 2048 + 1) + 1) * 4 * 2);
@@ -88,7 +107,7 @@ __device__ __forceinline__ bool fr_gt_half(const Fr& s) {
   return false;
 }
 
-__global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, long n, int c, int W, int NB, int mont,
+__global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, long n, int c, int W, int keystride, int mont,
                                                     uint32_t* __restrict__ count, uint32_t* __restrict__ digits,
                                                     uint32_t* __restrict__ rank) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, l
     // Histogram + rank.  Runs of equal scalars are the norm in this protocol (s(X,y) carries n copies of
     // one coefficient when a weight row is all ones), and they would serialise 2^18 atomics on one
     // address: lanes that share the first active lane's key are counted with ONE atomic per wave.
-    const uint32_t key = d ? (uint32_t)w * NB + d - 1 : 0xffffffffu;
+    const uint32_t key = d ? (uint32_t)w * keystride + d - 1 : 0xffffffffu;
     const unsigned long long act = __ballot(d != 0);
     if (act) {
       const int first_lane = __ffsll((long long)act) - 1;
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, l
   }
 }
 
-__global__ __launch_bounds__(256) void k_msm_scatter(long n, int W, int NB, const uint32_t* __restrict__ digits,
+__global__ __launch_bounds__(256) void k_msm_scatter(long n, int W, int keystride, const uint32_t* __restrict__ digits,
                                                      const uint32_t* __restrict__ rank, const uint32_t* __restrict__ off,
                                                      uint32_t* __restrict__ entries) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,8 +165,8 @@ __global__ __launch_bounds__(256) void k_msm_scatter(long n, int W, int NB, cons
   for (int w = 0; w < W; w++) {
     uint32_t dg = digits[(size_t)w * n + i];
     if (!dg) continue;
-    uint32_t key = (uint32_t)w * NB + (dg & 0x7fffffffu) - 1;
-    entries[off[key] + rank[(size_t)w * n + i]] = (uint32_t)i | (dg & 0x80000000u);
+    uint32_t key = (uint32_t)w * keystride + (dg & 0x7fffffffu) - 1;
+    entries[off[key] + rank[(size_t)w * n + i]] = (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (dg & 0x80000000u);   // index | window (tables only) | sign
   }
 }
 
@@ -232,15 +251,16 @@ __global__ __launch_bounds__(256) void k_border_scatter(const uint32_t* __restri
 }
 
 // ---- bucket accumulation ---------------------------------------------------------------------
-__device__ __forceinline__ G1Affine load_point_signed(const G1Affine* __restrict__ pts, uint32_t e) {
-  G1Affine p = pts[e & 0x7fffffffu];
-  if (e >> 31) p.y = fp_neg(p.y);
-  return p;
+// entry = point index | sign (bit 31); over window tables additionally the window in bits 26..30 and the
+// point of (i, w) is tab[w * stride + i] = 2^(c w) P_i
+__device__ __forceinline__ size_t entry_point(uint32_t e, long stride) {
+  if (stride == 0) return (size_t)(e & 0x7fffffffu);
+  return (size_t)(e & 0x03ffffffu) + (size_t)((e >> 26) & 31u) * (size_t)stride;
 }
 
 __global__ __launch_bounds__(256, 2) void k_bucket_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                       const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
-                                                      uint32_t nbuckets, uint32_t heavy_t,
+                                                      long stride, uint32_t nbuckets, uint32_t heavy_t,
                                                       G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs,
                                                       HeavyItem* items) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,10 +284,10 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const G1Affine* __restr
     const uint32_t last = end - 1;
     uint32_t e_cur = entries[beg];
     uint32_t e_nxt = entries[beg + 1 <= last ? beg + 1 : last];
-    G1Affine p_cur = pts[e_cur & 0x7fffffffu];
+    G1Affine p_cur = pts[entry_point(e_cur, stride)];
     for (uint32_t e = beg; e < end; e++) {
       const uint32_t e_nn = entries[e + 2 <= last ? e + 2 : last];
-      const G1Affine p_nxt = pts[e_nxt & 0x7fffffffu];
+      const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
       if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
       acc = g1_add_mixed(acc, p_cur);
       p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const G1Affine* __restr
 }
 
 __global__ __launch_bounds__(256, 2) void k_heavy_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
-                                                     const uint32_t* __restrict__ off, const HeavyMeta* hm,
+                                                     const uint32_t* __restrict__ off, long stride, const HeavyMeta* hm,
                                                      const HeavyItem* items, G1XYZZ* __restrict__ partial) {
   __shared__ G1XYZZ sh[256];
   const uint32_t n_items = hm->n_items;
@@ -293,10 +313,10 @@ __global__ __launch_bounds__(256, 2) void k_heavy_accum(const G1Affine* __restri
       uint32_t e = beg + threadIdx.x;
       uint32_t e_cur = entries[e];
       uint32_t e_nxt = entries[e + 256 <= last ? e + 256 : last];
-      G1Affine p_cur = pts[e_cur & 0x7fffffffu];
+      G1Affine p_cur = pts[entry_point(e_cur, stride)];
       for (; e < end; e += 256) {
         const uint32_t e_nn = entries[e + 512 <= last ? e + 512 : last];
-        const G1Affine p_nxt = pts[e_nxt & 0x7fffffffu];
+        const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
         if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
         acc = g1_add_mixed(acc, p_cur);
         p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
@@ -367,6 +387,21 @@ __global__ __launch_bounds__(256, 2) void k_window_sum(const G1XYZZ* __restrict_
   }
 }
 
+// out[g] = sum of in[g * group .. (g+1) * group): pre-reduction when one window has very many segments
+__global__ __launch_bounds__(256, 2) void k_group_sum(const G1XYZZ* __restrict__ in, long n_in, int group, G1XYZZ* __restrict__ out) {
+  __shared__ G1XYZZ sh[256];
+  const long base = (long)blockIdx.x * group;
+  G1XYZZ acc = G1XYZZ::inf();
+  for (long s = threadIdx.x; s < group && base + s < n_in; s += 256) acc = g1_add(acc, in[base + s]);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
 // ---- tail (host) -----------------------------------------------------------------------------
 // What is left of an MSM after the bulk kernels is W <= 64 window sums: Horner over the windows
 // (255 dependent doublings) and one Fq inversion for the canonical affine form.  That is ~2600
@@ -395,7 +430,8 @@ void g1_canonical_bytes_host(const G1XYZZ& p, uint8_t* out) {
 void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points, const Fr* d_scalars,
                  long n, bool scalars_mont, MsmSlot* d_slot) {
   ws.reserve(n > 0 ? n : 1, pl);
-  const size_t M = (size_t)pl.W * pl.NB;
+  const size_t M = (size_t)pl.Wb * pl.NB;
+  const int keystride = pl.Wb == 1 ? 0 : pl.NB;
   uint32_t* count = ws.count.as<uint32_t>();
   uint32_t* off = ws.off.as<uint32_t>();
   HeavyMeta* hm = ws.heavy_meta.as<HeavyMeta>();
@@ -403,7 +439,7 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
   HIP_OK(hipMemsetAsync(count, 0, (M + 1) * 4, st));
   HIP_OK(hipMemsetAsync(hm, 0, sizeof(HeavyMeta), st));
   if (n > 0) {
-    LAUNCH(k_msm_digits, ceil_div(n, 256), 256, 0, st, d_scalars, n, pl.c, pl.W, pl.NB, (int)scalars_mont, count,
+    LAUNCH(k_msm_digits, ceil_div(n, 256), 256, 0, st, d_scalars, n, pl.c, pl.W, keystride, (int)scalars_mont, count,
            ws.digits.as<uint32_t>(), ws.rank.as<uint32_t>());
   }
   const int ntiles = ceil_div((long)M + 1, 2048);
@@ -412,7 +448,7 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
   LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ntiles, tiles + ntiles);
   LAUNCH(k_scan_apply, ntiles, 256, 0, st, (const uint32_t*)count, M + 1, (const uint32_t*)tiles, off);
   if (n > 0) {
-    LAUNCH(k_msm_scatter, ceil_div(n, 256), 256, 0, st, n, pl.W, pl.NB, (const uint32_t*)ws.digits.as<uint32_t>(),
+    LAUNCH(k_msm_scatter, ceil_div(n, 256), 256, 0, st, n, pl.W, keystride, (const uint32_t*)ws.digits.as<uint32_t>(),
            (const uint32_t*)ws.rank.as<uint32_t>(), (const uint32_t*)off, ws.entries.as<uint32_t>());
   }
   {
@@ -428,15 +464,23 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
     LAUNCH(k_border_scatter, nblk, 256, 0, st, (const uint32_t*)off, (uint32_t)M, nblk, (const uint32_t*)hist_sc, ws.order.as<uint32_t>());
   }
   LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(),
-         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), (uint32_t)M, pl.heavy_threshold, ws.buckets.as<G1XYZZ>(), hm, hrecs,
+         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, ws.buckets.as<G1XYZZ>(), hm, hrecs,
          ws.heavy_items.as<HeavyItem>());
   LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
-         (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
+         pl.table_stride, (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
   LAUNCH(k_heavy_finish, 256, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), ws.buckets.as<G1XYZZ>());
-  LAUNCH(k_bucket_segments, ceil_div((long)pl.W * pl.nseg, 64), 64, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), pl.W,
+  LAUNCH(k_bucket_segments, ceil_div((long)pl.Wb * pl.nseg, 64), 64, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), pl.Wb,
          pl.NB, pl.K, pl.nseg, ws.segres.as<G1XYZZ>());
-  LAUNCH(k_window_sum, pl.W, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), pl.W, pl.c, pl.nseg, d_slot);
+  if (pl.Wb == 1 && pl.nseg > 4096) {
+    // one window with tens of thousands of segments: 256-way groups first, then the window tree
+    const int group = 256, ngroups = ceil_div(pl.nseg, group);
+    G1XYZZ* part = ws.segres.as<G1XYZZ>() + pl.nseg;
+    LAUNCH(k_group_sum, ngroups, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), (long)pl.nseg, group, part);
+    LAUNCH(k_window_sum, 1, 256, 0, st, (const G1XYZZ*)part, 1, pl.c, ngroups, d_slot);
+  } else {
+    LAUNCH(k_window_sum, pl.Wb, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), pl.Wb, pl.c, pl.nseg, d_slot);
+  }
 }
 
 }  // namespace sonic

@@ -8,12 +8,15 @@ namespace sonic {
 struct MsmPlan {
   int c;        // window bits
   int W;        // windows: ceil(255 / c) (scalars are first folded into [0, (r-1)/2])
-  int NB;       // buckets per window: digit magnitudes 1 .. 2^(c-1)
+  int Wb;       // bucket sets: W (one per window), or 1 when the windows share buckets over precomputed tables
+  long table_stride;   // points per window table (0: no tables, every window reads the same points)
+  int NB;       // buckets per set: digit magnitudes 1 .. 2^(c-1)
   int K;        // buckets per running-sum segment
   int nseg;     // segments per window
   uint32_t heavy_threshold;
 };
 MsmPlan msm_plan(long n);
+MsmPlan msm_plan_tables(long n, int c, int W, long table_stride);
 
 constexpr int MSM_MAX_WINDOWS = 64;
 

@@ -45,7 +45,7 @@ static void commit_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& w
   const long ih = -shift - lo;
   if (ih >= i0 && ih < i1) flag_nonzero_enqueue(st, poly + ih, 1, d_flags, FLAG_SRS_INDEX);
   const long n = i1 - i0;
-  MsmPlan pl = msm_plan(n > 0 ? n : 1);
+  MsmPlan pl = srs_msm_plan(srs, n);
   msm_enqueue(st, ws, pl, srs_basis(srs, 1) + (lo + i0 + shift + d), poly + i0, n, true, slot);
 }
 
@@ -73,7 +73,7 @@ static void open_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws,
   flag_nonzero_enqueue(st, q, i0, d_flags, FLAG_SRS_INDEX);
   flag_nonzero_enqueue(st, q + i1, qn - i1, d_flags, FLAG_SRS_INDEX);
   const long n = i1 - i0;
-  MsmPlan pl = msm_plan(n > 0 ? n : 1);
+  MsmPlan pl = srs_msm_plan(srs, n);
   msm_enqueue(st, ws, pl, srs_basis(srs, 0) + (lo + i0 + d), q + i0, n, true, slot);
 }
 
@@ -223,6 +223,7 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
     mkev(&l.done);
     l.sc.reserve(tlen);
     l.sc.scan.ensure(sizeof(Fr) * (tlen / 1024 + 2));
+    l.ws.reserve(tlen, srs_msm_plan(srs, tlen));
     l.ws.reserve(tlen, msm_plan(tlen));
   }
   HIP_OK(hipStreamSynchronize(st));

@@ -78,6 +78,37 @@ __global__ __launch_bounds__(64) void k_batch_affine(const G1XYZZ* __restrict__ 
   }
 }
 
+// dst[i] = 2^c * src[i]
+__global__ __launch_bounds__(256) void k_table_step(const G1Affine* __restrict__ src, G1XYZZ* __restrict__ dst, long m, int c) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const G1Affine p = src[i];
+  G1XYZZ acc = g1_dbl_affine(p);
+  for (int k = 1; k < c; k++) acc = g1_dbl(acc);
+  dst[i] = acc;
+}
+
+void srs_build_tables(hipStream_t st, sonic_srs* s) {
+  const int W = srs_tab_W(s), c = srs_tab_c(s);
+  if (getenv("SONIC_DEBUG_TIMING")) fprintf(stderr, "[sonic] window tables: c=%d W=%d d=%ld\n", c, W, (long)srs_d(s));
+  if (W <= 1) return;
+  const long n = 2 * srs_d(s) + 1;
+  const long SLAB = 1L << 20;
+  const long cap = n < SLAB ? n : SLAB;
+  DevBuf x(sizeof(G1XYZZ) * cap), pref(sizeof(Fq) * cap);
+  for (int b = 0; b < 2; b++) {
+    G1Affine* tab = srs_basis_mut(s, b);
+    for (int w = 1; w < W; w++) {
+      for (long base = 0; base < n; base += SLAB) {
+        const long m = n - base < SLAB ? n - base : SLAB;
+        LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (const G1Affine*)(tab + (size_t)(w - 1) * n + base), x.as<G1XYZZ>(), m, c);
+        LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), tab + (size_t)w * n + base, pref.as<Fq>(), m);
+      }
+    }
+  }
+  HIP_OK(hipStreamSynchronize(st));
+}
+
 __global__ void k_fr_setup_x(const Fr* in_std, Fr* out) {  // out = {x, x^-1, alpha} Montgomery
   Fr x = fp_to_mont(in_std[0]), a = fp_to_mont(in_std[1]);
   out[0] = x; out[1] = fp_inv(x); out[2] = a;
@@ -106,6 +137,7 @@ void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha
     LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x1.as<G1XYZZ>(), srs_basis_mut(s, 1) + base, pref.as<Fq>(), m);
   }
   HIP_OK(hipStreamSynchronize(st));
+  srs_build_tables(st, s);
 }
 
 }  // namespace sonic

@@ -62,6 +62,29 @@ def test_msm_srs_slices(sonic, orc, srs_pair, n, kind):
         assert msm_g1_srs(g, basis, e0, sc) == orc.msm_srs(o, basis, e0, sc, 1, NCPU)
 
 
+def test_window_tables(sonic, orc, srs_pair):
+    """the precomputed window tables (table w = 2^(c w) * basis) behind the shared-bucket MSM, read back through the
+    diagnostic basis index b + 2w; and an SRS built with the tables switched off gives the same MSM"""
+    import os
+    from sonic_amd.commitment import msm_g1_srs
+    d, x, alpha, g, o = srs_pair
+    c = 11                                       # floor(log2 d) - 1 for d = 2^12
+    P = o.points(1, -d, 2 * d + 1)
+    for w in (1, 2, 23):
+        T = g.points(1 + 2 * w, -d, 2 * d + 1)
+        for i in (0, 1, 63, 64, 65, 4095, 4096, 4097, 8192):
+            assert T[i].tobytes() == orc.g1_mul(P[i].tobytes(), pow(2, c * w, R)), (w, i)
+    os.environ["SONIC_MSM_TABLES"] = "0"
+    try:
+        plain = sonic.SRS.new(d, x, alpha)
+    finally:
+        del os.environ["SONIC_MSM_TABLES"]
+    with pytest.raises(sonic.SonicError):
+        plain.points(2, 0, 1)                    # no table 1
+    sc = rand_fr_array(np.random.default_rng(77), 5000)
+    assert msm_g1_srs(plain, 1, -2500, sc) == msm_g1_srs(g, 1, -2500, sc) == orc.msm_srs(o, 1, -2500, sc, 1, NCPU)
+
+
 @pytest.mark.parametrize("c", [4, 7, 11, 16])
 def test_msm_window_sizes(sonic, orc, srs_pair, c):
     from sonic_amd import _lib

@@ -199,23 +199,26 @@ def cxx(name: str, cls: str, N: int, p: int) -> str:
     lines.append(f'      ".popsection{NL}"')
     lines.append("  );")
     lines.append("}")
-    ins_out = ", ".join(f'"+{{v{j}}}"(r.l[{j}])' for j in range(N))
-    ins_in = ", ".join(f'"{{v{N + j}}}"(b.l[{j}])' for j in range(N))
-    clob = [f'"v{k}"' for k in range(2 * N, nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 58))] + ['"vcc"', '"scc"', '"memory"']
+    # Operands use generic "v" constraints and are moved to / from the routine's fixed registers INSIDE the asm
+    # text.  (Binding them with physical-register constraints, "{v0}" ..., made ROCm 7.2's clang silently drop
+    # copies between consecutive calls -- wrong products in some kernels -- and crash its scheduler in others.)
+    outs = ", ".join(f'"=v"(r.l[{j}])' for j in range(N))
+    ins = ", ".join([f'"v"(a.l[{j}])' for j in range(N)] + [f'"v"(b.l[{j}])' for j in range(N)])
+    clob = [f'"v{k}"' for k in range(0, nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 58))] + ['"vcc"', '"scc"']
     lines.append(f"__device__ __forceinline__ {cls} {name}_call(const {cls}& a, const {cls}& b) {{")
-    lines.append(f"  {cls} r = a;")
-    lines.append("  // the scheduler of ROCm 7.2's clang mishandles (crashes on, or misorders around) asm statements with")
-    lines.append("  // this many physical-register operands: fence the marshalling copies and the call on both sides")
-    lines.append("  __builtin_amdgcn_sched_barrier(0);")
+    lines.append(f"  {cls} r;")
     lines.append("  asm volatile(")
+    for j in range(2 * N):
+        lines.append(f'      "v_mov_b32_e32 v{j}, %{N + j}\\n\\t"')
     lines.append('      "s_getpc_b64 s[56:57]\\n\\t"')
     lines.append(f'      "s_add_u32 s56, s56, {name}@rel32@lo+4\\n\\t"')
     lines.append(f'      "s_addc_u32 s57, s57, {name}@rel32@hi+12\\n\\t"')
-    lines.append('      "s_swappc_b64 s[30:31], s[56:57]"')
-    lines.append(f"      : {ins_out}")
-    lines.append(f"      : {ins_in}")
-    lines.append(f"      : {', '.join(clob[:-1])});")
-    lines.append("  __builtin_amdgcn_sched_barrier(0);")
+    lines.append('      "s_swappc_b64 s[30:31], s[56:57]\\n\\t"')
+    for j in range(N):
+        lines.append(f'      "v_mov_b32_e32 %{j}, v{j}' + ('\\n\\t"' if j < N - 1 else '"'))
+    lines.append(f"      : {outs}")
+    lines.append(f"      : {ins}")
+    lines.append(f"      : {', '.join(clob)});")
     lines.append("  return r;")
     lines.append("}")
     return "\n".join(lines)

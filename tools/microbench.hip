@@ -113,6 +113,22 @@ template <class F> int check_mul(const char* name) {
   return hb;
 }
 
+__global__ void k_check_dbl(const G1Affine* pts, int n, int* bad, int c) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  G1Affine p = pts[t];
+  G1XYZZ a = g1_dbl_affine(p);
+  for (int k = 1; k < c; k++) a = g1_dbl(a);
+  G1XYZZ b = g1_mul_small(G1XYZZ::from_affine(p), 1u << 11);
+  G1Affine x = g1_to_affine(a), y = g1_to_affine(b);
+  if (x.x != y.x || x.y != y.y) atomicAdd(bad, 1);
+  // mixed add of equal points must take the doubling path
+  G1XYZZ c2 = g1_add_mixed(G1XYZZ::from_affine(p), p);
+  G1XYZZ d2 = g1_dbl(G1XYZZ::from_affine(p));
+  G1Affine u = g1_to_affine(c2), v = g1_to_affine(d2);
+  if (u.x != v.x || u.y != v.y) atomicAdd(bad + 1, 1);
+}
+
 template <class F> float time_ms(F f, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -129,6 +145,9 @@ int main() {
   void* buf; CK(hipMalloc(&buf, (size_t)blocks * threads * sizeof(G1XYZZ)));
   G1Affine* pts; CK(hipMalloc(&pts, 4096 * sizeof(G1Affine)));
   hipLaunchKernelGGL(k_mkpts, 16, 256, 0, 0, pts); CK(hipDeviceSynchronize());
+  { int* bad; int hb[2] = {0, 0}; hipMalloc(&bad, 8); hipMemset(bad, 0, 8);
+    hipLaunchKernelGGL(k_check_dbl, 16, 256, 0, 0, (const G1Affine*)pts, 4096, bad, 11); hipMemcpy(hb, bad, 8, hipMemcpyDeviceToHost);
+    printf("dbl_affine^11 vs mul_small(2^11): %d mismatches; add_mixed(P,P) vs dbl: %d mismatches\n", hb[0], hb[1]); }
   const double lanes = (double)blocks * threads;
   { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_mad, blocks, threads, 0, 0, (uint64_t*)buf, 12345u, 67891u, it); }, 10);
     printf("v_mad_u64_u32: %.3f ms -> %.3e mad/s  (%.2f lane-ops/clk/CU at 2.4GHz)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
