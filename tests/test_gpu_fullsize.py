@@ -1,0 +1,130 @@
+"""Parity at BASELINE.json's full size (n = 2^18, d = 2^21) through a size-independent property: the
+known-trapdoor exponent check.  The SRS is built from known x, alpha (as every reference test does,
+test/Test/Protocol.hs:21), so every group element of a proof has a discrete log that is a polynomial
+*evaluation*, computable in O(n) big-integer operations without any MSM:
+
+    commitPoly srs max f = g^{alpha x^{d-max} f(x)}          openPoly srs z f = (f(z), g^{(f(x)-f(z))/(x-z)})
+
+The GPU proof must equal, byte for byte, the proof rebuilt from those logs (one fixed-base scalar
+multiplication per element on the CPU oracle) and the evaluations -- which is exactly what verify / pcV /
+hscVerify accept (src/Sonic/Protocol.hs:111-130, src/Sonic/Signature.hs:74-90)."""
+import random
+
+import numpy as np
+import pytest
+
+from util import NCPU, R, big_circuit, fr_bytes, rand_fr_array
+
+pytestmark = pytest.mark.gpu
+
+
+def geom(a, lo, hi):
+    """sum_{i=lo..hi} a^i  (a != 1)"""
+    return (pow(a, hi + 1, R) - pow(a, lo, R)) * pow(a - 1, -1, R) % R
+
+
+class Evals:
+    """evaluations of r'(X,Y), s(X,Y), k(Y) for the benchmark circuit (one all-ones row per weight matrix)"""
+
+    def __init__(self, circ, n, Q, cns):
+        self.n, self.Q, self.cns = n, Q, cns
+        self.la, self.lb, self.lo = circ["ints"]
+        self.rows, self.cs = circ["rows"], circ["cs_ints"]
+
+    def r1(self, a):
+        """r'(a, 1) = sum a_i a^i + b_i a^-i + c_i a^{-i-n} + sum c_{n+i} a^{-2n-i}"""
+        n = self.n
+        ai = pow(a, -1, R)
+        acc, p, q = 0, 1, 1
+        an = pow(ai, n, R)
+        for i in range(n):
+            p = p * a % R
+            q = q * ai % R
+            acc += self.la[i] * p + (self.lb[i] + self.lo[i] * an) * q
+        acc %= R
+        base = pow(ai, 2 * n, R)
+        for i, c in enumerate(self.cns, start=1):
+            acc += c * base * pow(ai, i, R)
+        return acc % R
+
+    def s(self, a, b):
+        """s(a, b) (Constraints.hs:34-53) with wL, wR, wO = one all-ones row at rows[0..2]"""
+        n = self.n
+        ai, bi = pow(a, -1, R), pow(b, -1, R)
+        rL, rR, rO = self.rows
+        u = pow(b, n + rL + 1, R) * geom(ai, 1, n)
+        v = pow(b, n + rR + 1, R) * geom(a, 1, n)
+        an = pow(a, n, R)
+        w = an * (pow(b, n + rO + 1, R) * geom(a, 1, n) - geom(a * b % R, 1, n) - geom(a * bi % R, 1, n))
+        return (u + v + w) % R
+
+    def k(self, b):
+        return sum(c * pow(b, self.n + q + 1, R) for q, c in enumerate(self.cs)) % R
+
+
+@pytest.mark.parametrize("log2n", [18])
+def test_prove_full_size_exponent_oracle(sonic, orc, log2n):
+    n, Q = 1 << log2n, 2
+    d = 8 * n
+    pyr = random.Random(2026)
+    x, alpha = pyr.randrange(2, R), pyr.randrange(2, R)
+    srs = sonic.SRS.new(d, x, alpha)
+    circ = big_circuit(4242, n, Q, orc)
+    tr = [pyr.randrange(2, R) for _ in range(8 + 2 * Q)]
+    p = sonic.Prover(srs, sonic.ArithCircuit(sonic.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
+    p.set_assignment(sonic.Assignment(circ["aL"], circ["aR"], circ["aO"]))
+    proof = sonic.Proof.from_bytes(p.prove_bytes(fr_bytes(tr)), Q)
+
+    cns, y, z = tr[0:4], tr[4], tr[5]
+    ys, zs, u, v = tr[6:6 + Q], tr[6 + Q:6 + 2 * Q], tr[6 + 2 * Q], tr[7 + 2 * Q]
+    E = Evals(circ, n, Q, cns)
+    g = orc.g1_gen()
+    G = lambda k: sonic.g1_from_bytes(orc.g1_mul(g, k % R))
+    inv = lambda a: pow(a, -1, R)
+    xd = lambda maxm: pow(x, d - maxm, R)
+
+    r_x, r_z, r_yz = E.r1(x), E.r1(z), E.r1(y * z % R)
+    t_at = lambda a: (E.r1(a) * (E.r1(a * y % R) + E.s(a, y)) - E.k(y)) % R   # r(X,y) = r(Xy,1): test/Test/Constraints.hs:29-34
+    t_x, t_z = t_at(x), t_at(z)
+    assert proof.prR == G(alpha * xd(n) * r_x)                                  # Protocol.hs:63
+    assert proof.prT == G(alpha * t_x)                                          # :73
+    assert proof.prA == r_z and proof.prWa == G((r_x - r_z) * inv(x - z))       # :79
+    assert proof.prB == r_yz and proof.prWb == G((r_x - r_yz) * inv(x - y * z)) # :80
+    assert proof.prWt == G((t_x - t_z) * inv(x - z))                            # :81
+    assert proof.prS == E.s(z, y)                                               # :83
+    assert (proof.prA * (proof.prB + proof.prS) - E.k(y)) % R == t_z            # verify's t, Protocol.hs:120
+    h = proof.prHscProof
+    s_ux = E.s(u, x)
+    assert h.hscC == G(alpha * s_ux)                                            # Signature.hs:52
+    assert h.hscQv == G((s_ux - E.s(u, v)) * inv(x - v))                        # :63
+    assert h.hscU == u and h.hscV == v
+    for j in range(Q):
+        s_xy, s_zy, s_uy = E.s(x, ys[j]), E.s(zs[j], ys[j]), E.s(u, ys[j])
+        cm, (sj, wj) = h.hscS[j]
+        sjp, wjp, qj = h.hscW[j]
+        assert cm == G(alpha * s_xy)                                            # :42
+        assert sj == s_zy and wj == G((s_xy - s_zy) * inv(x - zs[j]))           # :43
+        assert sjp == s_uy and wjp == G((s_xy - s_uy) * inv(x - u))             # :54-55
+        assert qj == G((s_ux - s_uy) * inv(x - ys[j]))                          # :55
+
+
+def test_msm_full_size_properties(sonic, orc):
+    """N = 2^20 MSM over an SRS slice: MSM(2a) == 2 MSM(a) (linearity), and the trapdoor value
+    g^{alpha x sum_i (x0 x)^i} for the geometric scalar vector 1, x0, x0^2, ... in closed form"""
+    from sonic_amd.commitment import msm_g1_srs
+    d = 1 << 19
+    pyr = random.Random(7)
+    x, alpha = pyr.randrange(2, R), pyr.randrange(2, R)
+    srs = sonic.SRS.new(d, x, alpha)
+    N = 1 << 20
+    a = rand_fr_array(np.random.default_rng(9), N)
+    A = msm_g1_srs(srs, 0, -d, a)
+    a2 = fr_bytes([2 * int.from_bytes(a[i].tobytes(), "little") % R for i in range(N)])
+    assert msm_g1_srs(srs, 0, -d, a2) == orc.g1_add(A, A)
+    x0 = pyr.randrange(2, R)
+    M = 1 << 16
+    pw = [1] * M
+    for i in range(1, M):
+        pw[i] = pw[i - 1] * x0 % R
+    got = msm_g1_srs(srs, 1, 1, fr_bytes(pw))
+    assert got == orc.g1_mul(orc.g1_gen(), alpha * x % R * geom(x0 * x % R, 0, M - 1) % R)

@@ -51,4 +51,5 @@ def big_circuit(seed: int, n: int, Q: int, orc):
     cs = [0] * Q
     for k, r_ in enumerate(rows):
         cs[int(r_)] = (cs[int(r_)] + sums[k]) % R
-    return dict(wL=W[0], wR=W[1], wO=W[2], cs=fr_bytes(cs), aL=aL, aR=aR, aO=aO)
+    return dict(wL=W[0], wR=W[1], wO=W[2], cs=fr_bytes(cs), aL=aL, aR=aR, aO=aO,
+                rows=[int(r_) for r_ in rows], ints=(la, lb, lo), cs_ints=cs)
