@@ -204,12 +204,13 @@ def main():
                 "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "modular-integer kernel: binding roof is v_mad_u64_u32 issue, see int_roofline"}
     # integer roof: W windows x N mixed additions x 10 Fq products x 288 MADs
-    from math import ceil
-    c_win = 16 if msm_n >= (1 << 20) else max(4, msm_n.bit_length() - 5)
-    mads = ceil(255 / c_win) * msm_n * 10 * 288
+    pc, pw_, pb = C.c_int(), C.c_int(), C.c_int()
+    L.sonic_msm_plan(srs._h, msm_n, C.byref(pc), C.byref(pw_), C.byref(pb))
+    mads = pw_.value * msm_n * 10 * 288
     int_roofline = {"bound": "v_mad_u64_u32", "achieved": round(mads / (accum_ms * 1e-3) / 1e12, 3) if accum_ms > 0 else 0.0,
                     "peak": MAD_PEAK_PER_S / 1e12, "unit": "TMAD/s",
-                    "frac": round(mads / (accum_ms * 1e-3) / MAD_PEAK_PER_S, 4) if accum_ms > 0 else 0.0}
+                    "frac": round(mads / (accum_ms * 1e-3) / MAD_PEAK_PER_S, 4) if accum_ms > 0 else 0.0,
+                    "plan": {"window_bits": pc.value, "windows": pw_.value, "bucket_sets": pb.value}}
 
     cpu_baseline = None
     if not args.no_cpu:

@@ -104,6 +104,9 @@ int sonic_ntt_fr(uint8_t* data, int log2n, int inverse);
 int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out);
 /* MSM tuning knob for tests: window bits (0 = automatic) */
 int sonic_msm_set_window(int c);
+/* what an n-term MSM over this SRS will run as: window bits, number of windows, and bucket sets
+ * (1 = all windows share one bucket set over the precomputed window tables, else one set per window) */
+int sonic_msm_plan(const sonic_srs_t* srs, int64_t n, int* window_bits, int* windows, int* bucket_sets);
 
 /* ---- Sonic.Protocol / Sonic.Signature ---- */
 size_t sonic_proof_size(int64_t Q);

@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
         "sonic_ntt_fr": [vp, i32, i32],
         "sonic_poly_mul_fr": [vp, i64, vp, i64, vp],
         "sonic_msm_set_window": [i32],
+        "sonic_msm_plan": [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "sonic_prove": [vp, i64, i64] + [vp] * 9,
         "sonic_prover_new": [vp, i64, i64, vp, vp, vp, vp, C.POINTER(vp)],
         "sonic_prover_set_assignment": [vp, vp, vp, vp],
@@ -92,7 +93,7 @@ EXPORTED = [
     "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_srs_new", "sonic_srs_from_points",
     "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
-    "sonic_g1_sum_partials", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window",
+    "sonic_g1_sum_partials", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
     "sonic_prover_prove", "sonic_prover_free", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
     "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",

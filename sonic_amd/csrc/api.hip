@@ -248,6 +248,15 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
 
 int sonic_msm_set_window(int c) { msm_set_window_override(c); return SONIC_OK; }
 
+int sonic_msm_plan(const sonic_srs_t* srs, int64_t n, int* window_bits, int* windows, int* bucket_sets) {
+  if (!srs || n < 0) return SONIC_ERR_INVALID_ARG;
+  MsmPlan pl = srs_msm_plan(srs, n);
+  if (window_bits) *window_bits = pl.c;
+  if (windows) *windows = pl.W;
+  if (bucket_sets) *bucket_sets = pl.Wb;
+  return SONIC_OK;
+}
+
 int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]) {
   API_BEGIN
   if (n < 0 || !out_g1 || (n > 0 && (!points || !scalars))) return SONIC_ERR_INVALID_ARG;
