@@ -100,7 +100,7 @@ struct Lane {
   MsmWorkspace ws;
   Scratch sc;
 };
-constexpr int N_LANES = 3;
+constexpr int N_LANES = 8;
 
 struct sonic_prover {
   const sonic_srs* srs = nullptr;
