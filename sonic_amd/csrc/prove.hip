@@ -92,8 +92,8 @@ using namespace sonic;
 
 // One MSM "lane": its own stream, bucket workspace and opening scratch.  The 7+4Q MSMs of a proof are
 // independent once their input polynomial exists, and every MSM has latency-bound phases (bucket
-// running sums, window trees, histogram atomics) that leave most of the chip idle: three lanes let one
-// MSM's reduction overlap another's accumulation.
+// running sums, window trees, histogram atomics) that leave most of the chip idle: several lanes let one
+// MSM's reduction overlap another's accumulation (measured at n = 2^18: 2 lanes 64.9 ms, 5: 60.9, 8: 58.3, 12: 59.5).
 struct Lane {
   hipStream_t st = nullptr;
   hipEvent_t done = nullptr;

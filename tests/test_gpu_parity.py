@@ -260,3 +260,21 @@ def test_prover_handle_reuse(sonic, orc, ref, srs_pair):
         tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
         want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
         assert p.prove_bytes(tr) == want
+
+
+def test_reference_verifier_accepts_gpu_proofs(sonic, ref):
+    """the reference's only end-to-end test, verify . prove (test/Test/Protocol.hs:14-23), with the proof made by
+    the HIP path and the verifier restated with real pairings (oracle/pairing.py: pcV, hscVerify, verify)"""
+    from oracle import pairing as pg
+    pyr = random.Random(31)
+    for n, Q in ((1, 1), (3, 2)):
+        circ, asg = ref.rnd_circuit(pyr, n, Q)
+        d = {1: 12}.get(n, 7 * n) + pyr.randrange(5)
+        x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+        g = sonic.SRS.new(d, x, alpha)
+        proof, ro = sonic.prove(g, sonic.Assignment(*asg), sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3]), rng=pyr)
+        vsrs = pg.SRS(d, x, alpha)
+        pr = pg.proof_from_bytes(proof.to_bytes(), Q)
+        assert pg.verify(vsrs, circ, pr, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+        pr["prB"] = (pr["prB"] + 1) % R
+        assert not pg.verify(vsrs, circ, pr, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)

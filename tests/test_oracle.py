@@ -199,3 +199,30 @@ def test_oracle_ntt_roundtrip_and_product(orc):
     assert np.array_equal(orc.ntt(orc.ntt(a), True), a)
     b = rand_fr_array(g, 100)
     assert np.array_equal(orc.poly_mul(a, b, True), orc.poly_mul(a, b, False))
+
+
+# ---- the reference's acceptance tests with real pairings (oracle/pairing.py) ---------------------
+def test_pairing_selfcheck():
+    from oracle import pairing
+    assert pairing.selfcheck()
+
+
+def test_verify_accepts_prove_with_pairings(ref):
+    """test/Test/Protocol.hs:14-23: verify srs circuit proof y z yzs == True for what prove produced, and
+    test/Test/CommitmentScheme.hs:58-71: pcV on r(X,1) with max = n -- through e(.,.) on BLS12-381, not the trapdoor"""
+    from oracle import pairing as pg
+    pyr = random.Random(77)
+    for circ, asg in (ref.arith_circuit_example1(), ref.rnd_circuit(pyr, 2, 1)):
+        n, Q = len(asg[0]), len(circ[0])
+        d = {1: 12, 2: 16}[n] + pyr.randrange(4)
+        srs = pg.SRS(d, pyr.randrange(1, R), pyr.randrange(1, R))
+        tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+        proof, ro = ref.prove(srs, asg, circ, tr)
+        assert pg.verify(srs, circ, proof, ro["y"], ro["z"], ro["yzs"])
+        bad = dict(proof); bad["prWt"] = ref.g1_add(proof["prWt"], ref.G1_GEN)
+        assert not pg.verify(srs, circ, bad, ro["y"], ro["z"], ro["yzs"])
+        rX1 = ref.eval_y(1, ref.r_poly(*asg))
+        z = pyr.randrange(1, R)
+        F, op = ref.commit_poly(srs, n, rX1), ref.open_poly(srs, z, rX1)
+        assert pg.pc_v(srs, n, F, z, op)
+        assert not pg.pc_v(srs, n, F, z, ((op[0] + 1) % R, op[1]))
