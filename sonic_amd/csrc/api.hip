@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "internal.hpp"
+#include "g2.hpp"
 
 namespace sonic {
 
@@ -132,6 +133,11 @@ struct sonic_srs {
   // (w = 0 is the basis itself; tab_W = 1 when the window tables are switched off)
   int tab_c = 0, tab_W = 1;
   DevBuf g, ga;
+  // verifier half, generated on first use from the trapdoor SRS.new was given (absent for from_points handles)
+  bool have_trapdoor = false;
+  Fr x_std, alpha_std;
+  mutable std::mutex g2_mu;
+  mutable DevBuf h, ha;      // G2Affine[2d+1] each
   const G1Affine* basis(int b) const { return (b ? ga : g).as<G1Affine>(); }
 };
 
@@ -164,6 +170,7 @@ sonic_srs* srs_alloc(int64_t d) {
   return s;
 }
 G1Affine* srs_basis_mut(sonic_srs* s, int b) { return (b ? s->ga : s->g).as<G1Affine>(); }
+void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std) { s->have_trapdoor = true; s->x_std = x_std; s->alpha_std = alpha_std; }
 
 // plan for an MSM over n consecutive SRS points: shared-bucket plan over the window tables unless the MSM is
 // tiny compared with the bucket set, the tables are off, or a test forces a window size
@@ -242,6 +249,30 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
   if (w >= srs->tab_W) { set_error("sonic_srs_get_points: no window table %d", w); return SONIC_ERR_INVALID_ARG; }
   LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs->basis(basis & 1) + (size_t)w * (2 * srs->d + 1) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
   HIP_OK(hipMemcpyAsync(out, raw.p, 96 * n, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  API_END
+}
+
+int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out) {
+  API_BEGIN
+  if (!srs || !out || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
+  if (e0 < -srs->d || e0 + n - 1 > srs->d) { set_error("sonic_srs_get_g2_points: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
+  if (!srs->have_trapdoor) { set_error("sonic_srs_get_g2_points: this SRS was built from points and has no G2 half"); return SONIC_ERR_INVALID_ARG; }
+  if (n == 0) return SONIC_OK;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  {
+    std::lock_guard<std::mutex> g2(srs->g2_mu);
+    if (!srs->h.p) {
+      const size_t cnt = (size_t)(2 * srs->d + 1);
+      srs->h.alloc(sizeof(G2Affine) * cnt);
+      srs->ha.alloc(sizeof(G2Affine) * cnt);
+      srs_generate_g2(st, srs->d, srs->x_std, srs->alpha_std, srs->h.as<G2Affine>(), srs->ha.as<G2Affine>());
+    }
+  }
+  DevBuf raw(192 * n);
+  g2_points_to_bytes_enqueue(st, (basis ? srs->ha : srs->h).as<G2Affine>() + (e0 + srs->d), raw.as<uint8_t>(), n);
+  HIP_OK(hipMemcpyAsync(out, raw.p, 192 * n, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   API_END
 }

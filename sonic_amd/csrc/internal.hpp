@@ -29,6 +29,11 @@ int srs_tab_W(const sonic_srs* s);
 MsmPlan srs_msm_plan(const sonic_srs* s, long n);
 // fills window tables 1 .. W-1 of both bases from table 0 (srs.hip)
 void srs_build_tables(hipStream_t st, sonic_srs* s);
+void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std);
+struct G2Affine;
+// G2 half (srs_g2.hip)
+void srs_generate_g2(hipStream_t st, long d, const Fr& x_std, const Fr& alpha_std, G2Affine* h0, G2Affine* h1);
+void g2_points_to_bytes_enqueue(hipStream_t st, const G2Affine* in, uint8_t* d_out, long n);
 
 // SRS generation (srs.hip): fills both bases of `s` from x, alpha (standard-form Fr on the host)
 void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha_std);

@@ -171,6 +171,7 @@ int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic
   std::lock_guard<std::mutex> g(call_mutex());
   sonic_srs* s = srs_alloc(d);
   try { srs_generate(default_stream(), s, xs, as); } catch (...) { sonic_srs_free(s); throw; }
+  srs_set_trapdoor(s, xs, as);
   *out = s;
   API_END
 }

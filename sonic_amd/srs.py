@@ -13,7 +13,7 @@ class SRS:
     """`data SRS` (SRS.hs:11-22), prover half.  Device layout: two arrays of 2d+1 affine points,
     basis 0 = g^{x^e}, basis 1 = g^{alpha x^e}, slot e + d; the reference's four G1 vectors are views:
     gNegativeX[k] = basis0[-(k+1)], gPositiveX[k] = basis0[k], gNegativeAlphaX[k] = basis1[-(k+1)],
-    gPositiveAlphaX[k] = basis1[k+1].  The G2 vectors are not held (the prover never reads them)."""
+    gPositiveAlphaX[k] = basis1[k+1].  The G2 vectors (verifier only) are generated lazily on first access."""
 
     def __init__(self, handle: C.c_void_p, d: int):
         self._h = handle
@@ -40,6 +40,33 @@ class SRS:
         out = np.zeros((n, 96), np.uint8)
         _lib.check(_lib.lib().sonic_srs_get_points(self._h, basis, e0, n, out.ctypes.data))
         return out
+
+    def g2_points(self, basis: int, e0: int, n: int) -> np.ndarray:
+        """G2 half (generated on the GPU on first use): uint8 [n, 192], x.c0 || x.c1 || y.c0 || y.c1"""
+        out = np.zeros((n, 192), np.uint8)
+        _lib.check(_lib.lib().sonic_srs_get_g2_points(self._h, basis, e0, n, out.ctypes.data))
+        return out
+
+    def _one_g2(self, name, basis, e, k, length):
+        if not (0 <= k < length):
+            raise IndexError(f"{name} is not long enough: {k} >= {length}")
+        b = self.g2_points(basis, e, 1)[0].tobytes()
+        if b == bytes(192):
+            return None
+        v = [int.from_bytes(b[i:i + 48], "little") for i in range(0, 192, 48)]
+        return ((v[0], v[1]), (v[2], v[3]))
+
+    def hNegativeX(self, k):            # SRS.hs:35
+        return self._one_g2("hNegativeX", 0, -(k + 1), k, self.srsD)
+
+    def hPositiveX(self, k):            # SRS.hs:36
+        return self._one_g2("hPositiveX", 0, k, k, self.srsD + 1)
+
+    def hNegativeAlphaX(self, k):       # SRS.hs:40
+        return self._one_g2("hNegativeAlphaX", 1, -(k + 1), k, self.srsD)
+
+    def hPositiveAlphaX(self, k):       # SRS.hs:41
+        return self._one_g2("hPositiveAlphaX", 1, k, k, self.srsD + 1)
 
     def _one(self, name, basis, e, k, length):
         if not (0 <= k < length):   # CommitmentScheme.hs:70-73

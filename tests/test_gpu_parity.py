@@ -62,6 +62,25 @@ def test_msm_srs_slices(sonic, orc, srs_pair, n, kind):
         assert msm_g1_srs(g, basis, e0, sc) == orc.msm_srs(o, basis, e0, sc, 1, NCPU)
 
 
+def test_srs_g2_half(sonic, srs_pair):
+    """the G2 vectors of SRS.new (SRS.hs:35-36,40-41) against python big-integer G2 arithmetic (oracle/pairing.py)"""
+    from oracle import pairing as pg
+    d, x, alpha, g, _ = srs_pair
+    s = pg.SRS(d, x, alpha)
+    for k in (0, 1, 7, d - 1):
+        assert g.hNegativeX(k) == s.hNegativeX(k)
+        assert g.hPositiveX(k) == s.hPositiveX(k)
+        assert g.hPositiveAlphaX(k) == s.hPositiveAlphaX(k)
+        assert g.hNegativeAlphaX(k) == pg.g2_mul(pg.G2_GEN, alpha * pow(s.x_inv, k + 1, R) % R)
+    assert g.hPositiveX(d) == s.hPositiveX(d) and g.hPositiveX(0) == pg.G2_GEN
+    with pytest.raises(IndexError):
+        g.hNegativeX(d)
+    blk = g.g2_points(0, -5, 11)
+    for i in (0, 4, 5, 10):
+        p_ = s.hPositiveX(i - 5) if i >= 5 else s.hNegativeX(4 - i)
+        assert blk[i].tobytes() == b"".join(v.to_bytes(48, "little") for v in (p_[0][0], p_[0][1], p_[1][0], p_[1][1]))
+
+
 def test_window_tables(sonic, orc, srs_pair):
     """the precomputed window tables (table w = 2^(c w) * basis) behind the shared-bucket MSM, read back through the
     diagnostic basis index b + 2w; and an SRS built with the tables switched off gives the same MSM"""
@@ -273,7 +292,11 @@ def test_reference_verifier_accepts_gpu_proofs(sonic, ref):
         x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
         g = sonic.SRS.new(d, x, alpha)
         proof, ro = sonic.prove(g, sonic.Assignment(*asg), sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3]), rng=pyr)
-        vsrs = pg.SRS(d, x, alpha)
+        class GpuG2(pg.SRS):             # the verifier reads its three G2 elements from the GPU-generated SRS
+            def hNegativeX(self, k): return g.hNegativeX(k)
+            def hPositiveX(self, k): return g.hPositiveX(k)
+            def hPositiveAlphaX(self, k): return g.hPositiveAlphaX(k)
+        vsrs = GpuG2(d, x, alpha)
         pr = pg.proof_from_bytes(proof.to_bytes(), Q)
         assert pg.verify(vsrs, circ, pr, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
         pr["prB"] = (pr["prB"] + 1) % R
