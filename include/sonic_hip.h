@@ -75,6 +75,10 @@ int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis
 void sonic_srs_free(sonic_srs_t* srs);
 int64_t sonic_srs_d(const sonic_srs_t* srs);        /* srsD */
 int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out);
+/* on-disk SRS (the reference has no persistence): "SONICSRS", u32 version = 1, u32 flags, i64 d, then the two G1
+ * bases as (2d+1) x 96 canonical bytes each.  Loading validates every point (on curve) like sonic_srs_from_points. */
+int sonic_srs_save(const sonic_srs_t* srs, const char* path);
+int sonic_srs_load(const char* path, sonic_srs_t** out);
 /* the G2 half (SRS.hs:35-36,40-41), generated on the GPU on first use: basis 0 = h^{x^e}, basis 1 = h^{alpha x^e},
  * e in [-d, d]; hNegativeX[k] = basis0[-(k+1)], hPositiveX[k] = basis0[k], hPositiveAlphaX[k] = basis1[k],
  * hNegativeAlphaX[k] = basis1[-(k+1)].  G2 encoding: 192 bytes x.c0 || x.c1 || y.c0 || y.c1 (48-byte

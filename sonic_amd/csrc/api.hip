@@ -277,6 +277,50 @@ int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64
   API_END
 }
 
+// ---- on-disk SRS: "SONICSRS" | u32 version | u32 flags | i64 d | basis0 (2d+1) x 96 B | basis1 (2d+1) x 96 B,
+// canonical affine encodings.  The reference has no persistence at all; this amortises SRS.new across runs.
+static const char SRS_MAGIC[8] = {'S', 'O', 'N', 'I', 'C', 'S', 'R', 'S'};
+
+int sonic_srs_save(const sonic_srs_t* srs, const char* path) {
+  API_BEGIN
+  if (!srs || !path) return SONIC_ERR_INVALID_ARG;
+  FILE* f = fopen(path, "wb");
+  if (!f) { set_error("sonic_srs_save: cannot open %s", path); return SONIC_ERR_INVALID_ARG; }
+  uint32_t ver = 1, flags = 0;
+  int64_t d = srs->d;
+  bool ok = fwrite(SRS_MAGIC, 1, 8, f) == 8 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&flags, 4, 1, f) == 1 && fwrite(&d, 8, 1, f) == 1;
+  const int64_t n = 2 * d + 1, CH = 1 << 16;
+  std::vector<uint8_t> buf(96 * (size_t)CH);
+  for (int b = 0; b < 2 && ok; b++)
+    for (int64_t i = 0; i < n && ok; i += CH) {
+      int64_t m = n - i < CH ? n - i : CH;
+      int rc = sonic_srs_get_points(srs, b, -d + i, m, buf.data());
+      if (rc) { fclose(f); return rc; }
+      ok = fwrite(buf.data(), 96, (size_t)m, f) == (size_t)m;
+    }
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { set_error("sonic_srs_save: write to %s failed", path); return SONIC_ERR_INVALID_ARG; }
+  API_END
+}
+
+int sonic_srs_load(const char* path, sonic_srs_t** out) {
+  API_BEGIN
+  if (!path || !out) return SONIC_ERR_INVALID_ARG;
+  FILE* f = fopen(path, "rb");
+  if (!f) { set_error("sonic_srs_load: cannot open %s", path); return SONIC_ERR_INVALID_ARG; }
+  char magic[8]; uint32_t ver = 0, flags = 0; int64_t d = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, SRS_MAGIC, 8) == 0 && fread(&ver, 4, 1, f) == 1 && fread(&flags, 4, 1, f) == 1 &&
+            fread(&d, 8, 1, f) == 1 && ver == 1 && d >= 1 && d < (1LL << 40);
+  if (!ok) { fclose(f); set_error("sonic_srs_load: %s is not a version-1 SRS file", path); return SONIC_ERR_BAD_ENCODING; }
+  const size_t n = (size_t)(2 * d + 1);
+  std::vector<uint8_t> b0(96 * n), b1(96 * n);
+  ok = fread(b0.data(), 96, n, f) == n && fread(b1.data(), 96, n, f) == n;
+  fclose(f);
+  if (!ok) { set_error("sonic_srs_load: %s is truncated", path); return SONIC_ERR_BAD_ENCODING; }
+  return sonic_srs_from_points(d, b0.data(), b1.data(), out);     // validates every point, rebuilds the window tables
+  API_END
+}
+
 int sonic_msm_set_window(int c) { msm_set_window_override(c); return SONIC_OK; }
 
 int sonic_msm_plan(const sonic_srs_t* srs, int64_t n, int* window_bits, int* windows, int* bucket_sets) {

@@ -36,6 +36,16 @@ class SRS:
         _lib.check(_lib.lib().sonic_srs_from_points(d, b0.ctypes.data, b1.ctypes.data, C.byref(h)))
         return cls(h, d)
 
+    def save(self, path: str) -> None:
+        """write the G1 bases to disk (format in include/sonic_hip.h)"""
+        _lib.check(_lib.lib().sonic_srs_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path: str) -> "SRS":
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sonic_srs_load(str(path).encode(), C.byref(h)))
+        return cls(h, int(_lib.lib().sonic_srs_d(h)))
+
     def points(self, basis: int, e0: int, n: int) -> np.ndarray:
         out = np.zeros((n, 96), np.uint8)
         _lib.check(_lib.lib().sonic_srs_get_points(self._h, basis, e0, n, out.ctypes.data))

@@ -62,6 +62,32 @@ def test_msm_srs_slices(sonic, orc, srs_pair, n, kind):
         assert msm_g1_srs(g, basis, e0, sc) == orc.msm_srs(o, basis, e0, sc, 1, NCPU)
 
 
+def test_srs_file_round_trip(sonic, orc, srs_pair, tmp_path):
+    """SRS on disk: save -> load gives the same points (validated on load), the same commitments; corrupt files are refused"""
+    d, x, alpha, g, o = srs_pair
+    path = tmp_path / "srs.bin"
+    g.save(path)
+    assert path.stat().st_size == 24 + 2 * (2 * d + 1) * 96
+    l = sonic.SRS.load(path)
+    assert l.srsD == d
+    for basis in (0, 1):
+        assert np.array_equal(l.points(basis, -d, 2 * d + 1), g.points(basis, -d, 2 * d + 1))
+    f = {e: (e * e + 7) % R for e in range(-300, 200) if e != 0}
+    assert sonic.commit_poly(l, d, f) == sonic.commit_poly(g, d, f)
+    with pytest.raises(sonic.SonicError):
+        l.hPositiveX(0)                              # a loaded SRS has no trapdoor, hence no G2 half
+    raw = bytearray(path.read_bytes())
+    raw[24 + 96 * 5] ^= 1                            # a point off the curve
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.SRS.load(bad)
+    assert e.value.code == 3
+    bad.write_bytes(bytes(raw[:1000]))
+    with pytest.raises(sonic.SonicError):
+        sonic.SRS.load(bad)
+
+
 def test_srs_g2_half(sonic, srs_pair):
     """the G2 vectors of SRS.new (SRS.hs:35-36,40-41) against python big-integer G2 arithmetic (oracle/pairing.py)"""
     from oracle import pairing as pg
