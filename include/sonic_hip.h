@@ -131,6 +131,15 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
 int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_proof);
 void sonic_prover_free(sonic_prover_t* p);
 
+/* ---- the verifier side of the API (host CPU; outside the accelerated path) ---- */
+/* pcV :: SRS -> Int -> G1 -> Fr -> (Fr, G1) -> Bool  (CommitmentScheme.hs:51-68); *accepted = 0 / 1 */
+int sonic_pc_v(const sonic_srs_t* srs, int64_t max, const uint8_t commitment[96], const uint8_t z[32], const uint8_t v[32],
+               const uint8_t w[96], int* accepted);
+/* verify :: SRS -> ArithCircuit Fr -> Proof -> Fr -> Fr -> [(Fr, Fr)] -> Bool  (Protocol.hs:111-130), including
+ * hscVerify (Signature.hs:74-90).  yzs = Q pairs y_j || z_j (64 bytes each), i.e. rndOracleYZs. */
+int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                 const uint8_t* cs, const uint8_t* proof, const uint8_t y[32], const uint8_t z[32], const uint8_t* yzs, int* accepted);
+
 /* ---- device memory for callers without a HIP binding ---- */
 int sonic_dev_alloc(size_t bytes, void** out);
 int sonic_dev_free(void* p);

@@ -4,8 +4,8 @@ Python host-side mirror of the reference's Haskell modules over the C ABI of
 ``sonic_amd/csrc/libsonic_hip.so`` (``include/sonic_hip.h``):
 
     Sonic.SRS               -> sonic_amd.srs          (SRS, SRS.new)
-    Sonic.CommitmentScheme  -> sonic_amd.commitment   (commit_poly, open_poly)
-    Sonic.Protocol          -> sonic_amd.protocol     (prove, Proof, RndOracle, Prover)
+    Sonic.CommitmentScheme  -> sonic_amd.commitment   (commit_poly, open_poly, pc_v)
+    Sonic.Protocol          -> sonic_amd.protocol     (prove, verify, Proof, RndOracle, Prover)
     Sonic.Signature         -> sonic_amd.protocol     (HscProof; hscProve runs inside prove)
 
 All compute happens in hand-written HIP kernels on the GPU; this package is ctypes plumbing.
@@ -14,8 +14,8 @@ There is no CPU fallback: without the built extension imports fail, without a GP
 from ._lib import SonicError, LIB_PATH  # noqa: F401
 from .encoding import R_MODULUS, Q_MODULUS, fr_to_bytes, fr_from_bytes, g1_to_bytes, g1_from_bytes  # noqa: F401
 from .srs import SRS  # noqa: F401
-from .commitment import commit_poly, open_poly, msm_g1  # noqa: F401
-from .protocol import prove, Proof, HscProof, RndOracle, Prover, ArithCircuit, Assignment, GateWeights  # noqa: F401
+from .commitment import commit_poly, open_poly, pc_v, msm_g1  # noqa: F401
+from .protocol import prove, verify, Proof, HscProof, RndOracle, Prover, ArithCircuit, Assignment, GateWeights  # noqa: F401
 
-__all__ = ["SRS", "commit_poly", "open_poly", "msm_g1", "prove", "Proof", "HscProof", "RndOracle", "Prover",
+__all__ = ["SRS", "commit_poly", "open_poly", "pc_v", "msm_g1", "prove", "verify", "Proof", "HscProof", "RndOracle", "Prover",
            "ArithCircuit", "Assignment", "GateWeights", "SonicError"]

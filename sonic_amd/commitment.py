@@ -36,6 +36,15 @@ def open_poly(srs: SRS, z: int, poly):
     return int.from_bytes(fz.raw, "little"), g1_from_bytes(out.raw)
 
 
+def pc_v(srs: SRS, maxm: int, commitment, z: int, opening) -> bool:
+    """pcV :: SRS -> Int -> G1 -> Fr -> (Fr, G1) -> Bool (CommitmentScheme.hs:51-68); host-side pairing check"""
+    from .encoding import g1_to_bytes
+    v, w = opening
+    ok = C.c_int(0)
+    _lib.check(_lib.lib().sonic_pc_v(srs._h, maxm, g1_to_bytes(commitment), fr_to_bytes(z), fr_to_bytes(v), g1_to_bytes(w), C.byref(ok)))
+    return bool(ok.value)
+
+
 def msm_g1(points: np.ndarray, scalars) -> bytes:
     """The fold inside commitPoly/openPoly on caller-supplied points: sum scalars[i] * points[i].
     points: uint8 [n, 96]; scalars: ints or uint8 [n, 32].  Returns the 96 canonical bytes."""

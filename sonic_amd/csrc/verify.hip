@@ -1,0 +1,313 @@
+// The verifier side of the reference's API, on the host CPU: pcV (src/Sonic/CommitmentScheme.hs:51-68),
+// hscVerify (src/Sonic/Signature.hs:74-90) and verify (src/Sonic/Protocol.hs:111-130).
+//
+// This is outside the accelerated hot path: (4+3Q) x 3 pairings and O(nQ) field work per
+// proof, independent of the MSM sizes, so it runs on the host with the same limb headers the kernels use.
+// The three G2 elements it needs come from the GPU-generated SRS (sonic_srs_get_g2_points).
+//
+// Pairing: only equalities of pairing products are tested (eA <> eB == eC), so any bilinear non-degenerate
+// pairing on (G1, G2) accepts exactly the same proofs as pairing-1.0.0's.  Used here: the Miller loop over
+// |x| = 0xd201000000010000 on the curve untwisted into Fq12 = Fq[w]/(w^12 - 2 w^6 + 2), one shared final
+// exponentiation (q^12 - 1)/r per check.  Plain and slow (~0.5 s per pcV) on purpose: it is a checker.
+#include <string.h>
+#include <vector>
+#include "internal.hpp"
+#include "g2.hpp"
+
+namespace sonic {
+namespace {
+
+// ---- Fq12 in the polynomial basis 1, w, ..., w^11 --------------------------------------------------
+struct F12 { Fq c[12]; };
+F12 f12_zero() { F12 r; for (auto& x : r.c) x = Fq::zero(); return r; }
+F12 f12_one() { F12 r = f12_zero(); r.c[0] = Fq::one(); return r; }
+bool f12_eq(const F12& a, const F12& b) { for (int i = 0; i < 12; i++) if (a.c[i] != b.c[i]) return false; return true; }
+F12 f12_add(const F12& a, const F12& b) { F12 r; for (int i = 0; i < 12; i++) r.c[i] = fp_add(a.c[i], b.c[i]); return r; }
+F12 f12_sub(const F12& a, const F12& b) { F12 r; for (int i = 0; i < 12; i++) r.c[i] = fp_sub(a.c[i], b.c[i]); return r; }
+F12 f12_small(const F12& a, int k) { F12 r = a; for (int j = 1; j < k; j++) r = f12_add(r, a); return r; }
+F12 f12_mul(const F12& a, const F12& b) {
+  Fq t[23];
+  for (auto& x : t) x = Fq::zero();
+  for (int i = 0; i < 12; i++) {
+    if (a.c[i].is_zero()) continue;
+    for (int j = 0; j < 12; j++) t[i + j] = fp_add(t[i + j], fp_mul(a.c[i], b.c[j]));
+  }
+  for (int k = 22; k >= 12; k--) {                 // w^12 = 2 w^6 - 2
+    Fq c2 = fp_dbl(t[k]);
+    t[k - 6] = fp_add(t[k - 6], c2);
+    t[k - 12] = fp_sub(t[k - 12], c2);
+  }
+  F12 r;
+  for (int i = 0; i < 12; i++) r.c[i] = t[i];
+  return r;
+}
+// inverse by the extended Euclidean algorithm on polynomials over Fq
+F12 f12_inv(const F12& a) {
+  auto deg = [](const std::vector<Fq>& p) { int d = (int)p.size() - 1; while (d > 0 && p[d].is_zero()) d--; return d; };
+  std::vector<Fq> lm(13, Fq::zero()), hm(13, Fq::zero()), low(13, Fq::zero()), high(13, Fq::zero());
+  lm[0] = Fq::one();
+  for (int i = 0; i < 12; i++) low[i] = a.c[i];
+  high[0] = fp_dbl(Fq::one()); high[6] = fp_neg(fp_dbl(Fq::one())); high[12] = Fq::one();
+  while (deg(low) > 0) {
+    // r = high div low
+    std::vector<Fq> rem = high, quo(13, Fq::zero());
+    const int dl = deg(low);
+    const Fq il = fp_inv(low[dl]);
+    for (int i = deg(rem) - dl; i >= 0; i--) {
+      Fq c = fp_mul(rem[dl + i], il);
+      quo[i] = c;
+      for (int j = 0; j <= dl; j++) rem[i + j] = fp_sub(rem[i + j], fp_mul(c, low[j]));
+    }
+    std::vector<Fq> nm = hm, nw = high;
+    for (int i = 0; i < 13; i++)
+      for (int j = 0; j < 13 - i; j++) {
+        nm[i + j] = fp_sub(nm[i + j], fp_mul(lm[i], quo[j]));
+        nw[i + j] = fp_sub(nw[i + j], fp_mul(low[i], quo[j]));
+      }
+    hm = lm; high = low; lm = nm; low = nw;
+  }
+  const Fq c = fp_inv(low[0]);
+  F12 r;
+  for (int i = 0; i < 12; i++) r.c[i] = fp_mul(lm[i], c);
+  return r;
+}
+// c0 + c1 u with u = w^6 - 1
+F12 f12_from_f2(const Fq2& a) { F12 r = f12_zero(); r.c[0] = fp_sub(a.c0, a.c1); r.c[6] = a.c1; return r; }
+F12 f12_from_fq(const Fq& a) { F12 r = f12_zero(); r.c[0] = a; return r; }
+
+struct E12 { F12 x, y; };
+
+F12 line(const E12& p1, const E12& p2, const E12& t) {
+  F12 m;
+  if (!f12_eq(p1.x, p2.x)) m = f12_mul(f12_sub(p2.y, p1.y), f12_inv(f12_sub(p2.x, p1.x)));
+  else if (f12_eq(p1.y, p2.y)) m = f12_mul(f12_small(f12_mul(p1.x, p1.x), 3), f12_inv(f12_small(p1.y, 2)));
+  else return f12_sub(t.x, p1.x);
+  return f12_sub(f12_mul(m, f12_sub(t.x, p1.x)), f12_sub(t.y, p1.y));
+}
+E12 e12_add(const E12& p1, const E12& p2) {
+  F12 m;
+  if (f12_eq(p1.x, p2.x) && f12_eq(p1.y, p2.y)) m = f12_mul(f12_small(f12_mul(p1.x, p1.x), 3), f12_inv(f12_small(p1.y, 2)));
+  else m = f12_mul(f12_sub(p2.y, p1.y), f12_inv(f12_sub(p2.x, p1.x)));
+  E12 r;
+  r.x = f12_sub(f12_sub(f12_mul(m, m), p1.x), p2.x);
+  r.y = f12_sub(f12_mul(m, f12_sub(p1.x, r.x)), p1.y);
+  return r;
+}
+
+F12 miller_loop(const G1Affine& p, const G2Affine& q) {
+  if (p.is_inf() || q.is_inf()) return f12_one();
+  F12 w2 = f12_zero(), w3 = f12_zero();
+  w2.c[2] = Fq::one(); w3.c[3] = Fq::one();
+  static const F12 w2i = f12_inv(w2), w3i = f12_inv(w3);
+  E12 Q, P, R;
+  Q.x = f12_mul(f12_from_f2(q.x), w2i);
+  Q.y = f12_mul(f12_from_f2(q.y), w3i);
+  P.x = f12_from_fq(p.x); P.y = f12_from_fq(p.y);
+  R = Q;
+  F12 f = f12_one();
+  const uint64_t loop = 0xd201000000010000ull;
+  for (int i = 62; i >= 0; i--) {
+    f = f12_mul(f12_mul(f, f), line(R, R, P));
+    R = e12_add(R, R);
+    if ((loop >> i) & 1) { f = f12_mul(f, line(R, Q, P)); R = e12_add(R, Q); }
+  }
+  return f;
+}
+
+// f^((q^12 - 1) / r): the exponent is computed once with schoolbook big-integer arithmetic
+const std::vector<uint32_t>& final_exponent() {
+  static std::vector<uint32_t> e;
+  if (!e.empty()) return e;
+  constexpr uint32_t q[12] = FQ_P, r[8] = FR_P;
+  std::vector<uint32_t> num(1, 1);
+  for (int k = 0; k < 12; k++) {                        // num = q^12
+    std::vector<uint32_t> t(num.size() + 12, 0);
+    for (size_t i = 0; i < num.size(); i++) {
+      uint64_t c = 0;
+      for (int j = 0; j < 12; j++) { c += (uint64_t)num[i] * q[j] + t[i + j]; t[i + j] = (uint32_t)c; c >>= 32; }
+      for (size_t j = i + 12; c; j++) { c += t[j]; t[j] = (uint32_t)c; c >>= 32; }
+    }
+    num = t;
+  }
+  num[0] -= 1;                                          // q^12 is odd, so no borrow
+  // long division by r, bit by bit (4600 x 8 limb steps)
+  std::vector<uint32_t> quo(num.size(), 0);
+  uint32_t rem[9] = {0};
+  for (long b = (long)num.size() * 32 - 1; b >= 0; b--) {
+    for (int i = 8; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
+    rem[0] = (rem[0] << 1) | ((num[b >> 5] >> (b & 31)) & 1);
+    bool ge = rem[8] != 0;
+    if (!ge) { ge = true; for (int i = 7; i >= 0; i--) { if (rem[i] != r[i]) { ge = rem[i] > r[i]; break; } } }
+    if (ge) {
+      uint64_t br = 0;
+      for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)rem[i] - r[i] - br; rem[i] = (uint32_t)d; br = (d >> 32) & 1; }
+      rem[8] -= (uint32_t)br;
+      quo[b >> 5] |= 1u << (b & 31);
+    }
+  }
+  while (quo.size() > 1 && quo.back() == 0) quo.pop_back();
+  e = quo;
+  return e;
+}
+F12 final_exp(const F12& f) {
+  const auto& e = final_exponent();
+  F12 acc = f12_one();
+  bool started = false;
+  for (long i = (long)e.size() * 32 - 1; i >= 0; i--) {
+    if (started) acc = f12_mul(acc, acc);
+    if ((e[i >> 5] >> (i & 31)) & 1) { acc = f12_mul(acc, f); started = true; }
+  }
+  return acc;
+}
+
+// ---- host-side group / field helpers -------------------------------------------------------------------
+G1XYZZ g1_mul_fr(const G1Affine& p, const Fr& k_std) {
+  G1XYZZ acc = G1XYZZ::inf();
+  const G1XYZZ base = G1XYZZ::from_affine(p);
+  bool started = false;
+  for (int i = 255; i >= 0; i--) {
+    if (started) acc = g1_dbl(acc);
+    if ((k_std.l[i >> 5] >> (i & 31)) & 1) { acc = g1_add(acc, base); started = true; }
+  }
+  return acc;
+}
+G1Affine g1_gen_host() {
+  constexpr uint32_t gx[12] = G1_GEN_X_MONT, gy[12] = G1_GEN_Y_MONT;
+  G1Affine g;
+  for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+  return g;
+}
+bool load_fr(const uint8_t* b, Fr& mont) { Fr s; memcpy(s.l, b, 32); if (!fp_is_canonical(s)) return false; mont = fp_to_mont(s); return true; }
+bool load_g1(const uint8_t* b, G1Affine& p) {
+  memcpy(p.x.l, b, 48); memcpy(p.y.l, b + 48, 48);
+  if (p.is_inf()) return true;
+  if (!fp_is_canonical(p.x) || !fp_is_canonical(p.y)) return false;
+  p.x = fp_to_mont(p.x); p.y = fp_to_mont(p.y);
+  Fq four = fp_dbl(fp_dbl(Fq::one()));
+  return fp_sqr(p.y) == fp_add(fp_mul(fp_sqr(p.x), p.x), four);
+}
+bool load_g2(const uint8_t* b, G2Affine& p) {
+  memcpy(p.x.c0.l, b, 48); memcpy(p.x.c1.l, b + 48, 48); memcpy(p.y.c0.l, b + 96, 48); memcpy(p.y.c1.l, b + 144, 48);
+  if (p.is_inf()) return true;
+  p.x.c0 = fp_to_mont(p.x.c0); p.x.c1 = fp_to_mont(p.x.c1); p.y.c0 = fp_to_mont(p.y.c0); p.y.c1 = fp_to_mont(p.y.c1);
+  return true;
+}
+Fr fr_pow(const Fr& a, uint64_t e) { return fp_pow_u64(a, e); }
+
+struct VerifierKey { G2Affine h_alpha, h_alpha_x; };   // hPositiveAlphaX[0], [1]
+
+int fetch_g2(const sonic_srs* srs, int basis, int64_t e, G2Affine& out) {
+  uint8_t b[192];
+  int rc = sonic_srs_get_g2_points(srs, basis, e, 1, b);
+  if (rc) return rc;
+  load_g2(b, out);
+  return SONIC_OK;
+}
+
+// pcV srs max F z (v, W)  (CommitmentScheme.hs:51-68)
+int pc_v(const sonic_srs* srs, const VerifierKey& vk, int64_t maxm, const G1Affine& F, const Fr& z_m, const Fr& v_m, const G1Affine& W, bool& ok) {
+  const int64_t d = srs_d(srs);
+  const int64_t difference = -d + maxm;                              // h^{x^{-d+max}}: hPositiveX / hNegativeX
+  if (difference > d || difference < -d) { set_error("pcV: hPositiveX / hNegativeX is not long enough: %ld", (long)difference); return SONIC_ERR_SRS_INDEX; }
+  G2Affine hxi;
+  int rc = fetch_g2(srs, 0, difference, hxi);
+  if (rc) return rc;
+  const Fr v = fp_from_mont(v_m), negz = fp_from_mont(fp_neg(z_m));
+  G1Affine left = g1_to_affine(g1_add(g1_mul_fr(g1_gen_host(), v), g1_mul_fr(W, negz)));   // g^v W^{-z}
+  G1Affine negF = g1_neg(F);
+  F12 f = f12_mul(f12_mul(miller_loop(W, vk.h_alpha_x), miller_loop(left, vk.h_alpha)), miller_loop(negF, hxi));
+  ok = f12_eq(final_exp(f), f12_one());                              // eA <> eB == eC
+  return SONIC_OK;
+}
+
+}  // namespace
+}  // namespace sonic
+
+using namespace sonic;
+
+extern "C" {
+
+int sonic_pc_v(const sonic_srs_t* srs, int64_t max, const uint8_t commitment[96], const uint8_t z[32], const uint8_t v[32],
+               const uint8_t w[96], int* accepted) {
+  try {
+    if (!srs || !commitment || !z || !v || !w || !accepted) return SONIC_ERR_INVALID_ARG;
+    G1Affine F, W; Fr zm, vm;
+    if (!load_g1(commitment, F) || !load_g1(w, W) || !load_fr(z, zm) || !load_fr(v, vm)) { set_error("pcV: bad encoding"); return SONIC_ERR_BAD_ENCODING; }
+    VerifierKey vk;
+    int rc = fetch_g2(srs, 1, 0, vk.h_alpha);
+    if (!rc) rc = fetch_g2(srs, 1, 1, vk.h_alpha_x);
+    if (rc) return rc;
+    bool ok = false;
+    rc = pc_v(srs, vk, max, F, zm, vm, W, ok);
+    *accepted = ok ? 1 : 0;
+    return rc;
+  } catch (const HipFail& f) { return f.code; }
+}
+
+// verify srs circuit proof y z yzs  (Protocol.hs:111-130); yzs = Q pairs (y_j, z_j), 64 bytes each
+int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                 const uint8_t* cs, const uint8_t* proof, const uint8_t y[32], const uint8_t z[32], const uint8_t* yzs, int* accepted) {
+  try {
+    if (!srs || n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !proof || !y || !z || !yzs || !accepted) return SONIC_ERR_INVALID_ARG;
+    *accepted = 0;
+    const uint8_t* p = proof;
+    auto G = [&](G1Affine& o) { bool k = load_g1(p, o); p += 96; return k; };
+    auto F = [&](Fr& o) { bool k = load_fr(p, o); p += 32; return k; };
+    G1Affine R, T, Wa, Wb, Wt, Qv, C;
+    Fr a, b, s, u, v, ym, zm;
+    bool enc = G(R) && G(T) && F(a) && G(Wa) && F(b) && G(Wb) && G(Wt) && F(s);
+    std::vector<G1Affine> Sj(Q), Wj(Q), Wpj(Q), Qj(Q);
+    std::vector<Fr> sj(Q), spj(Q), ys(Q), zs(Q);
+    for (int64_t j = 0; j < Q; j++) enc = enc && G(Sj[j]) && F(sj[j]) && G(Wj[j]);
+    for (int64_t j = 0; j < Q; j++) enc = enc && F(spj[j]) && G(Wpj[j]) && G(Qj[j]);
+    enc = enc && G(Qv) && G(C) && F(u) && F(v) && load_fr(y, ym) && load_fr(z, zm);
+    for (int64_t j = 0; j < Q; j++) enc = enc && load_fr(yzs + 64 * j, ys[j]) && load_fr(yzs + 64 * j + 32, zs[j]);
+    if (!enc) { set_error("verify: non-canonical field element or point off the curve"); return SONIC_ERR_BAD_ENCODING; }
+    // k(y) = sum_q cs[q] y^{n+q}                                  (Constraints.hs:67-68)
+    Fr ky = Fr::zero(), pw = fr_pow(ym, (uint64_t)n);
+    for (int64_t q = 0; q < Q; q++) { Fr c; if (!load_fr(cs + 32 * q, c)) return SONIC_ERR_BAD_ENCODING; pw = fp_mul(pw, ym); ky = fp_add(ky, fp_mul(c, pw)); }
+    const Fr t = fp_sub(fp_mul(a, fp_add(b, s)), ky);              // Protocol.hs:120
+    // s(u, v): sum_i u^-i U_i(v) + u^i V_i(v) + u^{i+n} W_i(v)   (Signature.hs:81; Constraints.hs:34-53)
+    if (u.is_zero() || v.is_zero()) { set_error("verify: u or v is zero"); return SONIC_ERR_INEXACT_DIVISION; }
+    std::vector<Fr> vq(Q);
+    { Fr x = fr_pow(v, (uint64_t)n); for (int64_t q = 0; q < Q; q++) { x = fp_mul(x, v); vq[q] = x; } }
+    const Fr uinv = fp_inv(u), vinv = fp_inv(v), un = fr_pow(u, (uint64_t)n);
+    Fr up = Fr::one(), um = Fr::one(), vp = Fr::one(), vm = Fr::one(), sv = Fr::zero();
+    for (int64_t i = 1; i <= n; i++) {
+      up = fp_mul(up, u); um = fp_mul(um, uinv); vp = fp_mul(vp, v); vm = fp_mul(vm, vinv);
+      Fr Ui = Fr::zero(), Vi = Fr::zero(), Wi = Fr::zero(), c;
+      for (int64_t q = 0; q < Q; q++) {
+        if (!load_fr(wL + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Ui = fp_add(Ui, fp_mul(c, vq[q]));
+        if (!load_fr(wR + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Vi = fp_add(Vi, fp_mul(c, vq[q]));
+        if (!load_fr(wO + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Wi = fp_add(Wi, fp_mul(c, vq[q]));
+      }
+      Wi = fp_sub(fp_sub(Wi, vp), vm);
+      sv = fp_add(sv, fp_add(fp_add(fp_mul(um, Ui), fp_mul(up, Vi)), fp_mul(fp_mul(up, un), Wi)));
+    }
+    VerifierKey vk;
+    int rc = fetch_g2(srs, 1, 0, vk.h_alpha);
+    if (!rc) rc = fetch_g2(srs, 1, 1, vk.h_alpha_x);
+    if (rc) return rc;
+    const int64_t d = srs_d(srs);
+    bool all = true, ok = false;
+    auto chk = [&](int64_t maxm, const G1Affine& Fc, const Fr& zz, const Fr& val, const G1Affine& W) {
+      if (rc) return;
+      rc = pc_v(srs, vk, maxm, Fc, zz, val, W, ok);
+      all = all && ok;
+    };
+    for (int64_t j = 0; j < Q; j++) {                              // hscVerify, Signature.hs:82-88
+      chk(d, Sj[j], zs[j], sj[j], Wj[j]);
+      chk(d, Sj[j], u, spj[j], Wpj[j]);
+      chk(d, C, ys[j], spj[j], Qj[j]);
+    }
+    chk(d, C, v, sv, Qv);                                          // Signature.hs:89
+    chk(n, R, zm, a, Wa);                                          // Protocol.hs:123
+    chk(n, R, fp_mul(ym, zm), b, Wb);                              // :124
+    chk(d, T, zm, t, Wt);                                          // :125
+    if (rc) return rc;
+    *accepted = all ? 1 : 0;
+    return SONIC_OK;
+  } catch (const HipFail& f) { return f.code; }
+}
+
+}  // extern "C"

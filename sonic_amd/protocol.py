@@ -166,3 +166,20 @@ def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: O
     t = [int(v) % R_MODULUS for v in transcript]
     oracle = RndOracle(t[4], t[5], list(zip(t[6:6 + Q], t[6 + Q:6 + 2 * Q])))
     return Proof.from_bytes(raw, Q), oracle
+
+
+def verify(srs: SRS, circuit: ArithCircuit, proof: Proof, y: int, z: int, yzs) -> bool:
+    """verify :: SRS -> ArithCircuit Fr -> Proof -> Fr -> Fr -> [(Fr, Fr)] -> Bool (Protocol.hs:111-130), with
+    hscVerify (Signature.hs:74-90).  Runs on the host CPU (pairings); the SRS must come from SRS.new (G2 half)."""
+    from .encoding import fr_to_bytes
+    w = circuit.weights
+    wL, wR, wO = fr_matrix(w.wL), fr_matrix(w.wR), fr_matrix(w.wO)
+    cs = fr_array(circuit.cs)
+    Q = cs.shape[0]
+    n = wL.shape[0] // Q
+    raw = proof.to_bytes()
+    flat = fr_array([v for pair in yzs for v in pair])
+    ok = C.c_int(0)
+    _lib.check(_lib.lib().sonic_verify(srs._h, n, Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data, cs.ctypes.data, raw,
+                                       fr_to_bytes(y), fr_to_bytes(z), flat.ctypes.data, C.byref(ok)))
+    return bool(ok.value)

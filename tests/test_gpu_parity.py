@@ -327,3 +327,31 @@ def test_reference_verifier_accepts_gpu_proofs(sonic, ref):
         assert pg.verify(vsrs, circ, pr, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
         pr["prB"] = (pr["prB"] + 1) % R
         assert not pg.verify(vsrs, circ, pr, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+
+
+def test_product_verifier(sonic, ref, srs_pair):
+    """verify . prove inside the product (test/Test/Protocol.hs:14-23): sonic_verify / sonic_pc_v (host pairings over the
+    GPU-generated G2 elements) accept GPU proofs, reject tampered ones, and agree with the oracle's verifier"""
+    from oracle import pairing as pg
+    pyr = random.Random(41)
+    n, Q = 3, 2
+    circ, asg = ref.rnd_circuit(pyr, n, Q)
+    d = 7 * n + 2
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    g = sonic.SRS.new(d, x, alpha)
+    circuit = sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3])
+    proof, ro = sonic.prove(g, sonic.Assignment(*asg), circuit, rng=pyr)
+    assert sonic.verify(g, circuit, proof, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    raw = bytearray(proof.to_bytes())
+    raw[2 * 96] ^= 1                                   # prA
+    bad = sonic.Proof.from_bytes(bytes(raw), Q)
+    assert not sonic.verify(g, circuit, bad, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    assert not sonic.verify(g, circuit, proof, ro.rndOracleY, (ro.rndOracleZ + 1) % R, ro.rndOracleYZs)
+    # pcV on r(X,1) with max = n (test/Test/CommitmentScheme.hs:58-71), against the oracle's pairing check
+    rX1 = ref.eval_y(1, ref.r_poly(*asg))
+    z = pyr.randrange(1, R)
+    F = sonic.commit_poly(g, n, rX1)
+    op = sonic.open_poly(g, z, rX1)
+    vs = pg.SRS(d, x, alpha)
+    assert sonic.pc_v(g, n, F, z, op) and pg.pc_v(vs, n, F, z, op)
+    assert not sonic.pc_v(g, n, F, z, ((op[0] + 1) % R, op[1])) and not sonic.pc_v(g, d, F, z, op)
