@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=11, help="n of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel HIP-event totals to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
     args = ap.parse_args()
 
@@ -64,15 +65,22 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    use_nccl = args.backend == "nccl"
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if use_nccl:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
+    coll_dev = torch.device("cuda", dev_index) if use_nccl else torch.device("cpu")
 
     import sonic_amd
     from sonic_amd import _lib
     from util import big_circuit, rand_fr_array, R
     L = _lib.lib()
-    _lib.check(L.sonic_init(local_rank))
+    _lib.check(L.sonic_init(dev_index))
 
     n, Q = 1 << args.log2n, args.Q
     d = 8 * n
@@ -120,7 +128,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.sonic_profile_enable(0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_prove = float(tmax.item())
@@ -150,7 +158,7 @@ def main():
 
     def msm_step():
         _lib.check(L.sonic_msm_g1_srs_partial_dev(srs._h, basis, e0, dsc, msm_n, part.ctypes.data))
-        parts = sd.allgather_partials(part, world, device=torch.device("cuda", local_rank))   # RCCL all-gather of 192 B
+        parts = sd.allgather_partials(part, world, device=coll_dev if use_nccl else None)       # RCCL all-gather of 192 B
         msm_result[0] = sd.sum_partials(parts, world)                                            # k-1 curve additions
 
     for _ in range(W):
@@ -164,7 +172,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.sonic_profile_enable(0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_msm = float(tmax.item())
