@@ -156,9 +156,12 @@ sonic_srs* srs_alloc(int64_t d) {
   int lg = 0;
   while ((2L << lg) <= d) lg++;                 // floor(log2 d)
   int c = lg - 1;
-  if (c < 9) c = 9;
   if (c > 20) c = 20;
-  int W = (255 + c - 1) / c;
+  // The scalars are folded below 2^254, so the top window holds only 254 - (W-1) c bits.  With shared buckets a
+  // nearly empty top window piles a quarter of all terms onto buckets 1..3; step c down until it is reasonably full.
+  while (c > 9 && 254 - ((254 + c - 1) / c - 1) * c < c - 6) c--;
+  if (c < 9) c = 9;
+  int W = (254 + c - 1) / c;
   const char* env = getenv("SONIC_MSM_TABLES");
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);

@@ -132,23 +132,22 @@ __global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, l
     // one coefficient when a weight row is all ones), and they would serialise 2^18 atomics on one
     // address: lanes that share the first active lane's key are counted with ONE atomic per wave.
     const uint32_t key = d ? (uint32_t)w * keystride + d - 1 : 0xffffffffu;
-    const unsigned long long act = __ballot(d != 0);
-    if (act) {
+    const int lane = threadIdx.x & 63;
+    bool pending = d != 0;
+    for (int round = 0; round < 4; round++) {
+      const unsigned long long act = __ballot(pending);
+      if (__popcll(act) < 8) break;
       const int first_lane = __ffsll((long long)act) - 1;
       const uint32_t k0 = __shfl(key, first_lane);
-      const bool same = d && key == k0;
+      const bool same = pending && key == k0;
       const unsigned long long m = __ballot(same);
-      const int lane = threadIdx.x & 63;
-      if (__popcll(m) >= 4) {
-        uint32_t base = 0;
-        if (lane == first_lane) base = atomicAdd(&count[k0], (uint32_t)__popcll(m));
-        base = __shfl(base, first_lane);
-        if (same) rk = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        else if (d) rk = atomicAdd(&count[key], 1u);
-      } else if (d) {
-        rk = atomicAdd(&count[key], 1u);
-      }
+      if (__popcll(m) < 4) break;
+      uint32_t base = 0;
+      if (lane == first_lane) base = atomicAdd(&count[k0], (uint32_t)__popcll(m));
+      base = __shfl(base, first_lane);
+      if (same) { rk = base + (uint32_t)__popcll(m & ((1ull << lane) - 1)); pending = false; }
     }
+    if (pending) rk = atomicAdd(&count[key], 1u);
     if (d) out = d | (sign << 31);
     if (live) {
       digits[(size_t)w * n + i] = out;

@@ -113,9 +113,14 @@ def test_window_tables(sonic, orc, srs_pair):
     import os
     from sonic_amd.commitment import msm_g1_srs
     d, x, alpha, g, o = srs_pair
-    c = 11                                       # floor(log2 d) - 1 for d = 2^12
+    import ctypes as C
+    from sonic_amd import _lib
+    pc, pw, pb = C.c_int(), C.c_int(), C.c_int()
+    _lib.check(_lib.lib().sonic_msm_plan(g._h, 5000, C.byref(pc), C.byref(pw), C.byref(pb)))
+    c, W = pc.value, pw.value
+    assert pb.value == 1 and W == -(-254 // c) and 254 - (W - 1) * c >= c - 6      # shared buckets, top window not nearly empty
     P = o.points(1, -d, 2 * d + 1)
-    for w in (1, 2, 23):
+    for w in (1, 2, W - 1):
         T = g.points(1 + 2 * w, -d, 2 * d + 1)
         for i in (0, 1, 63, 64, 65, 4095, 4096, 4097, 8192):
             assert T[i].tobytes() == orc.g1_mul(P[i].tobytes(), pow(2, c * w, R)), (w, i)
