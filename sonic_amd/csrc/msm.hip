@@ -39,7 +39,7 @@ struct HeavyItem { uint32_t bucket, seg; };
 
 static void plan_finish(MsmPlan& p, long n) {
   p.NB = 1 << (p.c - 1);
-  p.K = p.NB < 16 ? p.NB : 16;
+  p.K = p.NB < 8 ? p.NB : 8;     // 8: shortest dependent chain (16 additions + one small scalar multiplication) that still fits one wave per SIMD
   p.nseg = p.NB / p.K;
   long mean = n * (long)(p.W / p.Wb) / p.NB;
   long t = 8 * mean;
