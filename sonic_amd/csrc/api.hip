@@ -155,11 +155,14 @@ sonic_srs* srs_alloc(int64_t d) {
   const size_t n = (size_t)(2 * d + 1);
   int lg = 0;
   while ((2L << lg) <= d) lg++;                 // floor(log2 d)
-  int c = lg - 1;
-  if (c > 20) c = 20;
-  // The scalars are folded below 2^254, so the top window holds only 254 - (W-1) c bits.  With shared buckets a
-  // nearly empty top window piles a quarter of all terms onto buckets 1..3; step c down until it is reasonably full.
-  while (c > 9 && 254 - ((254 + c - 1) / c - 1) * c < c - 6) c--;
+  // measured (prove at n = d/8): up to d = 2^20 the MSMs (0.4 d .. 0.9 d terms) run best with ~2^16 bucket walks
+  // (c = 17: one to two waves per SIMD, short reduction); from d = 2^21 the two windows saved by c = 20 win.
+  int c = lg >= 21 ? 20 : (lg > 17 ? 17 : lg);
+  // The scalars are folded below 2^254, so the top window holds only t = 254 - (W-1) c bits.  With shared buckets a
+  // nearly empty top window piles a quarter of all terms onto buckets 1..3 (atomics on three addresses); step c
+  // down until it has at least 6 bits (the 2^t buckets it fills are then merely "heavy" and take the workgroup path).
+  auto top_bits = [](int cc) { return 254 - ((254 + cc - 1) / cc - 1) * cc; };
+  while (c > 9 && top_bits(c) < (c - 6 < 6 ? c - 6 : 6)) c--;
   if (c < 9) c = 9;
   int W = (254 + c - 1) / c;
   const char* env = getenv("SONIC_MSM_TABLES");
