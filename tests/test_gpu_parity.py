@@ -360,3 +360,50 @@ def test_product_verifier(sonic, ref, srs_pair):
     vs = pg.SRS(d, x, alpha)
     assert sonic.pc_v(g, n, F, z, op) and pg.pc_v(vs, n, F, z, op)
     assert not sonic.pc_v(g, n, F, z, ((op[0] + 1) % R, op[1])) and not sonic.pc_v(g, d, F, z, op)
+
+
+def test_commit_open_degenerate_inputs(sonic, orc, ref, srs_pair):
+    """empty / zero / constant / single-term polynomials through commitPoly and openPoly: the normalised sparse form
+    of the reference has no zero coefficients, so these reduce to mempty and to an empty quotient"""
+    d, x, alpha, g, o = srs_pair
+    s = ref.SRS(d, x, alpha)
+    assert sonic.commit_poly(g, d, {}) is None                          # fold over no terms = mempty
+    assert sonic.commit_poly(g, d, {3: 0, -2: 0}) is None
+    assert sonic.commit_poly(g, d, [(5, 7), (5, R - 7)]) is None         # cancels to the zero polynomial
+    fz, W = sonic.open_poly(g, 12345, {})
+    assert fz == 0 and W is None
+    fz, W = sonic.open_poly(g, 12345, {0: 99})                           # constant: f - f(z) = 0
+    assert fz == 99 and W is None
+    for f in ({1: 5}, {-1: 5}, {d: 3}, {-d: 3}, {-3: 1, 4: R - 1}):
+        for maxm in (d, d - 1):
+            try:
+                want = ref.commit_poly(s, maxm, f)
+            except IndexError:
+                with pytest.raises(sonic.SonicError) as e:
+                    sonic.commit_poly(g, maxm, f)
+                assert e.value.code == 2
+                continue
+            assert sonic.commit_poly(g, maxm, f) == want
+        z = 987654321
+        try:
+            want = ref.open_poly(s, z, f)
+        except IndexError:
+            with pytest.raises(sonic.SonicError):
+                sonic.open_poly(g, z, f)
+            continue
+        assert sonic.open_poly(g, z, f) == want
+
+
+def test_msm_zero_and_identity_scalars(sonic, orc, srs_pair):
+    from sonic_amd.commitment import msm_g1_srs
+    d, _, _, g, o = srs_pair
+    n = 3000
+    zeros = fr_bytes([0] * n)
+    assert msm_g1_srs(g, 0, -1500, zeros) == bytes(96)
+    one_hot = fr_bytes([0] * 1234 + [1] + [0] * (n - 1235))
+    assert msm_g1_srs(g, 0, -1500, one_hot) == o.points(0, -1500 + 1234, 1)[0].tobytes()
+    minus = fr_bytes([0] * 10 + [R - 1] + [0] * (n - 11))
+    got = sonic.g1_from_bytes(msm_g1_srs(g, 0, -1500, minus))
+    p = sonic.g1_from_bytes(o.points(0, -1490, 1)[0].tobytes())
+    Qm = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    assert got == (p[0], (Qm - p[1]) % Qm)
