@@ -62,7 +62,7 @@ class Evals:
         return sum(c * pow(b, self.n + q + 1, R) for q, c in enumerate(self.cs)) % R
 
 
-@pytest.mark.parametrize("log2n", [18])
+@pytest.mark.parametrize("log2n", [18, 20])      # BASELINE.json configs[2] (n = 2^18, d = 2^21) and configs[3] (n = 2^20, d = 2^23)
 def test_prove_full_size_exponent_oracle(sonic, orc, log2n):
     n, Q = 1 << log2n, 2
     d = 8 * n
