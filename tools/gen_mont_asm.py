@@ -28,6 +28,8 @@ Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB1
 R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 CARRY_GAP = 2          # instructions required between a VALU carry write and its VALU read
+MAD_LATENCY = 4        # scheduling model only: slots before a v_mad_u64_u32 result is used
+ALU_LATENCY = 1
 
 
 class Ins:
@@ -145,13 +147,18 @@ def schedule(prog):
     indeg = {k: len(prog[k].deps) for k in remaining}
     ready = {k for k in remaining if indeg[k] == 0}
     while remaining:
-        best = None
+        best, best_key = None, None
         for k in ready:
             ins = prog[k]
             if any(slot - carry_written_at.get(c, -10) <= CARRY_GAP for c in ins.carry_reads):
                 continue
-            if best is None or (ins.prio, -k) > (prog[best].prio, -best):
-                best = k
+            # latency model: prefer instructions whose producers' results have had time to land (a MAD result
+            # takes a few issue slots); among those the longest remaining critical path
+            lag = max((done_at[d] + (MAD_LATENCY if prog[d].text.startswith("v_mad_u64") else ALU_LATENCY) - slot
+                       for d in ins.deps if d in done_at), default=0)
+            key = (-(lag if lag > 0 else 0), ins.prio, -k)
+            if best is None or key > best_key:
+                best, best_key = k, key
         if best is None:
             out.append("s_nop 0")
             slot += 1
