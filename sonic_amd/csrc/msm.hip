@@ -47,6 +47,13 @@ static void plan_finish(MsmPlan& p, long n) {
   p.heavy_threshold = (uint32_t)t;
 }
 
+void msm_plan_set_segment(MsmPlan& p, int K) {
+  if (K > p.NB) K = p.NB;
+  if (K < 1) K = 1;
+  p.K = K;
+  p.nseg = p.NB / K;
+}
+
 MsmPlan msm_plan(long n) {
   MsmPlan p;
   int lg = 0;

@@ -17,6 +17,10 @@ struct MsmPlan {
 };
 MsmPlan msm_plan(long n);
 MsmPlan msm_plan_tables(long n, int c, int W, long table_stride);
+// Trade latency for work in the bucket running sums: K buckets per segment.  A standalone MSM wants the shortest
+// dependent chain (K = 8); inside prove() the reduction of one MSM hides under the accumulation of others, so fewer,
+// longer segments (fewer small scalar multiplications) cost less MAD issue overall.
+void msm_plan_set_segment(MsmPlan& p, int K);
 
 constexpr int MSM_MAX_WINDOWS = 64;
 

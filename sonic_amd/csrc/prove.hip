@@ -23,6 +23,9 @@
 namespace sonic {
 
 enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
+// buckets per running-sum segment inside prove(): measured at n = 2^18 (ms per proof): K=2 77.6, 4 63.4, 8 57.0, 16 58.1,
+// 32 61.4, 64 69.7, 128 86.0 -- the reduction's dependent chain, not its work, is what the lanes wait for
+static int PROVE_SEGMENT = getenv("SONIC_PROVE_SEGMENT") ? atoi(getenv("SONIC_PROVE_SEGMENT")) : 8;
 
 struct Scratch {
   DevBuf D, q, scan, fz_discard;
@@ -46,6 +49,7 @@ static void commit_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& w
   if (ih >= i0 && ih < i1) flag_nonzero_enqueue(st, poly + ih, 1, d_flags, FLAG_SRS_INDEX);
   const long n = i1 - i0;
   MsmPlan pl = srs_msm_plan(srs, n);
+  msm_plan_set_segment(pl, PROVE_SEGMENT);
   msm_enqueue(st, ws, pl, srs_basis(srs, 1) + (lo + i0 + shift + d), poly + i0, n, true, slot);
 }
 
@@ -74,6 +78,7 @@ static void open_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws,
   flag_nonzero_enqueue(st, q + i1, qn - i1, d_flags, FLAG_SRS_INDEX);
   const long n = i1 - i0;
   MsmPlan pl = srs_msm_plan(srs, n);
+  msm_plan_set_segment(pl, PROVE_SEGMENT);
   msm_enqueue(st, ws, pl, srs_basis(srs, 0) + (lo + i0 + d), q + i0, n, true, slot);
 }
 
