@@ -1,0 +1,73 @@
+"""Randomised parity sweep of the MSM path (the fold of CommitmentScheme.hs:26-29,45-48): random lengths, slices, bases,
+window plans and scalar patterns the protocol actually produces (zeros, +-1, long runs of one value, small values,
+values near r), every result compared byte for byte with the CPU oracle."""
+import random
+
+import numpy as np
+import pytest
+
+from util import NCPU, R, fr_bytes, rand_fr_array
+
+pytestmark = pytest.mark.gpu
+
+
+def _scalars(pyr, n):
+    kind = pyr.choice(["rand", "runs", "sparse", "small", "edge", "mixed"])
+    if kind == "rand":
+        return rand_fr_array(np.random.default_rng(pyr.randrange(1 << 30)), n)
+    if kind == "runs":                      # s(X,y): blocks of one repeated coefficient
+        vals, out = [pyr.randrange(R) for _ in range(pyr.randint(1, 4))], []
+        while len(out) < n:
+            out += [pyr.choice(vals)] * pyr.randint(1, max(1, n // 2))
+        return fr_bytes(out[:n])
+    if kind == "sparse":
+        return fr_bytes([pyr.randrange(R) if pyr.random() < 0.05 else 0 for _ in range(n)])
+    if kind == "small":
+        return fr_bytes([pyr.randrange(0, 1 << pyr.choice([1, 8, 20, 40])) for _ in range(n)])
+    if kind == "edge":
+        pool = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, (R + 1) // 2, 1 << 253, (1 << 254) - 1, 1 << 64]
+        return fr_bytes([pyr.choice(pool) for _ in range(n)])
+    a = rand_fr_array(np.random.default_rng(pyr.randrange(1 << 30)), n)
+    a[:: pyr.randint(2, 7)] = 0
+    a[1:: pyr.randint(2, 9)] = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
+    return a
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_msm_fuzz(sonic, orc, seed):
+    from sonic_amd import _lib
+    from sonic_amd.commitment import msm_g1_srs
+    pyr = random.Random(1000 + seed)
+    d = pyr.choice([300, 1 << 10, 5000, 1 << 13])
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    g, o = sonic.SRS.new(d, x, alpha), orc.SRS(d, x, alpha, threads=NCPU)
+    try:
+        for _ in range(12):
+            n = pyr.choice([pyr.randint(0, 70), pyr.randint(71, 2 * d), 2 * d + 1, pyr.randint(1, 2 * d + 1)])
+            e0 = pyr.randint(-d, d - n + 1) if n else 0
+            basis = pyr.randint(0, 1)
+            _lib.lib().sonic_msm_set_window(pyr.choice([0, 0, 0, 4, 5, 9, 13, 16]))
+            sc = _scalars(pyr, n)
+            assert msm_g1_srs(g, basis, e0, sc) == orc.msm_srs(o, basis, e0, sc, 1, NCPU), (seed, d, n, e0, basis)
+    finally:
+        _lib.lib().sonic_msm_set_window(0)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_prove_fuzz(sonic, orc, ref, seed):
+    """random (n, Q, d) in the range of the reference's own generator (rndCircuit: n <= 20, Q <= n; randomD) and beyond"""
+    from util import circuit_arrays
+    pyr = random.Random(2000 + seed)
+    for _ in range(4):
+        n = pyr.choice([pyr.randint(1, 20), pyr.randint(21, 300)])
+        Q = pyr.randint(1, min(n, 6))
+        d = {1: 12, 2: 16}.get(n, 7 * n) + pyr.randint(0, 3 * n)
+        x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+        g, o = sonic.SRS.new(d, x, alpha), orc.SRS(d, x, alpha, threads=NCPU)
+        circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+        tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+        want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+        p = sonic.Prover(g, sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3]))
+        p.set_assignment(sonic.Assignment(*asg))
+        assert p.prove_bytes(tr) == want, (seed, n, Q, d)
+        assert p.prove_bytes(tr) == want          # deterministic on repeat
