@@ -86,14 +86,15 @@ MsmPlan msm_plan_tables(long n, int c, int W, long table_stride) {
 void MsmWorkspace::reserve(long n, const MsmPlan& pl) {
   size_t M = (size_t)pl.Wb * pl.NB;
   size_t NW = (size_t)n * pl.W;
-  count.ensure((M + 1) * 4);
+  const size_t part_hn = (size_t)ceil_div((long)M, 1L << 10) * (size_t)ceil_div(n, 1024);   // partitions x pass-1 workgroups
+  count.ensure((2 * part_hn + 4) * 4);
   off.ensure((M + 1) * 4);
   digits.ensure(NW * 4);
   rank.ensure(NW * 4);
   entries.ensure(NW * 4);
   buckets.ensure(M * sizeof(G1XYZZ));
   segres.ensure(((size_t)pl.Wb * pl.nseg + pl.nseg / 256 + 2) * sizeof(G1XYZZ));
-  scan_tmp.ensure((M / 2048 + 2) * 4);
+  scan_tmp.ensure(((M > part_hn ? M : part_hn) / 2048 + 4) * 4);
   order.ensure((M + 1) * 4);
   size_hist.ensure((256 * (M / 2048 + 1) + 1) * 4 * 2);
   size_t max_heavy = NW / pl.heavy_threshold + 1;
@@ -114,65 +115,159 @@ __device__ __forceinline__ bool fr_gt_half(const Fr& s) {
   return false;
 }
 
-__global__ __launch_bounds__(256) void k_msm_digits(const Fr* __restrict__ sc, long n, int c, int W, int keystride, int mont,
-                                                    uint32_t* __restrict__ count, uint32_t* __restrict__ digits,
-                                                    uint32_t* __restrict__ rank) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  Fr s = live ? sc[i] : Fr::zero();
-  if (mont) s = fp_from_mont(s);
-  const bool neg = fr_gt_half(s);
-  if (neg) s = fp_neg(s);            // r - s, still standard form
-  const uint32_t mask = (1u << c) - 1;
-  const uint32_t half = 1u << (c - 1);
-  uint32_t carry = 0;
-  for (int w = 0; w < W; w++) {
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sh, uint32_t* total);
+
+// ---- digits + two-pass partition sort ---------------------------------------------------------
+// Every (scalar, window) pair becomes an entry (point index | window | sign) that must end up grouped by its
+// bucket key.  A global histogram with returning atomics plus a random scatter moved ~2 GB per 2^20-term MSM and
+// was bound by L2 atomic throughput.  Instead: pass 1 splits the keys by their high bits into <= 1024 partitions
+// with per-workgroup LDS histograms (k_part_hist, scan, k_part_scatter); pass 2 gives one workgroup per partition
+// (1024 consecutive buckets), which counts the low bits in LDS, scans them into the bucket offsets and places the
+// entries (k_part_sort).  Order inside a bucket is irrelevant (the sum is commutative), so nothing needs to be stable.
+constexpr int PART_LOW_BITS = 10;
+constexpr int PART_TILE = 1024;            // scalars per workgroup in pass 1
+
+struct DigitStream {
+  Fr s;
+  bool neg;
+  uint32_t carry;
+  __device__ __forceinline__ void init(const Fr* __restrict__ sc, long i, bool live, int mont) {
+    s = live ? sc[i] : Fr::zero();
+    if (mont) s = fp_from_mont(s);
+    neg = fr_gt_half(s);
+    if (neg) s = fp_neg(s);          // r - s, still standard form
+    carry = 0;
+  }
+  // next signed base-2^c digit: magnitude (0 = skip) and sign
+  __device__ __forceinline__ uint32_t next(int c, uint32_t& sign) {
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     uint32_t d = (s.l[0] & mask) + carry;
-    // shift the scalar right by c bits (static limb indices keep it in registers)
 #pragma unroll
-    for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));
+    for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));   // static limb indices stay in registers
     s.l[7] >>= c;
-    uint32_t sign = neg ? 1u : 0u;
+    sign = neg ? 1u : 0u;
     if (d > half) { d = (1u << c) - d; carry = 1; sign ^= 1u; } else carry = 0;
-    uint32_t out = 0, rk = 0;
-    // Histogram + rank.  Runs of equal scalars are the norm in this protocol (s(X,y) carries n copies of
-    // one coefficient when a weight row is all ones), and they would serialise 2^18 atomics on one
-    // address: lanes that share the first active lane's key are counted with ONE atomic per wave.
-    const uint32_t key = d ? (uint32_t)w * keystride + d - 1 : 0xffffffffu;
-    const int lane = threadIdx.x & 63;
-    bool pending = d != 0;
-    for (int round = 0; round < 4; round++) {
-      const unsigned long long act = __ballot(pending);
-      if (__popcll(act) < 8) break;
-      const int first_lane = __ffsll((long long)act) - 1;
-      const uint32_t k0 = __shfl(key, first_lane);
-      const bool same = pending && key == k0;
-      const unsigned long long m = __ballot(same);
-      if (__popcll(m) < 4) break;
-      uint32_t base = 0;
-      if (lane == first_lane) base = atomicAdd(&count[k0], (uint32_t)__popcll(m));
-      base = __shfl(base, first_lane);
-      if (same) { rk = base + (uint32_t)__popcll(m & ((1ull << lane) - 1)); pending = false; }
+    return d;
+  }
+};
+
+// LDS counter increment that returns the old value, with the lanes that share a key served by ONE LDS atomic: runs of
+// equal scalars are the norm in this protocol (s(X,y) carries n copies of one coefficient when a weight row is all
+// ones, test/Test/Reference.hs:143-145) and would otherwise serialise a whole wave on one LDS word.
+__device__ __forceinline__ uint32_t lds_take(uint32_t* cnt, bool valid, uint32_t idx) {
+  const int lane = threadIdx.x & 63;
+  uint32_t r = 0;
+  bool pending = valid;
+  for (int round = 0; round < 2; round++) {
+    const unsigned long long act = __ballot(pending);
+    if (__popcll(act) < 16) break;
+    const int first_lane = __ffsll((long long)act) - 1;
+    const uint32_t k0 = __shfl(idx, first_lane);
+    const bool same = pending && idx == k0;
+    const unsigned long long m = __ballot(same);
+    if (__popcll(m) < 8) break;
+    uint32_t base = 0;
+    if (lane == first_lane) base = atomicAdd(&cnt[k0], (uint32_t)__popcll(m));
+    base = __shfl(base, first_lane);
+    if (same) { r = base + (uint32_t)__popcll(m & ((1ull << lane) - 1)); pending = false; }
+  }
+  if (pending) r = atomicAdd(&cnt[idx], 1u);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_part_hist(const Fr* __restrict__ sc, long n, int c, int W, int keystride, int mont, int P,
+                                                   uint32_t nblk, uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t h[];
+  for (int t = threadIdx.x; t < P; t += 256) h[t] = 0;
+  __syncthreads();
+  for (int k = 0; k < PART_TILE / 256; k++) {
+    const long i = (long)blockIdx.x * PART_TILE + k * 256 + threadIdx.x;
+    DigitStream ds;
+    ds.init(sc, i, i < n, mont);
+    for (int w = 0; w < W; w++) {
+      uint32_t sign;
+      const uint32_t d = ds.next(c, sign);
+      const uint32_t key = (uint32_t)w * keystride + d - 1;
+      lds_take(h, d != 0, key >> PART_LOW_BITS);
     }
-    if (pending) rk = atomicAdd(&count[key], 1u);
-    if (d) out = d | (sign << 31);
-    if (live) {
-      digits[(size_t)w * n + i] = out;
-      rank[(size_t)w * n + i] = rk;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < P; t += 256) hist[(size_t)t * nblk + blockIdx.x] = h[t];
+}
+
+__global__ __launch_bounds__(256) void k_part_scatter(const Fr* __restrict__ sc, long n, int c, int W, int keystride, int mont, int P,
+                                                      uint32_t nblk, const uint32_t* __restrict__ base, uint16_t* __restrict__ part_lo,
+                                                      uint32_t* __restrict__ part_pay) {
+  extern __shared__ uint32_t cur[];
+  for (int t = threadIdx.x; t < P; t += 256) cur[t] = base[(size_t)t * nblk + blockIdx.x];
+  __syncthreads();
+  for (int k = 0; k < PART_TILE / 256; k++) {
+    const long i = (long)blockIdx.x * PART_TILE + k * 256 + threadIdx.x;
+    DigitStream ds;
+    ds.init(sc, i, i < n, mont);
+    for (int w = 0; w < W; w++) {
+      uint32_t sign;
+      const uint32_t d = ds.next(c, sign);
+      const uint32_t key = (uint32_t)w * keystride + d - 1;
+      const uint32_t pos = lds_take(cur, d != 0, key >> PART_LOW_BITS);
+      if (d) {
+        part_lo[pos] = (uint16_t)(key & ((1u << PART_LOW_BITS) - 1));
+        part_pay[pos] = (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (sign << 31);   // index | window (tables only) | sign
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_msm_scatter(long n, int W, int keystride, const uint32_t* __restrict__ digits,
-                                                     const uint32_t* __restrict__ rank, const uint32_t* __restrict__ off,
-                                                     uint32_t* __restrict__ entries) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for (int w = 0; w < W; w++) {
-    uint32_t dg = digits[(size_t)w * n + i];
-    if (!dg) continue;
-    uint32_t key = (uint32_t)w * keystride + (dg & 0x7fffffffu) - 1;
-    entries[off[key] + rank[(size_t)w * n + i]] = (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (dg & 0x80000000u);   // index | window (tables only) | sign
+// one workgroup per partition p = keys [p * 1024, (p+1) * 1024): bucket offsets and final placement
+__global__ __launch_bounds__(256) void k_part_sort(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_pay,
+                                                   const uint32_t* __restrict__ base, const uint32_t* __restrict__ total, uint32_t nblk, int P,
+                                                   uint32_t M, uint32_t* __restrict__ off, uint32_t* __restrict__ entries) {
+  __shared__ uint32_t cnt[1 << PART_LOW_BITS];
+  __shared__ uint32_t sc4[256];
+  const int p = blockIdx.x;
+  const uint32_t beg = base[(size_t)p * nblk];
+  const uint32_t end = p + 1 < P ? base[(size_t)(p + 1) * nblk] : *total;
+  for (int t = threadIdx.x; t < (1 << PART_LOW_BITS); t += 256) cnt[t] = 0;
+  __syncthreads();
+  // every lane of a wave must reach lds_take: round the trip count up to the wave
+  const uint32_t span = end - beg, trips = (span + 255) / 256;
+  constexpr int B = 8;                       // loads in flight per lane (the walk is latency-bound otherwise)
+  for (uint32_t k0 = 0; k0 < trips; k0 += B) {
+    uint32_t lo[B];
+#pragma unroll
+    for (int j = 0; j < B; j++) { const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x; lo[j] = e < end ? part_lo[e] : 0xffffffffu; }
+#pragma unroll
+    for (int j = 0; j < B; j++) if (k0 + j < trips) lds_take(cnt, lo[j] != 0xffffffffu, lo[j] & 1023u);
+  }
+  __syncthreads();
+  // exclusive scan of the 1024 counters: 4 per thread + a 256-wide scan
+  uint32_t v[4], ssum = 0;
+  for (int k = 0; k < 4; k++) { v[k] = cnt[threadIdx.x * 4 + k]; ssum += v[k]; }
+  uint32_t ex = block_exclusive_scan_256(ssum, sc4, nullptr);
+  for (int k = 0; k < 4; k++) {
+    const uint32_t key = (uint32_t)p * (1u << PART_LOW_BITS) + threadIdx.x * 4 + k;
+    cnt[threadIdx.x * 4 + k] = ex;                 // becomes the running cursor
+    if (key < M) off[key] = beg + ex;
+    ex += v[k];
+  }
+  if (p == P - 1 && threadIdx.x == 0) off[M] = *total;
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < trips; k0 += B) {
+    uint32_t lo[B], pay[B];
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x;
+      const bool live = e < end;
+      lo[j] = live ? part_lo[e] : 0xffffffffu;
+      pay[j] = live ? part_pay[e] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      if (k0 + j >= trips) continue;
+      const bool live = lo[j] != 0xffffffffu;
+      const uint32_t pos = lds_take(cnt, live, lo[j] & 1023u);
+      if (live) entries[beg + pos] = pay[j];
+    }
   }
 }
 
@@ -438,24 +533,27 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
   ws.reserve(n > 0 ? n : 1, pl);
   const size_t M = (size_t)pl.Wb * pl.NB;
   const int keystride = pl.Wb == 1 ? 0 : pl.NB;
-  uint32_t* count = ws.count.as<uint32_t>();
   uint32_t* off = ws.off.as<uint32_t>();
   HeavyMeta* hm = ws.heavy_meta.as<HeavyMeta>();
   HeavyRec* hrecs = reinterpret_cast<HeavyRec*>(hm + 1);
-  HIP_OK(hipMemsetAsync(count, 0, (M + 1) * 4, st));
   HIP_OK(hipMemsetAsync(hm, 0, sizeof(HeavyMeta), st));
-  if (n > 0) {
-    LAUNCH(k_msm_digits, ceil_div(n, 256), 256, 0, st, d_scalars, n, pl.c, pl.W, keystride, (int)scalars_mont, count,
-           ws.digits.as<uint32_t>(), ws.rank.as<uint32_t>());
-  }
-  const int ntiles = ceil_div((long)M + 1, 2048);
   uint32_t* tiles = ws.scan_tmp.as<uint32_t>();
-  LAUNCH(k_scan_tile_sums, ntiles, 256, 0, st, (const uint32_t*)count, M + 1, tiles);
-  LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ntiles, tiles + ntiles);
-  LAUNCH(k_scan_apply, ntiles, 256, 0, st, (const uint32_t*)count, M + 1, (const uint32_t*)tiles, off);
-  if (n > 0) {
-    LAUNCH(k_msm_scatter, ceil_div(n, 256), 256, 0, st, n, pl.W, keystride, (const uint32_t*)ws.digits.as<uint32_t>(),
-           (const uint32_t*)ws.rank.as<uint32_t>(), (const uint32_t*)off, ws.entries.as<uint32_t>());
+  {
+    const int P = ceil_div((long)M, 1L << PART_LOW_BITS);
+    const uint32_t pblk = (uint32_t)ceil_div(n > 0 ? n : 1, PART_TILE);
+    const size_t hn = (size_t)P * pblk;
+    uint32_t* hist = ws.count.as<uint32_t>();
+    uint32_t* hbase = hist + hn + 1;
+    const int ht = ceil_div((long)hn + 1, 2048);
+    uint32_t* total = tiles + ht;
+    LAUNCH(k_part_hist, pblk, 256, P * 4, st, d_scalars, n, pl.c, pl.W, keystride, (int)scalars_mont, P, pblk, hist);
+    LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
+    LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
+    LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
+    LAUNCH(k_part_scatter, pblk, 256, P * 4, st, d_scalars, n, pl.c, pl.W, keystride, (int)scalars_mont, P, pblk, (const uint32_t*)hbase,
+           ws.digits.as<uint16_t>(), ws.rank.as<uint32_t>());
+    LAUNCH(k_part_sort, P, 256, 0, st, (const uint16_t*)ws.digits.as<uint16_t>(), (const uint32_t*)ws.rank.as<uint32_t>(), (const uint32_t*)hbase,
+           (const uint32_t*)total, pblk, P, (uint32_t)M, off, ws.entries.as<uint32_t>());
   }
   {
     const uint32_t nblk = (uint32_t)ceil_div((long)M, 2048);
