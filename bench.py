@@ -84,7 +84,7 @@ def main():
 
     n, Q = 1 << args.log2n, args.Q
     d = 8 * n
-    msm_n = 1 << args.msm_log2
+    msm_n = min(1 << args.msm_log2, 2 * d)          # the standalone MSM reads its points from this SRS (2d+1 per basis)
     K, W = args.steps, args.warmup
 
     def barrier():

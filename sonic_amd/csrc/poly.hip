@@ -161,6 +161,30 @@ void s_of_y_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, co
   LAUNCH(k_s_of_y, ceil_div(n + 1, 256), 256, 0, st, wL, wR, wO, ypow, n, Q, s);
 }
 
+// s(X,Y) = sum_q Y^{n+q} P_q(X) + sum_i (-Y^i - Y^{-i}) X^{i+n}  with  P_q(X) = sum_i wL[q][i] X^{-i} + wR[q][i] X^i + wO[q][i] X^{i+n}
+// (Constraints.hs:34-53, regrouped by constraint).  P_q depends on the circuit only, so Commit(P_q) is computed once per
+// prover handle and Commit(s(X,y)) = sum_q y^{n+q} Commit(P_q) + Commit(diagonal part): an n-term MSM instead of a 3n-term one.
+__global__ __launch_bounds__(256) void k_weight_row_poly(const Fr* __restrict__ wL, const Fr* __restrict__ wR, const Fr* __restrict__ wO,
+                                                         long n, long q, Fr* __restrict__ s) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x + 1;   // 1..n
+  if (i > n) { if (i == n + 1) s[n] = Fr::zero(); return; }
+  s[n - i] = wL[q * n + i - 1];
+  s[n + i] = wR[q * n + i - 1];
+  s[2 * n + i] = wO[q * n + i - 1];
+}
+void weight_row_poly_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, long n, long q, Fr* s) {
+  LAUNCH(k_weight_row_poly, ceil_div(n + 1, 256), 256, 0, st, wL, wR, wO, n, q, s);
+}
+// diag[i-1] = -(y^i + y^-i), i = 1..n (coefficients of X^{n+1..2n});  yq[q] = y^{n+1+q}
+__global__ __launch_bounds__(256) void k_s_diag_part(const Fr* __restrict__ ypow, long n, long Q, Fr* __restrict__ diag, Fr* __restrict__ yq) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) diag[t] = fp_neg(fp_add(ypow[n + t + 1], ypow[n - t - 1]));
+  if (t < Q) yq[t] = ypow[2 * n + 1 + t];
+}
+void s_diag_part_enqueue(hipStream_t st, const Fr* ypow, long n, long Q, Fr* diag, Fr* yq) {
+  LAUNCH(k_s_diag_part, ceil_div(n > Q ? n : Q, 256), 256, 0, st, ypow, n, Q, diag, yq);
+}
+
 // s(u,Y) over [-n, n+Q] given upow[e + n] = u^e for e in [-n, 2n]:
 //   Y^{+-i}: -u^{i+n};  Y^{n+q}: sum_i u^-i wL[q][i] + u^i wR[q][i] + u^{i+n} wO[q][i]   (Utils.hs:17-18)
 __global__ __launch_bounds__(256) void k_s_of_u_diag(const Fr* __restrict__ upow, long n, Fr* __restrict__ s) {

@@ -7,6 +7,8 @@ namespace sonic {
 
 void build_r1_enqueue(hipStream_t st, const Fr* aL, const Fr* aR, const Fr* aO, const Fr* cns, long n, Fr* r1);
 void s_of_y_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* ypow, long n, long Q, Fr* s);
+void weight_row_poly_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, long n, long q, Fr* s);
+void s_diag_part_enqueue(hipStream_t st, const Fr* ypow, long n, long Q, Fr* diag, Fr* yq);
 void s_of_u_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* upow, long n, long Q, Fr* s, DevBuf& tmp);
 void add_into_enqueue(hipStream_t st, Fr* dst, const Fr* src, long n);
 void sub_k_of_y_enqueue(hipStream_t st, Fr* slot, const Fr* cs, const Fr* ypow_nq, long Q, int* flags, int flag_bit);

@@ -118,6 +118,10 @@ struct sonic_prover {
   NttTables ntt;
   DevBuf S, IN, PAIRS, r1, sy0, su, pw, fa, fb, slots, frout, flags, tmp;
   std::vector<DevBuf> syj;
+  // sonic_prover_prepare: Commit(P_q) per constraint row (affine, Montgomery) and per-j scalar buffers
+  bool prepared = false;
+  DevBuf cq;
+  std::vector<DevBuf> diag, yq;
   hipEvent_t ev_r1 = nullptr, ev_sy0 = nullptr, ev_t = nullptr, ev_su = nullptr;
   std::vector<hipEvent_t> ev_syj;
   int log2m = 0;
@@ -326,8 +330,15 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
     Fr* syj = p->syj[j].as<Fr>();
     poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
     s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, syj);                                   // s(X, y_j)
+    if (p->prepared) s_diag_part_enqueue(ms, pw, n, Q, p->diag[j].as<Fr>(), p->yq[j].as<Fr>());
     ready(p->ev_syj[j]);
-    commit(p->ev_syj[j], syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j           :42
+    if (p->prepared) {                                                               // S_j           :42
+      Lane& l = p->pick(p->ev_syj[j]);
+      commit_enqueue(l.st, srs, l.ws, p->diag[j].as<Fr>(), n + 1, n, d, &slots[5 + 2 * j], flags);
+      msm_enqueue(l.st, l.ws, msm_plan(Q), p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
+    } else {
+      commit(p->ev_syj[j], syj, s_lo, s_len, d, 5 + 2 * j);
+    }
     open(p->ev_syj[j], syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);          // (s_j, W_j)    :43
     open(p->ev_syj[j], syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);            // W'_j          :54
   }
@@ -342,10 +353,11 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   fr_from_mont_enqueue(ms, frout, 3 + 2 * Q);
 
   const int K = (int)(7 + 4 * Q);
-  std::vector<MsmSlot> hs(K);
+  const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
+  std::vector<MsmSlot> hs(KS);
   std::vector<uint8_t> hfr(32 * (3 + 2 * Q));
   int hflags = 0;
-  HIP_OK(hipMemcpyAsync(hs.data(), slots, sizeof(MsmSlot) * K, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(hs.data(), slots, sizeof(MsmSlot) * KS, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(hfr.data(), frout, hfr.size(), hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
@@ -358,7 +370,14 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
     std::vector<std::thread> th;
     const int nt = K < 16 ? K : 16;
     for (int w = 0; w < nt; w++)
-      th.emplace_back([&, w] { for (int i = w; i < K; i += nt) g1_canonical_bytes_host(msm_finish_host(hs[i]), &pts[96 * (size_t)i]); });
+      th.emplace_back([&, w] {
+        for (int i = w; i < K; i += nt) {
+          G1XYZZ s = msm_finish_host(hs[i]);
+          const int j = (i - 5) / 2;
+          if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) s = g1_add(s, msm_finish_host(hs[K + j]));
+          g1_canonical_bytes_host(s, &pts[96 * (size_t)i]);
+        }
+      });
     for (auto& x : th) x.join();
     if (timing) fprintf(stderr, "[sonic] host tails of %d MSMs: %.3f ms\n", K, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
@@ -372,6 +391,52 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   for (long j = 0; j < Q; j++) { putF(F(3 + Q + j)); putG(5 + 2 * Q + 2 * j); putG(6 + 2 * Q + 2 * j); }   // hscW
   putG(5 + 4 * Q); putG(6 + 4 * Q);                                                      // Qv, C
   putF(transcript + 32 * (6 + 2 * Q)); putF(transcript + 32 * (7 + 2 * Q));              // u, v
+  API_END
+}
+
+// Circuit-only precomputation for handles that prove more than once: C_q = Commit(d, P_q), P_q the q-th constraint's
+// weight polynomial.  Afterwards S_j = Commit(d, s(X, y_j)) (Signature.hs:42) is assembled as
+// sum_q y_j^{n+q} C_q + Commit(d, diagonal part): the same group element from an n-term MSM instead of a 3n-term one.
+int sonic_prover_prepare(sonic_prover_t* p) {
+  API_BEGIN
+  if (!p) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  if (p->prepared) return SONIC_OK;
+  const long n = p->n, Q = p->Q, d = srs_d(p->srs);
+  int* flags = p->flags.as<int>();
+  HIP_OK(hipMemsetAsync(flags, 0, 4, p->st));
+  HIP_OK(hipStreamSynchronize(p->st));
+  DevBuf slots(sizeof(MsmSlot) * Q);
+  std::vector<DevBuf> rows(std::min<long>(Q, N_LANES));
+  for (auto& b : rows) b.alloc(sizeof(Fr) * (3 * n + 1));
+  for (long q = 0; q < Q; q++) {
+    Lane& l = p->lanes[q % N_LANES];
+    Fr* row = rows[q % N_LANES].as<Fr>();
+    weight_row_poly_enqueue(l.st, p->wL.as<Fr>(), p->wR.as<Fr>(), p->wO.as<Fr>(), n, q, row);
+    commit_enqueue(l.st, p->srs, l.ws, row, -n, 3 * n + 1, d, slots.as<MsmSlot>() + q, flags);
+  }
+  for (auto& l : p->lanes) HIP_OK(hipStreamSynchronize(l.st));
+  std::vector<MsmSlot> hs(Q);
+  HIP_OK(hipMemcpy(hs.data(), slots.p, sizeof(MsmSlot) * Q, hipMemcpyDeviceToHost));
+  int hflags = 0;
+  HIP_OK(hipMemcpy(&hflags, flags, 4, hipMemcpyDeviceToHost));
+  if (hflags) return flags_to_status(hflags, "sonic_prover_prepare");
+  std::vector<G1Affine> cq(Q);
+  {
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<long>(Q, 16);
+    for (int w = 0; w < nt; w++)
+      th.emplace_back([&, w] { for (long q = w; q < Q; q += nt) cq[q] = g1_to_affine(msm_finish_host(hs[q])); });
+    for (auto& x : th) x.join();
+  }
+  p->cq.alloc(sizeof(G1Affine) * Q);
+  HIP_OK(hipMemcpy(p->cq.p, cq.data(), sizeof(G1Affine) * Q, hipMemcpyHostToDevice));
+  p->diag.resize(Q); p->yq.resize(Q);
+  for (auto& b : p->diag) b.alloc(sizeof(Fr) * n);
+  for (auto& b : p->yq) b.alloc(sizeof(Fr) * Q);
+  p->slots.ensure(sizeof(MsmSlot) * (7 + 5 * Q));
+  for (auto& l : p->lanes) l.ws.reserve(Q, msm_plan(Q));
+  p->prepared = true;
   API_END
 }
 

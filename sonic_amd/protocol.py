@@ -110,7 +110,7 @@ def draw_transcript(Q: int, rng=None) -> List[int]:
 class Prover:
     """Circuit (and assignment) resident in HBM across proofs: sonic_prover_* of the C ABI."""
 
-    def __init__(self, srs: SRS, circuit: ArithCircuit):
+    def __init__(self, srs: SRS, circuit: ArithCircuit, prepare: bool = True):
         w = circuit.weights
         wL, wR, wO = fr_matrix(w.wL), fr_matrix(w.wR), fr_matrix(w.wO)
         cs = fr_array(circuit.cs)
@@ -123,6 +123,8 @@ class Prover:
         self._h = C.c_void_p()
         _lib.check(_lib.lib().sonic_prover_new(srs._h, self.n, self.Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data,
                                                cs.ctypes.data, C.byref(self._h)))
+        if prepare:     # a handle exists to prove repeatedly: commit the constraint rows once (sonic_prover_prepare)
+            _lib.check(_lib.lib().sonic_prover_prepare(self._h))
 
     def set_assignment(self, assignment: Assignment):
         aL, aR, aO = fr_array(assignment.aL), fr_array(assignment.aR), fr_array(assignment.aO)

@@ -312,6 +312,35 @@ def test_prover_handle_reuse(sonic, orc, ref, srs_pair):
         assert p.prove_bytes(tr) == want
 
 
+def test_prepared_handle_same_bytes(sonic, orc, ref, srs_pair):
+    """sonic_prover_prepare (S_j assembled from the per-constraint commitments) must not change a single byte:
+    rndCircuit weights, dense random weights, and a constraint row that is all zero (its commitment is O)"""
+    d, x, alpha, g, o = srs_pair
+    pyr = random.Random(81)
+    for n, Q, kind in ((33, 2, "rnd"), (40, 3, "dense"), (17, 3, "zero-row"), (1, 1, "rnd")):
+        circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+        if kind != "rnd":
+            wL = [[pyr.randrange(R) for _ in range(n)] for _ in range(Q)]
+            wR = [[pyr.randrange(R) for _ in range(n)] for _ in range(Q)]
+            wO = [[pyr.randrange(R) for _ in range(n)] for _ in range(Q)]
+            if kind == "zero-row":
+                wL[1] = [0] * n; wR[1] = [0] * n; wO[1] = [0] * n
+            aL, aR, aO = asg
+            cs = [(sum(a * b for a, b in zip(wL[q], aL)) + sum(a * b for a, b in zip(wR[q], aR)) +
+                   sum(a * b for a, b in zip(wO[q], aO))) % R for q in range(Q)]
+            circ = (wL, wR, wO, cs)
+            enc = dict(enc, wL=fr_bytes([v for row in wL for v in row]), wR=fr_bytes([v for row in wR for v in row]),
+                       wO=fr_bytes([v for row in wO for v in row]), cs=fr_bytes(cs))
+        ac = sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3])
+        plain, prep = sonic.Prover(g, ac, prepare=False), sonic.Prover(g, ac, prepare=True)
+        plain.set_assignment(sonic.Assignment(*asg)); prep.set_assignment(sonic.Assignment(*asg))
+        for _ in range(2):
+            tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+            want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+            assert plain.prove_bytes(tr) == want, (n, Q, kind)
+            assert prep.prove_bytes(tr) == want, (n, Q, kind)
+
+
 def test_reference_verifier_accepts_gpu_proofs(sonic, ref):
     """the reference's only end-to-end test, verify . prove (test/Test/Protocol.hs:14-23), with the proof made by
     the HIP path and the verifier restated with real pairings (oracle/pairing.py: pcV, hscVerify, verify)"""
