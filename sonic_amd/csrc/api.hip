@@ -158,6 +158,7 @@ sonic_srs* srs_alloc(int64_t d) {
   // measured (prove at n = d/8): up to d = 2^20 the MSMs (0.4 d .. 0.9 d terms) run best with ~2^16 bucket walks
   // (c = 17: one to two waves per SIMD, short reduction); from d = 2^21 the two windows saved by c = 20 win.
   int c = lg >= 21 ? 20 : (lg > 17 ? 17 : lg);
+  if (const char* tc = getenv("SONIC_MSM_TABLE_C")) { int v = atoi(tc); if (v >= 9 && v <= 22) c = v; }   // tuning knob
   // The scalars are folded below 2^254, so the top window holds only t = 254 - (W-1) c bits.  With shared buckets a
   // nearly empty top window piles a quarter of all terms onto buckets 1..3 (atomics on three addresses); step c
   // down until it has at least 6 bits (the 2^t buckets it fills are then merely "heavy" and take the workgroup path).

@@ -25,7 +25,9 @@ namespace sonic {
 enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
 // buckets per running-sum segment inside prove(): measured at n = 2^18 (ms per proof): K=2 77.6, 4 63.4, 8 57.0, 16 58.1,
 // 32 61.4, 64 69.7, 128 86.0 -- the reduction's dependent chain, not its work, is what the lanes wait for
-static int PROVE_SEGMENT = getenv("SONIC_PROVE_SEGMENT") ? atoi(getenv("SONIC_PROVE_SEGMENT")) : 8;
+// Below 2^18 buckets the chain length matters more than the work (n = 2^16: K=2 21.5 ms, 4 21.8, 8 22.4; n = 2^14: 13.7, 13.6, 14.4).
+static int PROVE_SEGMENT = getenv("SONIC_PROVE_SEGMENT") ? atoi(getenv("SONIC_PROVE_SEGMENT")) : 0;
+static int prove_segment(const MsmPlan& pl) { return PROVE_SEGMENT > 0 ? PROVE_SEGMENT : (pl.NB >= (1 << 18) ? 8 : 4); }
 
 struct Scratch {
   DevBuf D, q, scan, fz_discard;
@@ -49,7 +51,7 @@ static void commit_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& w
   if (ih >= i0 && ih < i1) flag_nonzero_enqueue(st, poly + ih, 1, d_flags, FLAG_SRS_INDEX);
   const long n = i1 - i0;
   MsmPlan pl = srs_msm_plan(srs, n);
-  msm_plan_set_segment(pl, PROVE_SEGMENT);
+  msm_plan_set_segment(pl, prove_segment(pl));
   msm_enqueue(st, ws, pl, srs_basis(srs, 1) + (lo + i0 + shift + d), poly + i0, n, true, slot);
 }
 
@@ -78,7 +80,7 @@ static void open_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws,
   flag_nonzero_enqueue(st, q + i1, qn - i1, d_flags, FLAG_SRS_INDEX);
   const long n = i1 - i0;
   MsmPlan pl = srs_msm_plan(srs, n);
-  msm_plan_set_segment(pl, PROVE_SEGMENT);
+  msm_plan_set_segment(pl, prove_segment(pl));
   msm_enqueue(st, ws, pl, srs_basis(srs, 0) + (lo + i0 + d), q + i0, n, true, slot);
 }
 
@@ -261,6 +263,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   if (!p || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
   if (!p->have_assignment) { set_error("sonic_prover_prove: no assignment set"); return SONIC_ERR_INVALID_ARG; }
   std::lock_guard<std::mutex> g(p->mu);
+  const auto t_begin = std::chrono::steady_clock::now();
   const long n = p->n, Q = p->Q;
   const sonic_srs* srs = p->srs;
   hipStream_t st = p->st;
@@ -352,6 +355,8 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   fr_from_mont_enqueue(ms, frout, 3 + 2 * Q);
 
+  const bool timing = getenv("SONIC_DEBUG_TIMING") != nullptr;
+  const auto t_enq = std::chrono::steady_clock::now();
   const int K = (int)(7 + 4 * Q);
   const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
   std::vector<MsmSlot> hs(KS);
@@ -361,11 +366,13 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   HIP_OK(hipMemcpyAsync(hfr.data(), frout, hfr.size(), hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
+  if (timing) fprintf(stderr, "[sonic] prove: enqueue %.3f ms, then waited %.3f ms for the device\n",
+                      std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
   if (hflags) return flags_to_status(hflags, "prove");
   std::vector<uint8_t> pts(96 * (size_t)K);
   {
     // host tails (Horner over <= 64 window sums + one inversion each), one task per MSM
-    const bool timing = getenv("SONIC_DEBUG_TIMING") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     const int nt = K < 16 ? K : 16;
