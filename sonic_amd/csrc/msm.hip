@@ -22,6 +22,7 @@
 // Algorithmic traffic: 96 B point + 32 B scalar per term read once from HBM per window pass;
 // the kernel is integer-issue bound (v_mad_u64_u32), not HBM bound -- see DESIGN.md.
 #include <string.h>
+#include <stdexcept>
 #include "msm.hpp"
 
 namespace sonic {
@@ -83,17 +84,18 @@ MsmPlan msm_plan_tables(long n, int c, int W, long table_stride) {
   return p;
 }
 
-void MsmWorkspace::reserve(long n, const MsmPlan& pl) {
-  size_t M = (size_t)pl.Wb * pl.NB;
+void MsmWorkspace::reserve(long n, const MsmPlan& pl, int k) {
+  const size_t sets = (size_t)k * pl.Wb;
+  size_t M = sets * pl.NB;
   size_t NW = (size_t)n * pl.W;
-  const size_t part_hn = (size_t)ceil_div((long)M, 1L << 10) * (size_t)ceil_div(n, 1024);   // partitions x pass-1 workgroups
+  const size_t part_hn = (size_t)ceil_div((long)pl.Wb * pl.NB, 1L << 10) * (size_t)(ceil_div(n, 1024) + k);   // partitions per job x pass-1 workgroups
   count.ensure((2 * part_hn + 4) * 4);
   off.ensure((M + 1) * 4);
   digits.ensure(NW * 4);
   rank.ensure(NW * 4);
   entries.ensure(NW * 4);
   buckets.ensure(M * sizeof(G1XYZZ));
-  segres.ensure(((size_t)pl.Wb * pl.nseg + pl.nseg / 256 + 2) * sizeof(G1XYZZ));
+  segres.ensure((sets * pl.nseg + sets * (pl.nseg / 256 + 1) + 2) * sizeof(G1XYZZ));
   scan_tmp.ensure(((M > part_hn ? M : part_hn) / 2048 + 4) * 4);
   order.ensure((M + 1) * 4);
   size_hist.ensure((256 * (M / 2048 + 1) + 1) * 4 * 2);
@@ -126,6 +128,21 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // entries (k_part_sort).  Order inside a bucket is irrelevant (the sum is commutative), so nothing needs to be stable.
 constexpr int PART_LOW_BITS = 10;
 constexpr int PART_TILE = 1024;            // scalars per workgroup in pass 1
+
+// kernel-argument view of a batch (by value); tile0[j] = first pass-1 workgroup of job j
+struct MsmBatchDev {
+  int k;
+  uint32_t tile0[MSM_MAX_JOBS + 1];
+  const G1Affine* points[MSM_MAX_JOBS];
+  const Fr* scalars[MSM_MAX_JOBS];
+  long n[MSM_MAX_JOBS];
+  MsmSlot* slot[MSM_MAX_JOBS];
+};
+__device__ __forceinline__ int batch_job_of_tile(const MsmBatchDev& b, uint32_t tile) {
+  int j = 0;
+  while (j + 1 < b.k && tile >= b.tile0[j + 1]) j++;
+  return j;
+}
 
 struct DigitStream {
   Fr s;
@@ -175,13 +192,19 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* cnt, bool valid, uint32_t
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_part_hist(const Fr* __restrict__ sc, long n, int c, int W, int keystride, int mont, int P,
-                                                   uint32_t nblk, uint32_t* __restrict__ hist) {
+// Histogram layout: job-major, then partition, then the job's workgroups -- index (j, t, b) = P tile0[j] + t nblk_j + b, P =
+// partitions per job.  Its exclusive scan is the write cursor of every (partition, workgroup) pair.
+__global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int c, int W, int keystride, int mont, int P,
+                                                   uint32_t* __restrict__ hist) {
   extern __shared__ uint32_t h[];
   for (int t = threadIdx.x; t < P; t += 256) h[t] = 0;
   __syncthreads();
+  const int job = batch_job_of_tile(batch, blockIdx.x);
+  const uint32_t blk = blockIdx.x - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
+  const Fr* __restrict__ sc = batch.scalars[job];
+  const long n = batch.n[job];
   for (int k = 0; k < PART_TILE / 256; k++) {
-    const long i = (long)blockIdx.x * PART_TILE + k * 256 + threadIdx.x;
+    const long i = (long)blk * PART_TILE + k * 256 + threadIdx.x;
     DigitStream ds;
     ds.init(sc, i, i < n, mont);
     for (int w = 0; w < W; w++) {
@@ -192,17 +215,23 @@ __global__ __launch_bounds__(256) void k_part_hist(const Fr* __restrict__ sc, lo
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < P; t += 256) hist[(size_t)t * nblk + blockIdx.x] = h[t];
+  uint32_t* out = hist + (size_t)P * batch.tile0[job] + blk;
+  for (int t = threadIdx.x; t < P; t += 256) out[(size_t)t * nblk] = h[t];
 }
 
-__global__ __launch_bounds__(256) void k_part_scatter(const Fr* __restrict__ sc, long n, int c, int W, int keystride, int mont, int P,
-                                                      uint32_t nblk, const uint32_t* __restrict__ base, uint16_t* __restrict__ part_lo,
+__global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, int c, int W, int keystride, int mont, int P,
+                                                      const uint32_t* __restrict__ base, uint16_t* __restrict__ part_lo,
                                                       uint32_t* __restrict__ part_pay) {
   extern __shared__ uint32_t cur[];
-  for (int t = threadIdx.x; t < P; t += 256) cur[t] = base[(size_t)t * nblk + blockIdx.x];
+  const int job = batch_job_of_tile(batch, blockIdx.x);
+  const uint32_t blk = blockIdx.x - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
+  const Fr* __restrict__ sc = batch.scalars[job];
+  const long n = batch.n[job];
+  const uint32_t* in = base + (size_t)P * batch.tile0[job] + blk;
+  for (int t = threadIdx.x; t < P; t += 256) cur[t] = in[(size_t)t * nblk];
   __syncthreads();
   for (int k = 0; k < PART_TILE / 256; k++) {
-    const long i = (long)blockIdx.x * PART_TILE + k * 256 + threadIdx.x;
+    const long i = (long)blk * PART_TILE + k * 256 + threadIdx.x;
     DigitStream ds;
     ds.init(sc, i, i < n, mont);
     for (int w = 0; w < W; w++) {
@@ -218,15 +247,19 @@ __global__ __launch_bounds__(256) void k_part_scatter(const Fr* __restrict__ sc,
   }
 }
 
-// one workgroup per partition p = keys [p * 1024, (p+1) * 1024): bucket offsets and final placement
-__global__ __launch_bounds__(256) void k_part_sort(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_pay,
-                                                   const uint32_t* __restrict__ base, const uint32_t* __restrict__ total, uint32_t nblk, int P,
-                                                   uint32_t M, uint32_t* __restrict__ off, uint32_t* __restrict__ entries) {
+// one workgroup per (job, partition): keys [job * jobstride + t * 1024, +1024): bucket offsets and final placement
+__global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_pay,
+                                                   const uint32_t* __restrict__ base, const uint32_t* __restrict__ total, size_t hn, int P,
+                                                   uint32_t jobstride, uint32_t* __restrict__ off, uint32_t* __restrict__ entries) {
   __shared__ uint32_t cnt[1 << PART_LOW_BITS];
   __shared__ uint32_t sc4[256];
-  const int p = blockIdx.x;
-  const uint32_t beg = base[(size_t)p * nblk];
-  const uint32_t end = p + 1 < P ? base[(size_t)(p + 1) * nblk] : *total;
+  const int job = blockIdx.x / P, t = blockIdx.x % P;
+  const uint32_t nblk = batch.tile0[job + 1] - batch.tile0[job];
+  const size_t idx = (size_t)P * batch.tile0[job] + (size_t)t * nblk, idx_next = idx + nblk;
+  const uint32_t beg = idx < hn ? base[idx] : *total;
+  const uint32_t end = idx_next < hn ? base[idx_next] : *total;
+  const uint32_t M = (uint32_t)batch.k * jobstride;
+  const bool last_block = blockIdx.x == gridDim.x - 1;
   for (int t = threadIdx.x; t < (1 << PART_LOW_BITS); t += 256) cnt[t] = 0;
   __syncthreads();
   // every lane of a wave must reach lds_take: round the trip count up to the wave
@@ -245,12 +278,12 @@ __global__ __launch_bounds__(256) void k_part_sort(const uint16_t* __restrict__ 
   for (int k = 0; k < 4; k++) { v[k] = cnt[threadIdx.x * 4 + k]; ssum += v[k]; }
   uint32_t ex = block_exclusive_scan_256(ssum, sc4, nullptr);
   for (int k = 0; k < 4; k++) {
-    const uint32_t key = (uint32_t)p * (1u << PART_LOW_BITS) + threadIdx.x * 4 + k;
+    const uint32_t local = (uint32_t)t * (1u << PART_LOW_BITS) + threadIdx.x * 4 + k;
     cnt[threadIdx.x * 4 + k] = ex;                 // becomes the running cursor
-    if (key < M) off[key] = beg + ex;
+    if (local < jobstride) off[(uint32_t)job * jobstride + local] = beg + ex;
     ex += v[k];
   }
-  if (p == P - 1 && threadIdx.x == 0) off[M] = *total;
+  if (last_block && threadIdx.x == 0) off[M] = *total;
   __syncthreads();
   for (uint32_t k0 = 0; k0 < trips; k0 += B) {
     uint32_t lo[B], pay[B];
@@ -359,7 +392,7 @@ __device__ __forceinline__ size_t entry_point(uint32_t e, long stride) {
   return (size_t)(e & 0x03ffffffu) + (size_t)((e >> 26) & 31u) * (size_t)stride;
 }
 
-__global__ __launch_bounds__(256, 2) void k_bucket_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
                                                       const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
                                                       long stride, uint32_t nbuckets, uint32_t heavy_t,
                                                       G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs,
@@ -369,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const G1Affine* __restr
   const uint32_t b = order[t];
   const uint32_t beg = off[b], end = off[b + 1];
   const uint32_t cnt = end - beg;
+  const G1Affine* __restrict__ pts = batch.points[b / jobstride];
   if (cnt > heavy_t) {
     uint32_t ns = (cnt + HEAVY_SEG - 1) / HEAVY_SEG;
     uint32_t base = atomicAdd(&hm->n_items, ns);
@@ -397,13 +431,14 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const G1Affine* __restr
   buckets[b] = acc;
 }
 
-__global__ __launch_bounds__(256, 2) void k_heavy_accum(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(256, 2) void k_heavy_accum(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
                                                      const uint32_t* __restrict__ off, long stride, const HeavyMeta* hm,
                                                      const HeavyItem* items, G1XYZZ* __restrict__ partial) {
   __shared__ G1XYZZ sh[256];
   const uint32_t n_items = hm->n_items;
   for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
     const HeavyItem item = items[it];
+    const G1Affine* __restrict__ pts = batch.points[item.bucket / jobstride];
     const uint32_t beg = off[item.bucket] + item.seg * HEAVY_SEG;
     uint32_t end = beg + HEAVY_SEG;
     const uint32_t bend = off[item.bucket + 1];
@@ -471,9 +506,12 @@ __global__ __launch_bounds__(64, 2) void k_bucket_segments(const G1XYZZ* __restr
   segres[t] = tot;
 }
 
-__global__ __launch_bounds__(256, 2) void k_window_sum(const G1XYZZ* __restrict__ segres, int W, int c, int nseg, MsmSlot* slot) {
+// block = bucket set (job * Wb + window); the sum lands in that job's slot
+__global__ __launch_bounds__(256, 2) void k_window_sum(const G1XYZZ* __restrict__ segres, int W, int c, int nseg, const MsmBatchDev batch) {
   __shared__ G1XYZZ sh[256];
-  const int w = blockIdx.x;
+  const int w = blockIdx.x % W;
+  MsmSlot* slot = batch.slot[blockIdx.x / W];
+  segres += (size_t)(blockIdx.x - w) * nseg;
   G1XYZZ acc = G1XYZZ::inf();
   for (int s = threadIdx.x; s < nseg; s += 256) acc = g1_add(acc, segres[(size_t)w * nseg + s]);
   sh[threadIdx.x] = acc;
@@ -528,10 +566,24 @@ void g1_canonical_bytes_host(const G1XYZZ& p, uint8_t* out) {
 }
 
 // ---------------------------------------------------------------------------------------------
-void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points, const Fr* d_scalars,
-                 long n, bool scalars_mont, MsmSlot* d_slot) {
-  ws.reserve(n > 0 ? n : 1, pl);
-  const size_t M = (size_t)pl.Wb * pl.NB;
+bool msm_can_batch(const MsmPlan& pl) { return pl.Wb == 1 && pl.NB >= (1 << PART_LOW_BITS); }
+
+void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const MsmJob* jobs, int k, bool scalars_mont) {
+  if (k < 1 || k > MSM_MAX_JOBS) throw std::runtime_error("msm_enqueue_batch: 1..MSM_MAX_JOBS jobs");
+  if (k > 1 && !msm_can_batch(pl)) throw std::runtime_error("msm_enqueue_batch: plan cannot be batched");
+  MsmBatchDev batch;
+  memset(&batch, 0, sizeof batch);
+  batch.k = k;
+  long n_total = 0;
+  for (int j = 0; j < k; j++) {
+    batch.points[j] = jobs[j].points; batch.scalars[j] = jobs[j].scalars; batch.n[j] = jobs[j].n; batch.slot[j] = jobs[j].slot;
+    batch.tile0[j + 1] = batch.tile0[j] + (uint32_t)ceil_div(jobs[j].n, PART_TILE);
+    n_total += jobs[j].n;
+  }
+  if (batch.tile0[k] == 0) for (int j = 1; j <= k; j++) batch.tile0[j] = 1;      // nothing to do: one idle workgroup keeps the chain uniform
+  ws.reserve(n_total > 0 ? n_total : 1, pl, k);
+  const uint32_t jobstride = (uint32_t)pl.Wb * pl.NB;              // buckets per job
+  const size_t M = (size_t)k * jobstride;
   const int keystride = pl.Wb == 1 ? 0 : pl.NB;
   uint32_t* off = ws.off.as<uint32_t>();
   HeavyMeta* hm = ws.heavy_meta.as<HeavyMeta>();
@@ -539,21 +591,21 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
   HIP_OK(hipMemsetAsync(hm, 0, sizeof(HeavyMeta), st));
   uint32_t* tiles = ws.scan_tmp.as<uint32_t>();
   {
-    const int P = ceil_div((long)M, 1L << PART_LOW_BITS);
-    const uint32_t pblk = (uint32_t)ceil_div(n > 0 ? n : 1, PART_TILE);
+    const int P = ceil_div((long)jobstride, 1L << PART_LOW_BITS);   // partitions per job
+    const uint32_t pblk = batch.tile0[k];
     const size_t hn = (size_t)P * pblk;
     uint32_t* hist = ws.count.as<uint32_t>();
     uint32_t* hbase = hist + hn + 1;
     const int ht = ceil_div((long)hn + 1, 2048);
     uint32_t* total = tiles + ht;
-    LAUNCH(k_part_hist, pblk, 256, P * 4, st, d_scalars, n, pl.c, pl.W, keystride, (int)scalars_mont, P, pblk, hist);
+    LAUNCH(k_part_hist, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, P, hist);
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
-    LAUNCH(k_part_scatter, pblk, 256, P * 4, st, d_scalars, n, pl.c, pl.W, keystride, (int)scalars_mont, P, pblk, (const uint32_t*)hbase,
+    LAUNCH(k_part_scatter, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, P, (const uint32_t*)hbase,
            ws.digits.as<uint16_t>(), ws.rank.as<uint32_t>());
-    LAUNCH(k_part_sort, P, 256, 0, st, (const uint16_t*)ws.digits.as<uint16_t>(), (const uint32_t*)ws.rank.as<uint32_t>(), (const uint32_t*)hbase,
-           (const uint32_t*)total, pblk, P, (uint32_t)M, off, ws.entries.as<uint32_t>());
+    LAUNCH(k_part_sort, k * P, 256, 0, st, batch, (const uint16_t*)ws.digits.as<uint16_t>(), (const uint32_t*)ws.rank.as<uint32_t>(),
+           (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>());
   }
   {
     const uint32_t nblk = (uint32_t)ceil_div((long)M, 2048);
@@ -567,24 +619,31 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hist_sc);
     LAUNCH(k_border_scatter, nblk, 256, 0, st, (const uint32_t*)off, (uint32_t)M, nblk, (const uint32_t*)hist_sc, ws.order.as<uint32_t>());
   }
-  LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(),
+  LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
          (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, ws.buckets.as<G1XYZZ>(), hm, hrecs,
          ws.heavy_items.as<HeavyItem>());
-  LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, d_points, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
+  LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
          pl.table_stride, (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
   LAUNCH(k_heavy_finish, 256, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), ws.buckets.as<G1XYZZ>());
-  LAUNCH(k_bucket_segments, ceil_div((long)pl.Wb * pl.nseg, 64), 64, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), pl.Wb,
+  const int sets = k * pl.Wb;
+  LAUNCH(k_bucket_segments, ceil_div((long)sets * pl.nseg, 64), 64, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), sets,
          pl.NB, pl.K, pl.nseg, ws.segres.as<G1XYZZ>());
-  if (pl.Wb == 1 && pl.nseg > 4096) {
-    // one window with tens of thousands of segments: 256-way groups first, then the window tree
-    const int group = 256, ngroups = ceil_div(pl.nseg, group);
-    G1XYZZ* part = ws.segres.as<G1XYZZ>() + pl.nseg;
-    LAUNCH(k_group_sum, ngroups, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), (long)pl.nseg, group, part);
-    LAUNCH(k_window_sum, 1, 256, 0, st, (const G1XYZZ*)part, 1, pl.c, ngroups, d_slot);
+  if (pl.nseg > 4096) {
+    // sets with tens of thousands of segments: 256-way groups first (nseg is a power of two), then one tree per set
+    const int group = 256, ngroups = pl.nseg / group;
+    G1XYZZ* part = ws.segres.as<G1XYZZ>() + (size_t)sets * pl.nseg;
+    LAUNCH(k_group_sum, sets * ngroups, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), (long)sets * pl.nseg, group, part);
+    LAUNCH(k_window_sum, sets, 256, 0, st, (const G1XYZZ*)part, pl.Wb, pl.c, ngroups, batch);
   } else {
-    LAUNCH(k_window_sum, pl.Wb, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), pl.Wb, pl.c, pl.nseg, d_slot);
+    LAUNCH(k_window_sum, sets, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), pl.Wb, pl.c, pl.nseg, batch);
   }
+}
+
+void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points, const Fr* d_scalars,
+                 long n, bool scalars_mont, MsmSlot* d_slot) {
+  MsmJob job{d_points, d_scalars, n, d_slot};
+  msm_enqueue_batch(st, ws, pl, &job, 1, scalars_mont);
 }
 
 }  // namespace sonic

@@ -32,7 +32,8 @@ struct MsmSlot {
 
 struct MsmWorkspace {
   DevBuf count, off, digits, rank, entries, buckets, segres, scan_tmp, order, size_hist, heavy_meta, heavy_items, heavy_partial;
-  void reserve(long n, const MsmPlan& pl);
+  // n = total terms over the k jobs of a batch
+  void reserve(long n, const MsmPlan& pl, int k = 1);
 };
 
 // Queues one MSM on `st`: sum_i scalars[i] * points[i].  `scalars_mont` tells whether the Fr
@@ -40,6 +41,14 @@ struct MsmWorkspace {
 // Writes the W per-window sums into *d_slot.
 void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points,
                  const Fr* d_scalars, long n, bool scalars_mont, MsmSlot* d_slot);
+
+// Several MSMs as ONE kernel chain (shared-bucket plans over window tables only): job j owns bucket set j, so the
+// latency-bound phases (running sums, trees, sort passes) run k times wider instead of k times in a row.  The jobs may
+// differ in size, points and scalars; they share the plan (c, W, table stride).  k <= MSM_MAX_JOBS.
+constexpr int MSM_MAX_JOBS = 8;
+struct MsmJob { const G1Affine* points; const Fr* scalars; long n; MsmSlot* slot; };
+bool msm_can_batch(const MsmPlan& pl);
+void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const MsmJob* jobs, int k, bool scalars_mont);
 
 // Host tail: Horner over the slot's window sums -> un-normalised XYZZ sum.
 G1XYZZ msm_finish_host(const MsmSlot& s);

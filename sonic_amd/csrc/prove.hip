@@ -38,8 +38,8 @@ struct Scratch {
 // `poly` dense over exponents [lo, lo+len).  Terms whose shifted exponent leaves [-d, d] or hits the
 // e' = 0 hole are legal only if their coefficient is zero (the reference's normalised sparse form
 // would not contain them); otherwise FLAG_SRS_INDEX (`index` panics, CommitmentScheme.hs:70-73).
-static void commit_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const Fr* poly, long lo, long len, long maxm,
-                           MsmSlot* slot, int* d_flags) {
+// Queues the checks and returns the MSM that is left to run.
+static MsmJob commit_job(hipStream_t st, const sonic_srs* srs, const Fr* poly, long lo, long len, long maxm, MsmSlot* slot, int* d_flags) {
   const long d = srs_d(srs), shift = d - maxm;
   long i0 = -d - shift - lo, i1 = d - shift - lo + 1;     // in-range i: lo + i + shift in [-d, d]
   if (i0 < 0) i0 = 0;
@@ -49,15 +49,32 @@ static void commit_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& w
   flag_nonzero_enqueue(st, poly + i1, len - i1, d_flags, FLAG_SRS_INDEX);
   const long ih = -shift - lo;
   if (ih >= i0 && ih < i1) flag_nonzero_enqueue(st, poly + ih, 1, d_flags, FLAG_SRS_INDEX);
-  const long n = i1 - i0;
-  MsmPlan pl = srs_msm_plan(srs, n);
-  msm_plan_set_segment(pl, prove_segment(pl));
-  msm_enqueue(st, ws, pl, srs_basis(srs, 1) + (lo + i0 + shift + d), poly + i0, n, true, slot);
+  return MsmJob{srs_basis(srs, 1) + (lo + i0 + shift + d), poly + i0, i1 - i0, slot};
+}
+
+// The MSMs that become ready together run as one batched kernel chain when the SRS has window tables (msm.hpp);
+// otherwise one after the other.
+static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const MsmJob* jobs, int k) {
+  if (k <= 0) return;
+  long nmax = 0;
+  for (int j = 0; j < k; j++) nmax = std::max(nmax, jobs[j].n);
+  MsmPlan pl = srs_msm_plan(srs, nmax);
+  if (k > 1 && msm_can_batch(pl)) {
+    msm_plan_set_segment(pl, prove_segment(pl));
+    msm_enqueue_batch(st, ws, pl, jobs, k, true);
+    return;
+  }
+  for (int j = 0; j < k; j++) {
+    MsmPlan p1 = srs_msm_plan(srs, jobs[j].n);
+    msm_plan_set_segment(p1, prove_segment(p1));
+    msm_enqueue_batch(st, ws, p1, &jobs[j], 1, true);
+  }
 }
 
 // f(z) for a dense Laurent f: D_e = c_e z^e, inclusive prefix sums, f(z) = last prefix.
 static void eval_prefix_enqueue(hipStream_t st, Scratch& sc, const Fr* poly, long lo, long len, const Fr* zpair, Fr* d_fz) {
   sc.reserve(len);
+  sc.scan.ensure(sizeof(Fr) * (len / 1024 + 2));
   poly_scale_powers_enqueue(st, poly, sc.D.as<Fr>(), len, lo, zpair, zpair + 1);
   poly_prefix_sum_enqueue(st, sc.D.as<Fr>(), len, sc.scan);
   HIP_OK(hipMemcpyAsync(d_fz, sc.D.as<Fr>() + (len - 1), sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -65,9 +82,11 @@ static void eval_prefix_enqueue(hipStream_t st, Scratch& sc, const Fr* poly, lon
 
 // openPoly (CommitmentScheme.hs:36-48).  Requires lo <= 0 <= lo+len-1 (callers extend the range to
 // contain X^0, where `fX - monomial 0 fz` puts -f(z)).  Quotient exponents [lo, lo+len-2], plain basis.
-static void open_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, Scratch& sc, const Fr* poly, long lo, long len,
-                         const Fr* zpair, Fr* d_fz, MsmSlot* slot, int* d_flags) {
+// Queues evaluation + quotient and returns the MSM that is left to run (its scalars live in `sc` until then).
+static MsmJob open_job(hipStream_t st, const sonic_srs* srs, Scratch& sc, const Fr* poly, long lo, long len,
+                       const Fr* zpair, Fr* d_fz, MsmSlot* slot, int* d_flags) {
   const long d = srs_d(srs);
+  sc.reserve(len);
   eval_prefix_enqueue(st, sc, poly, lo, len, zpair, d_fz ? d_fz : sc.fz_discard.as<Fr>());
   const long qn = len - 1;
   poly_quotient_enqueue(st, sc.D.as<Fr>(), sc.q.as<Fr>(), len, lo, zpair, zpair + 1);
@@ -78,10 +97,7 @@ static void open_enqueue(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws,
   const Fr* q = sc.q.as<Fr>();
   flag_nonzero_enqueue(st, q, i0, d_flags, FLAG_SRS_INDEX);
   flag_nonzero_enqueue(st, q + i1, qn - i1, d_flags, FLAG_SRS_INDEX);
-  const long n = i1 - i0;
-  MsmPlan pl = srs_msm_plan(srs, n);
-  msm_plan_set_segment(pl, prove_segment(pl));
-  msm_enqueue(st, ws, pl, srs_basis(srs, 0) + (lo + i0 + d), q + i0, n, true, slot);
+  return MsmJob{srs_basis(srs, 0) + (lo + i0 + d), q + i0, i1 - i0, slot};
 }
 
 // IN = [y, z, y*z, u, v, y_1..y_Q, z_1..z_Q] from the transcript S = [c1..c4, y, z, ys, zs, u, v]
@@ -89,6 +105,17 @@ __global__ void k_prep_scalars(const Fr* __restrict__ S, long Q, Fr* __restrict_
   long t = threadIdx.x + (long)blockIdx.x * blockDim.x;
   if (t == 0) { IN[0] = S[4]; IN[1] = S[5]; IN[2] = fp_mul(S[4], S[5]); IN[3] = S[6 + 2 * Q]; IN[4] = S[7 + 2 * Q]; }
   if (t < 2 * Q) IN[5 + t] = S[6 + t];
+}
+
+// k * P on the host, k in standard form (the Q per-constraint commitments of a prepared handle, Q <= HOST_CQ_MAX)
+constexpr long HOST_CQ_MAX = 4;
+static G1XYZZ g1_mul_fr_host(const G1Affine& p, const Fr& k_std) {
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int i = 254; i >= 0; i--) {
+    acc = g1_dbl(acc);
+    if ((k_std.l[i >> 5] >> (i & 31)) & 1u) acc = g1_add_mixed(acc, p);
+  }
+  return acc;
 }
 
 static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
@@ -105,7 +132,9 @@ struct Lane {
   hipStream_t st = nullptr;
   hipEvent_t done = nullptr;
   MsmWorkspace ws;
-  Scratch sc;
+  Scratch sc[MSM_MAX_JOBS];       // one per opening of the group in flight (grown on first use)
+  MsmJob jobs[MSM_MAX_JOBS];
+  int njobs = 0;
 };
 constexpr int N_LANES = 8;
 
@@ -123,6 +152,7 @@ struct sonic_prover {
   // sonic_prover_prepare: Commit(P_q) per constraint row (affine, Montgomery) and per-j scalar buffers
   bool prepared = false;
   DevBuf cq;
+  std::vector<G1Affine> cq_host;
   std::vector<DevBuf> diag, yq;
   hipEvent_t ev_r1 = nullptr, ev_sy0 = nullptr, ev_t = nullptr, ev_su = nullptr;
   std::vector<hipEvent_t> ev_syj;
@@ -230,13 +260,10 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   mkev(&p->ev_r1); mkev(&p->ev_sy0); mkev(&p->ev_t); mkev(&p->ev_su);
   p->ev_syj.resize(Q, nullptr);
   for (auto& e : p->ev_syj) mkev(&e);
+  // MSM workspaces and opening scratch grow on first use: every proof maps the same group of MSMs to the same lane
   for (auto& l : p->lanes) {
     HIP_OK(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
     mkev(&l.done);
-    l.sc.reserve(tlen);
-    l.sc.scan.ensure(sizeof(Fr) * (tlen / 1024 + 2));
-    l.ws.reserve(tlen, srs_msm_plan(srs, tlen));
-    l.ws.reserve(tlen, msm_plan(tlen));
   }
   HIP_OK(hipStreamSynchronize(st));
   *out = p.release();
@@ -290,30 +317,40 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   const long r_lo = -2 * n - 4, r_len = 3 * n + 5, s_lo = -n, s_len = 3 * n + 1, t_lo = -4 * n - 8, t_len = 7 * n + 9;
   const long M = 1L << p->log2m;
 
-  // The main stream builds the polynomials; each commitment / opening runs on the next MSM lane as
-  // soon as its input exists (event).  Results land in disjoint slots / frout entries.
+  // The main stream builds the polynomials.  The commitments / openings that depend on one polynomial form a group:
+  // it runs on the next MSM lane as soon as its input exists (event), as ONE batched MSM kernel chain.
+  // Results land in disjoint slots / frout entries.
   hipStream_t ms = st;
+  p->next_lane = 0;
   auto ready = [&](hipEvent_t e) { HIP_OK(hipEventRecord(e, ms)); };
-  auto commit = [&](hipEvent_t e, const Fr* poly, long lo, long len, long maxm, long slot) {
-    Lane& l = p->pick(e);
-    commit_enqueue(l.st, srs, l.ws, poly, lo, len, maxm, &slots[slot], flags);
+  Lane* cur = nullptr;
+  auto begin_group = [&](hipEvent_t e) { cur = &p->pick(e); cur->njobs = 0; };
+  auto flush_group = [&] { run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs); cur->njobs = 0; };
+  auto commit = [&](const Fr* poly, long lo, long len, long maxm, long slot) {
+    if (cur->njobs == MSM_MAX_JOBS) flush_group();
+    cur->jobs[cur->njobs++] = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
   };
-  auto open = [&](hipEvent_t e, const Fr* poly, long lo, long len, const Fr* zp, Fr* fz, long slot) {
-    Lane& l = p->pick(e);
-    open_enqueue(l.st, srs, l.ws, l.sc, poly, lo, len, zp, fz, &slots[slot], flags);
+  auto open = [&](const Fr* poly, long lo, long len, const Fr* zp, Fr* fz, long slot) {
+    if (cur->njobs == MSM_MAX_JOBS) flush_group();
+    Scratch& sc = cur->sc[cur->njobs];
+    cur->jobs[cur->njobs++] = open_job(cur->st, srs, sc, poly, lo, len, zp, fz, &slots[slot], flags);
   };
+  const bool host_cq = p->prepared && Q <= HOST_CQ_MAX;
   Fr* sy = p->sy0.as<Fr>();
   // zkP_1: r'(X,1), R = Commit(n, r(X,1))                                          Protocol.hs:58-63
   build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
   ready(p->ev_r1);
-  commit(p->ev_r1, r1, r_lo, r_len, n, 0);
-  open(p->ev_r1, r1, r_lo, r_len, pZ, &frout[0], 2);                                 // (a, W_a)     :79
-  open(p->ev_r1, r1, r_lo, r_len, pYZ, &frout[1], 3);                                // (b, W_b)     :80
+  begin_group(p->ev_r1);
+  commit(r1, r_lo, r_len, n, 0);
+  open(r1, r_lo, r_len, pZ, &frout[0], 2);                                             // (a, W_a)     :79
+  open(r1, r_lo, r_len, pYZ, &frout[1], 3);                                            // (b, W_b)     :80
+  flush_group();
   // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y)                               Protocol.hs:69-73, Constraints.hs:56-68
   poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
   s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
   ready(p->ev_sy0);
-  { Lane& l = p->pick(p->ev_sy0); eval_prefix_enqueue(l.st, l.sc, sy, s_lo, s_len, pZ, &frout[2]); }   // s(z,y)  :83
+  Lane& lane_t = p->pick(p->ev_sy0);                                                   // s(z,y) now, T / W_t later  :83
+  eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);
   HIP_OK(hipMemsetAsync(fa, 0, sizeof(Fr) * M, ms));
   HIP_OK(hipMemsetAsync(fb, 0, sizeof(Fr) * M, ms));
   HIP_OK(hipMemcpyAsync(fa, r1, sizeof(Fr) * r_len, hipMemcpyDeviceToDevice, ms));
@@ -326,8 +363,11 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   Fr* t = fa;                                                                         // exponents [t_lo, t_lo + t_len)
   sub_k_of_y_enqueue(ms, t + (0 - t_lo), cs, pw + (2 * n + 1), Q, flags, 0);
   ready(p->ev_t);
-  commit(p->ev_t, t, t_lo, t_len, d, 1);                                              // T            :73
-  open(p->ev_t, t, t_lo, t_len, pZ, nullptr, 4);                                      // W_t          :81
+  HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
+  cur = &lane_t; cur->njobs = 0;
+  commit(t, t_lo, t_len, d, 1);                                                        // T            :73
+  open(t, t_lo, t_len, pZ, nullptr, 4);                                                // W_t          :81
+  flush_group();
   // hscProve                                                                        Signature.hs:38-72
   for (long j = 0; j < Q; j++) {
     Fr* syj = p->syj[j].as<Fr>();
@@ -335,30 +375,31 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
     s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, syj);                                   // s(X, y_j)
     if (p->prepared) s_diag_part_enqueue(ms, pw, n, Q, p->diag[j].as<Fr>(), p->yq[j].as<Fr>());
     ready(p->ev_syj[j]);
-    if (p->prepared) {                                                               // S_j           :42
-      Lane& l = p->pick(p->ev_syj[j]);
-      commit_enqueue(l.st, srs, l.ws, p->diag[j].as<Fr>(), n + 1, n, d, &slots[5 + 2 * j], flags);
-      msm_enqueue(l.st, l.ws, msm_plan(Q), p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
-    } else {
-      commit(p->ev_syj[j], syj, s_lo, s_len, d, 5 + 2 * j);
-    }
-    open(p->ev_syj[j], syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);          // (s_j, W_j)    :43
-    open(p->ev_syj[j], syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);            // W'_j          :54
+    begin_group(p->ev_syj[j]);
+    if (p->prepared) commit(p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);            // S_j (diagonal part)   :42
+    else commit(syj, s_lo, s_len, d, 5 + 2 * j);                                     // S_j                   :42
+    open(syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);                        // (s_j, W_j)    :43
+    open(syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                          // W'_j          :54
+    flush_group();
+    if (p->prepared && !host_cq)                                                      // sum_q y_j^{n+q} C_q, Q-term MSM
+      msm_enqueue(cur->st, cur->ws, msm_plan(Q), p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
   }
   poly_scale_powers_enqueue(ms, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);             // u^e, e in [-n, 2n]
   const long u_lo = -n, u_len = 2 * n + Q + 1;
   s_of_u_enqueue(ms, wL, wR, wO, pw, n, Q, su, p->tmp);                              // s(u, Y)       :51
   ready(p->ev_su);
-  commit(p->ev_su, su, u_lo, u_len, d, 6 + 4 * Q);                                   // C             :52
-  for (long j = 0; j < Q; j++) open(p->ev_su, su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
-  open(p->ev_su, su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                           // Q_v           :63
+  begin_group(p->ev_su);
+  commit(su, u_lo, u_len, d, 6 + 4 * Q);                                             // C             :52
+  for (long j = 0; j < Q; j++) open(su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
+  open(su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                                     // Q_v           :63
+  flush_group();
   for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   fr_from_mont_enqueue(ms, frout, 3 + 2 * Q);
 
   const bool timing = getenv("SONIC_DEBUG_TIMING") != nullptr;
   const auto t_enq = std::chrono::steady_clock::now();
   const int K = (int)(7 + 4 * Q);
-  const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
+  const int KS = K + (p->prepared && !host_cq ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
   std::vector<MsmSlot> hs(KS);
   std::vector<uint8_t> hfr(32 * (3 + 2 * Q));
   int hflags = 0;
@@ -381,7 +422,17 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
         for (int i = w; i < K; i += nt) {
           G1XYZZ s = msm_finish_host(hs[i]);
           const int j = (i - 5) / 2;
-          if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) s = g1_add(s, msm_finish_host(hs[K + j]));
+          if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) {
+            if (host_cq) {                                   // few constraints: the Q scalar multiplications cost less here than a launch chain
+              Fr yj;
+              memcpy(yj.l, transcript + 32 * (6 + j), 32);
+              Fr yp = fp_pow_u64(fp_to_mont(yj), (uint64_t)n + 1);
+              const Fr ym = fp_to_mont(yj);
+              for (long q = 0; q < Q; q++) { s = g1_add(s, g1_mul_fr_host(p->cq_host[q], fp_from_mont(yp))); yp = fp_mul(yp, ym); }
+            } else {
+              s = g1_add(s, msm_finish_host(hs[K + j]));
+            }
+          }
           g1_canonical_bytes_host(s, &pts[96 * (size_t)i]);
         }
       });
@@ -420,7 +471,8 @@ int sonic_prover_prepare(sonic_prover_t* p) {
     Lane& l = p->lanes[q % N_LANES];
     Fr* row = rows[q % N_LANES].as<Fr>();
     weight_row_poly_enqueue(l.st, p->wL.as<Fr>(), p->wR.as<Fr>(), p->wO.as<Fr>(), n, q, row);
-    commit_enqueue(l.st, p->srs, l.ws, row, -n, 3 * n + 1, d, slots.as<MsmSlot>() + q, flags);
+    MsmJob job = commit_job(l.st, p->srs, row, -n, 3 * n + 1, d, slots.as<MsmSlot>() + q, flags);
+    run_jobs(l.st, p->srs, l.ws, &job, 1);
   }
   for (auto& l : p->lanes) HIP_OK(hipStreamSynchronize(l.st));
   std::vector<MsmSlot> hs(Q);
@@ -436,13 +488,13 @@ int sonic_prover_prepare(sonic_prover_t* p) {
       th.emplace_back([&, w] { for (long q = w; q < Q; q += nt) cq[q] = g1_to_affine(msm_finish_host(hs[q])); });
     for (auto& x : th) x.join();
   }
+  p->cq_host = cq;
   p->cq.alloc(sizeof(G1Affine) * Q);
   HIP_OK(hipMemcpy(p->cq.p, cq.data(), sizeof(G1Affine) * Q, hipMemcpyHostToDevice));
   p->diag.resize(Q); p->yq.resize(Q);
   for (auto& b : p->diag) b.alloc(sizeof(Fr) * n);
   for (auto& b : p->yq) b.alloc(sizeof(Fr) * Q);
   p->slots.ensure(sizeof(MsmSlot) * (7 + 5 * Q));
-  for (auto& l : p->lanes) l.ws.reserve(Q, msm_plan(Q));
   p->prepared = true;
   API_END
 }
@@ -499,7 +551,8 @@ int sonic_commit_poly(const sonic_srs_t* srs, int64_t max, int64_t n_terms, cons
   DensePoly f;
   int rc = densify(st, srs, n_terms, exps, coeffs, false, f, flags.as<int>());
   if (rc) return rc;
-  commit_enqueue(st, srs, shared_msm_ws(), f.c.as<Fr>(), f.lo, f.len, max, slot.as<MsmSlot>(), flags.as<int>());
+  MsmJob job = commit_job(st, srs, f.c.as<Fr>(), f.lo, f.len, max, slot.as<MsmSlot>(), flags.as<int>());
+  run_jobs(st, srs, shared_msm_ws(), &job, 1);
   MsmSlot h;
   HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));
   int fl = read_flags(st, flags);
@@ -524,7 +577,8 @@ int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms
   fr_to_mont_enqueue(st, zin.as<Fr>(), 1, flags.as<int>());
   fr_with_inverse_enqueue(st, zin.as<Fr>(), 1, zpair.as<Fr>());
   Scratch sc;
-  open_enqueue(st, srs, shared_msm_ws(), sc, f.c.as<Fr>(), f.lo, f.len, zpair.as<Fr>(), fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>());
+  MsmJob job = open_job(st, srs, sc, f.c.as<Fr>(), f.lo, f.len, zpair.as<Fr>(), fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>());
+  run_jobs(st, srs, shared_msm_ws(), &job, 1);
   fr_from_mont_enqueue(st, fz.as<Fr>(), 1);
   MsmSlot h;
   HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));
