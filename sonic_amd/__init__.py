@@ -11,11 +11,18 @@ Python host-side mirror of the reference's Haskell modules over the C ABI of
 All compute happens in hand-written HIP kernels on the GPU; this package is ctypes plumbing.
 There is no CPU fallback: without the built extension imports fail, without a GPU calls raise.
 """
-from ._lib import SonicError, LIB_PATH  # noqa: F401
-from .encoding import R_MODULUS, Q_MODULUS, fr_to_bytes, fr_from_bytes, g1_to_bytes, g1_from_bytes  # noqa: F401
-from .srs import SRS  # noqa: F401
-from .commitment import commit_poly, open_poly, pc_v, msm_g1  # noqa: F401
-from .protocol import prove, verify, Proof, HscProof, RndOracle, Prover, ArithCircuit, Assignment, GateWeights  # noqa: F401
+import os as _os
+
+# prove() drives the t(X,y) product and up to six MSM groups on their own HIP streams; the ROCm runtime multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one run behind each other.  Read when the HIP
+# runtime initialises, so this only takes effect if the package is imported before the process first touches the GPU.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from ._lib import SonicError, LIB_PATH  # noqa: F401,E402
+from .encoding import R_MODULUS, Q_MODULUS, fr_to_bytes, fr_from_bytes, g1_to_bytes, g1_from_bytes  # noqa: F401,E402
+from .srs import SRS  # noqa: F401,E402
+from .commitment import commit_poly, open_poly, pc_v, msm_g1  # noqa: F401,E402
+from .protocol import prove, verify, Proof, HscProof, RndOracle, Prover, ArithCircuit, Assignment, GateWeights  # noqa: F401,E402
 
 __all__ = ["SRS", "commit_poly", "open_poly", "pc_v", "msm_g1", "prove", "verify", "Proof", "HscProof", "RndOracle", "Prover",
            "ArithCircuit", "Assignment", "GateWeights", "SonicError"]

@@ -195,6 +195,9 @@ int sonic_init(int device_ordinal) {
     {
       std::lock_guard<std::mutex> g(g_init_mu);
       if (g_device < 0 && device_ordinal >= 0) {
+        // one hardware queue per prover stream (the runtime's default of 4 makes streams queue behind each other);
+        // only effective when this is the process's first HIP call, harmless otherwise
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || n <= 0) { set_error("no HIP device available: libsonic_hip has no CPU fallback"); return SONIC_ERR_NO_DEVICE; }

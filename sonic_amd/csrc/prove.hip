@@ -27,7 +27,8 @@ enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
 // 32 61.4, 64 69.7, 128 86.0 -- the reduction's dependent chain, not its work, is what the lanes wait for
 // Below 2^18 buckets the chain length matters more than the work (n = 2^16: K=2 21.5 ms, 4 21.8, 8 22.4; n = 2^14: 13.7, 13.6, 14.4).
 static int PROVE_SEGMENT = getenv("SONIC_PROVE_SEGMENT") ? atoi(getenv("SONIC_PROVE_SEGMENT")) : 0;
-static int prove_segment(const MsmPlan& pl) { return PROVE_SEGMENT > 0 ? PROVE_SEGMENT : (pl.NB >= (1 << 18) ? 8 : 4); }
+// Batched chains (k jobs -> k times the threads) shift the optimum at 2^19 buckets: n = 2^18, K=8 50.3 ms, 16 47.9, 32 47.1, 64 49.1.
+static int prove_segment(const MsmPlan& pl, int k) { return PROVE_SEGMENT > 0 ? PROVE_SEGMENT : (pl.NB >= (1 << 18) ? (k > 1 ? 32 : 8) : 4); }
 
 struct Scratch {
   DevBuf D, q, scan, fz_discard;
@@ -60,13 +61,13 @@ static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, con
   for (int j = 0; j < k; j++) nmax = std::max(nmax, jobs[j].n);
   MsmPlan pl = srs_msm_plan(srs, nmax);
   if (k > 1 && msm_can_batch(pl)) {
-    msm_plan_set_segment(pl, prove_segment(pl));
+    msm_plan_set_segment(pl, prove_segment(pl, k));
     msm_enqueue_batch(st, ws, pl, jobs, k, true);
     return;
   }
   for (int j = 0; j < k; j++) {
     MsmPlan p1 = srs_msm_plan(srs, jobs[j].n);
-    msm_plan_set_segment(p1, prove_segment(p1));
+    msm_plan_set_segment(p1, prove_segment(p1, 1));
     msm_enqueue_batch(st, ws, p1, &jobs[j], 1, true);
   }
 }
@@ -124,10 +125,10 @@ static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < 
 
 using namespace sonic;
 
-// One MSM "lane": its own stream, bucket workspace and opening scratch.  The 7+4Q MSMs of a proof are
-// independent once their input polynomial exists, and every MSM has latency-bound phases (bucket
-// running sums, window trees, histogram atomics) that leave most of the chip idle: several lanes let one
-// MSM's reduction overlap another's accumulation (measured at n = 2^18: 2 lanes 64.9 ms, 5: 60.9, 8: 58.3, 12: 59.5).
+// One MSM "lane": its own stream, bucket workspace and opening scratch.  The MSMs of a proof that depend on the same
+// polynomial form a group (R, W_a, W_b | T, W_t | S_j, W_j, W'_j | C, Q_j.., Q_v) that runs on one lane as ONE batched
+// kernel chain (msm_enqueue_batch); different groups run on different lanes so that one group's sort and reduction
+// phases run under another's accumulation.
 struct Lane {
   hipStream_t st = nullptr;
   hipEvent_t done = nullptr;
@@ -136,18 +137,19 @@ struct Lane {
   MsmJob jobs[MSM_MAX_JOBS];
   int njobs = 0;
 };
-constexpr int N_LANES = 8;
+constexpr int N_LANES = 6;
 
 struct sonic_prover {
   const sonic_srs* srs = nullptr;
   long n = 0, Q = 0;
   hipStream_t st = nullptr;
+  hipStream_t ts = nullptr;                  // the t(X,y) product (NTT) runs beside the hscProve polynomials
   bool have_assignment = false;
   DevBuf wL, wR, wO, cs, aL, aR, aO;        // Montgomery, resident across proofs
   Lane lanes[N_LANES];
   int next_lane = 0;
   NttTables ntt;
-  DevBuf S, IN, PAIRS, r1, sy0, su, pw, fa, fb, slots, frout, flags, tmp;
+  DevBuf S, IN, PAIRS, r1, sy0, su, pw, kpow, fa, fb, slots, frout, flags, tmp;
   std::vector<DevBuf> syj;
   // sonic_prover_prepare: Commit(P_q) per constraint row (affine, Montgomery) and per-j scalar buffers
   bool prepared = false;
@@ -158,9 +160,17 @@ struct sonic_prover {
   std::vector<hipEvent_t> ev_syj;
   int log2m = 0;
   std::mutex mu;
+  // Lane N_LANES-1 carries the t(X,y) group (the largest, ready last); the other groups alternate over the rest, which
+  // balances the point additions per lane (Q = 2: 55M / 51M / 48M) while one lane's sort and reduction phases run under
+  // another lane's accumulation.  Streams beyond the 4 hardware queues would serialise behind each other.
   Lane& pick(hipEvent_t ready) {
     Lane& l = lanes[next_lane];
-    next_lane = (next_lane + 1) % N_LANES;
+    next_lane = (next_lane + 1) % (N_LANES - 1);
+    (void)hipStreamWaitEvent(l.st, ready, 0);
+    return l;
+  }
+  Lane& t_lane(hipEvent_t ready) {
+    Lane& l = lanes[N_LANES - 1];
     (void)hipStreamWaitEvent(l.st, ready, 0);
     return l;
   }
@@ -169,6 +179,7 @@ struct sonic_prover {
     for (hipEvent_t e : {ev_r1, ev_sy0, ev_t, ev_su}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_syj) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
+    if (ts) (void)hipStreamDestroy(ts);
   }
 };
 
@@ -230,6 +241,7 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   std::unique_ptr<sonic_prover> p(new sonic_prover());
   p->srs = srs; p->n = n; p->Q = Q;
   HIP_OK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&p->ts, hipStreamNonBlocking));
   hipStream_t st = p->st;
   p->flags.alloc(4);
   HIP_OK(hipMemsetAsync(p->flags.p, 0, 4, st));
@@ -253,6 +265,7 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   for (auto& b : p->syj) b.alloc(sizeof(Fr) * (3 * n + 1));
   p->su.alloc(sizeof(Fr) * (2 * n + Q + 1));
   p->pw.alloc(sizeof(Fr) * (3 * n + Q + 2));
+  p->kpow.alloc(sizeof(Fr) * Q);
   p->S.alloc(sizeof(Fr) * (8 + 2 * Q)); p->IN.alloc(sizeof(Fr) * (5 + 2 * Q)); p->PAIRS.alloc(sizeof(Fr) * 2 * (5 + 2 * Q));
   p->slots.alloc(sizeof(MsmSlot) * (7 + 4 * Q));
   p->frout.alloc(sizeof(Fr) * (3 + 2 * Q));
@@ -337,46 +350,56 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   };
   const bool host_cq = p->prepared && Q <= HOST_CQ_MAX;
   Fr* sy = p->sy0.as<Fr>();
-  // zkP_1: r'(X,1), R = Commit(n, r(X,1))                                          Protocol.hs:58-63
+  // ---- all polynomials first (small kernels; queued behind a bucket accumulation they would each wait ~0.5 ms for CUs) ----
+  // zkP_1: r'(X,1)                                                                   Protocol.hs:58-63
   build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
   ready(p->ev_r1);
+  // s(X,y)                                                                           Protocol.hs:69-70
+  poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
+  s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
+  HIP_OK(hipMemcpyAsync(p->kpow.p, pw + (2 * n + 1), sizeof(Fr) * Q, hipMemcpyDeviceToDevice, ms));   // y^{n+1..n+Q} for k(y); pw is reused below
+  ready(p->ev_sy0);
+  {
+    // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y), on its own stream          Protocol.hs:69-73, Constraints.hs:56-68
+    hipStream_t ts = p->ts;
+    HIP_OK(hipStreamWaitEvent(ts, p->ev_sy0, 0));          // ev_sy0 follows ev_r1 on the main stream
+    HIP_OK(hipMemsetAsync(fa, 0, sizeof(Fr) * M, ts));
+    HIP_OK(hipMemsetAsync(fb, 0, sizeof(Fr) * M, ts));
+    HIP_OK(hipMemcpyAsync(fa, r1, sizeof(Fr) * r_len, hipMemcpyDeviceToDevice, ts));
+    poly_scale_powers_enqueue(ts, r1, fb, r_len, r_lo, pY, pY + 1);                  // r(X,y): c_e y^e (diagonal)
+    add_into_enqueue(ts, fb + (s_lo - r_lo), sy, s_len);
+    ntt_forward_enqueue(ts, p->ntt, fa, p->log2m);
+    ntt_forward_enqueue(ts, p->ntt, fb, p->log2m);
+    fr_pointwise_mul_enqueue(ts, fa, fb, M);
+    ntt_inverse_enqueue(ts, p->ntt, fa, p->log2m);
+    sub_k_of_y_enqueue(ts, fa + (0 - t_lo), cs, p->kpow.as<Fr>(), Q, flags, 0);
+    HIP_OK(hipEventRecord(p->ev_t, ts));
+  }
+  Fr* t = fa;                                                                         // exponents [t_lo, t_lo + t_len)
+  // hscProve: s(X, y_j), s(u, Y)                                                     Signature.hs:41,51
+  for (long j = 0; j < Q; j++) {
+    poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
+    s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, p->syj[j].as<Fr>());
+    if (p->prepared) s_diag_part_enqueue(ms, pw, n, Q, p->diag[j].as<Fr>(), p->yq[j].as<Fr>());
+    ready(p->ev_syj[j]);
+  }
+  poly_scale_powers_enqueue(ms, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);             // u^e, e in [-n, 2n]
+  const long u_lo = -n, u_len = 2 * n + Q + 1;
+  s_of_u_enqueue(ms, wL, wR, wO, pw, n, Q, su, p->tmp);
+  ready(p->ev_su);
+
+  // ---- the MSM groups, largest first where its input allows ----
+  Lane& lane_t = p->t_lane(p->ev_sy0);
+  eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);         // s(z,y)       :83
   begin_group(p->ev_r1);
-  commit(r1, r_lo, r_len, n, 0);
+  commit(r1, r_lo, r_len, n, 0);                                                       // R            :63
   open(r1, r_lo, r_len, pZ, &frout[0], 2);                                             // (a, W_a)     :79
   open(r1, r_lo, r_len, pYZ, &frout[1], 3);                                            // (b, W_b)     :80
   flush_group();
-  // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y)                               Protocol.hs:69-73, Constraints.hs:56-68
-  poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
-  s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
-  ready(p->ev_sy0);
-  Lane& lane_t = p->pick(p->ev_sy0);                                                   // s(z,y) now, T / W_t later  :83
-  eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);
-  HIP_OK(hipMemsetAsync(fa, 0, sizeof(Fr) * M, ms));
-  HIP_OK(hipMemsetAsync(fb, 0, sizeof(Fr) * M, ms));
-  HIP_OK(hipMemcpyAsync(fa, r1, sizeof(Fr) * r_len, hipMemcpyDeviceToDevice, ms));
-  poly_scale_powers_enqueue(ms, r1, fb, r_len, r_lo, pY, pY + 1);                    // r(X,y): c_e y^e (diagonal)
-  add_into_enqueue(ms, fb + (s_lo - r_lo), sy, s_len);
-  ntt_forward_enqueue(ms, p->ntt, fa, p->log2m);
-  ntt_forward_enqueue(ms, p->ntt, fb, p->log2m);
-  fr_pointwise_mul_enqueue(ms, fa, fb, M);
-  ntt_inverse_enqueue(ms, p->ntt, fa, p->log2m);
-  Fr* t = fa;                                                                         // exponents [t_lo, t_lo + t_len)
-  sub_k_of_y_enqueue(ms, t + (0 - t_lo), cs, pw + (2 * n + 1), Q, flags, 0);
-  ready(p->ev_t);
-  HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
-  cur = &lane_t; cur->njobs = 0;
-  commit(t, t_lo, t_len, d, 1);                                                        // T            :73
-  open(t, t_lo, t_len, pZ, nullptr, 4);                                                // W_t          :81
-  flush_group();
-  // hscProve                                                                        Signature.hs:38-72
   for (long j = 0; j < Q; j++) {
     Fr* syj = p->syj[j].as<Fr>();
-    poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
-    s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, syj);                                   // s(X, y_j)
-    if (p->prepared) s_diag_part_enqueue(ms, pw, n, Q, p->diag[j].as<Fr>(), p->yq[j].as<Fr>());
-    ready(p->ev_syj[j]);
     begin_group(p->ev_syj[j]);
-    if (p->prepared) commit(p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);            // S_j (diagonal part)   :42
+    if (p->prepared) commit(p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);            // S_j (diagonal part)   Signature.hs:42
     else commit(syj, s_lo, s_len, d, 5 + 2 * j);                                     // S_j                   :42
     open(syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);                        // (s_j, W_j)    :43
     open(syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                          // W'_j          :54
@@ -384,14 +407,15 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
     if (p->prepared && !host_cq)                                                      // sum_q y_j^{n+q} C_q, Q-term MSM
       msm_enqueue(cur->st, cur->ws, msm_plan(Q), p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
   }
-  poly_scale_powers_enqueue(ms, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);             // u^e, e in [-n, 2n]
-  const long u_lo = -n, u_len = 2 * n + Q + 1;
-  s_of_u_enqueue(ms, wL, wR, wO, pw, n, Q, su, p->tmp);                              // s(u, Y)       :51
-  ready(p->ev_su);
   begin_group(p->ev_su);
   commit(su, u_lo, u_len, d, 6 + 4 * Q);                                             // C             :52
   for (long j = 0; j < Q; j++) open(su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
   open(su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                                     // Q_v           :63
+  flush_group();
+  HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
+  cur = &lane_t; cur->njobs = 0;
+  commit(t, t_lo, t_len, d, 1);                                                        // T            Protocol.hs:73
+  open(t, t_lo, t_len, pZ, nullptr, 4);                                                // W_t          :81
   flush_group();
   for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   fr_from_mont_enqueue(ms, frout, 3 + 2 * Q);
