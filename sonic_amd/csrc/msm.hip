@@ -32,7 +32,9 @@ int msm_window_override() { return g_window_override; }
 void msm_set_window_override(int c) { g_window_override = c; }
 
 static constexpr uint32_t HEAVY_SEG = 16384;  // entries per heavy work item (256 threads x 64)
-static constexpr int HEAVY_GRID = 1024;
+// Usually there is nothing heavy and the launch only has to notice that; on a chip full of other MSMs' accumulation every
+// workgroup still waits for a free slot (1024 idle workgroups delayed the chain behind them by 1.4-3.4 ms in prove()).
+static int HEAVY_GRID = getenv("SONIC_HEAVY_GRID") ? atoi(getenv("SONIC_HEAVY_GRID")) : 128;
 
 struct HeavyMeta { uint32_t n_items, n_heavy; };
 struct HeavyRec { uint32_t bucket, base, nseg; };
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(64, 2) void k_heavy_finish(const HeavyMeta* hm, con
 }
 
 // ---- bucket reduction: sum_b (b+1) * B_b per window -----------------------------------------
-__global__ __launch_bounds__(64, 2) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg,
+__global__ __launch_bounds__(256, 1) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg,
                                                         G1XYZZ* __restrict__ segres) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * nseg) return;
@@ -502,7 +504,25 @@ __global__ __launch_bounds__(64, 2) void k_bucket_segments(const G1XYZZ* __restr
     run = g1_add(run, B[j]);
     tot = g1_add(tot, run);          // ends as sum_j (j+1) B[j]
   }
-  if (k0) tot = g1_add(tot, g1_mul_small(run, (uint32_t)k0));
+  if (nseg % 64 == 0) {
+    // k0 * run with k0 = sg * K: the 64 lanes of a wave hold consecutive sg, so the bits of sg above the lane bits are
+    // wave-uniform and their conditional additions are uniform branches; only the six lane bits pay for both paths
+    // (a per-lane double-and-add executes an addition at every bit as soon as any lane needs one).
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)sg >> 6), lo = (uint32_t)sg & 63u;
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int i = 31 - __clz((int)(hi | 1u)); i >= 0; i--) {
+      acc = g1_dbl(acc);
+      if ((hi >> i) & 1u) acc = g1_add(acc, run);
+    }
+    for (int i = 5; i >= 0; i--) {
+      acc = g1_dbl(acc);
+      if ((lo >> i) & 1u) acc = g1_add(acc, run);
+    }
+    for (int s = K; s > 1; s >>= 1) acc = g1_dbl(acc);
+    tot = g1_add(tot, acc);
+  } else if (k0) {
+    tot = g1_add(tot, g1_mul_small(run, (uint32_t)k0));
+  }
   segres[t] = tot;
 }
 
@@ -624,10 +644,10 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
          ws.heavy_items.as<HeavyItem>());
   LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
          pl.table_stride, (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
-  LAUNCH(k_heavy_finish, 256, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
+  LAUNCH(k_heavy_finish, HEAVY_GRID / 2, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), ws.buckets.as<G1XYZZ>());
   const int sets = k * pl.Wb;
-  LAUNCH(k_bucket_segments, ceil_div((long)sets * pl.nseg, 64), 64, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), sets,
+  LAUNCH(k_bucket_segments, ceil_div((long)sets * pl.nseg, 256), 256, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), sets,
          pl.NB, pl.K, pl.nseg, ws.segres.as<G1XYZZ>());
   if (pl.nseg > 4096) {
     // sets with tens of thousands of segments: 256-way groups first (nseg is a power of two), then one tree per set

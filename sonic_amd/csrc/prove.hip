@@ -55,13 +55,14 @@ static MsmJob commit_job(hipStream_t st, const sonic_srs* srs, const Fr* poly, l
 
 // The MSMs that become ready together run as one batched kernel chain when the SRS has window tables (msm.hpp);
 // otherwise one after the other.
-static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const MsmJob* jobs, int k) {
+static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const MsmJob* jobs, int k, bool last = false) {
   if (k <= 0) return;
   long nmax = 0;
   for (int j = 0; j < k; j++) nmax = std::max(nmax, jobs[j].n);
   MsmPlan pl = srs_msm_plan(srs, nmax);
   if (k > 1 && msm_can_batch(pl)) {
-    msm_plan_set_segment(pl, prove_segment(pl, k));
+    // the group that finishes last reduces with nothing left to hide under: shortest chain instead of least work
+    msm_plan_set_segment(pl, last && PROVE_SEGMENT == 0 ? 8 : prove_segment(pl, k));
     msm_enqueue_batch(st, ws, pl, jobs, k, true);
     return;
   }
@@ -338,7 +339,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   auto ready = [&](hipEvent_t e) { HIP_OK(hipEventRecord(e, ms)); };
   Lane* cur = nullptr;
   auto begin_group = [&](hipEvent_t e) { cur = &p->pick(e); cur->njobs = 0; };
-  auto flush_group = [&] { run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs); cur->njobs = 0; };
+  auto flush_group = [&](bool last = false) { run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last); cur->njobs = 0; };
   auto commit = [&](const Fr* poly, long lo, long len, long maxm, long slot) {
     if (cur->njobs == MSM_MAX_JOBS) flush_group();
     cur->jobs[cur->njobs++] = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
@@ -416,7 +417,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   cur = &lane_t; cur->njobs = 0;
   commit(t, t_lo, t_len, d, 1);                                                        // T            Protocol.hs:73
   open(t, t_lo, t_len, pZ, nullptr, 4);                                                // W_t          :81
-  flush_group();
+  flush_group(true);
   for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   fr_from_mont_enqueue(ms, frout, 3 + 2 * Q);
 
