@@ -37,6 +37,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MAD_PEAK_PER_S = 2.79e13       # measured v_mad_u64_u32 issue rate, tools/microbench.hip (profiles/r01_microbench.txt)
+ACCUM_INSTR_PER_ADD = 7762     # static ISA count of one bucket-walk iteration incl. 10 x the 680-instruction Montgomery routine (tools/count_accum_instrs.py; lower bound)
+VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4    # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_msm.json")   # FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc)
 
 
@@ -221,6 +223,11 @@ def main():
                     "peak": MAD_PEAK_PER_S / 1e12, "unit": "TMAD/s",
                     "frac": round(mads / (accum_ms * 1e-3) / MAD_PEAK_PER_S, 4) if accum_ms > 0 else 0.0,
                     "plan": {"window_bits": pc.value, "windows": pw_.value, "bucket_sets": pb.value}}
+    # VALU issue model: one wave per SIMD already issues the routine back to back (1.1 us per dependent product = 680 x 4 cycles),
+    # so the kernel pays for instructions, not latency: additions x static instructions per addition / (time x issue rate)
+    n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value          # the first term of a bucket is a copy
+    int_roofline["valu_issue"] = {"instr_per_mixed_add": ACCUM_INSTR_PER_ADD, "wave_instr_per_s_peak": VALU_WAVE_INSTR_PER_S,
+                                  "frac": round(n_adds * ACCUM_INSTR_PER_ADD / 64 / (accum_ms * 1e-3) / VALU_WAVE_INSTR_PER_S, 4) if accum_ms > 0 else 0.0}
 
     cpu_baseline = None
     if not args.no_cpu:

@@ -4,20 +4,23 @@
 // src/Sonic/CommitmentScheme.hs:25-29 (alpha basis) and :45-48 (plain basis): per-term 255-bit
 // double-and-add.  Here: Pippenger's bucket method, laid out for one MI355X.
 //
-//   1. k_msm_digits    one thread per scalar: fold s into [0,(r-1)/2] (negating the point
-//                      instead), signed base-2^c digits, histogram per (window, |digit|) with the
-//                      atomic's return value kept as the entry's rank inside its bucket
-//   2. scan            exclusive scan of the W * 2^(c-1) bucket sizes
-//   3. k_msm_scatter   counting-sort scatter: entries[off[bucket] + rank] = point index | sign
+//   1. k_part_hist / scan / k_part_scatter   one thread per scalar: fold s into [0,(r-1)/2] (negating the point
+//                      instead), signed base-2^c digits; entries split by the high bits of their bucket key into
+//                      <= 1024-bucket partitions through per-workgroup LDS histograms
+//   2. k_part_sort     one workgroup per partition: LDS count of the low key bits -> bucket offsets, final placement
+//                      entries[off[bucket] ..] = point index | window | sign
+//   3. k_border_*      counting sort of the buckets by size (largest first), so that equal-length walks share a wave
 //   4. k_bucket_accum  one thread per bucket walks its entries: affine point gathered from HBM
 //                      (96 B contiguous), XYZZ mixed addition.  Buckets far above the mean (the
 //                      protocol produces them: s(X,y) has n equal coefficients when a weight row
-//                      is all ones, test/Test/Reference.hs:143-145) are split into 4096-entry
+//                      is all ones, test/Test/Reference.hs:143-145) are split into 16384-entry
 //                      items, each reduced by a whole workgroup through LDS (k_heavy_accum)
-//   5. k_bucket_segments / k_window_sum   sum_b b*B_b per window by running sums over K-bucket
-//                      segments, then an LDS tree per window
+//   5. k_bucket_segments / k_group_sum / k_window_sum   sum_b b*B_b per bucket set by running sums over K-bucket
+//                      segments, then LDS trees
 //   6. host tail       Horner over the W window sums + normalisation to the canonical affine
 //                      bytes (msm_finish_host): O(W) sequential work, deferred by the caller
+//
+// msm_enqueue_batch runs k MSMs that share a plan as ONE such chain (job j = bucket set j): see msm.hpp.
 //
 // Algorithmic traffic: 96 B point + 32 B scalar per term read once from HBM per window pass;
 // the kernel is integer-issue bound (v_mad_u64_u32), not HBM bound -- see DESIGN.md.
