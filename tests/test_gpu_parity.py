@@ -341,6 +341,48 @@ def test_prepared_handle_same_bytes(sonic, orc, ref, srs_pair):
             assert prep.prove_bytes(tr) == want, (n, Q, kind)
 
 
+@pytest.mark.parametrize("n,Q", [(9, 5), (12, 7), (10, 9), (300, 8)])
+def test_many_constraints_group_paths(sonic, orc, ref, srs_pair, n, Q):
+    """Q > 4: the per-constraint commitments of a prepared handle are combined by a Q-term MSM on the GPU instead of on the host;
+    Q + 2 > 8: the s(u,Y) group (C, Q_1..Q_Q, Q_v) no longer fits one batched MSM chain and is split.  Prepared and plain
+    handles must both match the oracle."""
+    d, x, alpha, g, o = srs_pair
+    pyr = random.Random(900 + 17 * n + Q)
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    ac = sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3])
+    tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+    want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+    for prepare in (False, True):
+        p = sonic.Prover(g, ac, prepare=prepare)
+        p.set_assignment(sonic.Assignment(*asg))
+        assert p.prove_bytes(tr) == want, (n, Q, prepare)
+        assert p.prove_bytes(tr) == want, (n, Q, prepare, "repeat")
+        p.close()
+
+
+def test_prove_without_window_tables(sonic, orc, ref, srs_pair):
+    """an SRS built with SONIC_MSM_TABLES=0 has no shared-bucket plan: the MSM groups of prove() then run one MSM after the
+    other over per-window buckets, and must give the same proof"""
+    import os
+    d, x, alpha, g, o = srs_pair
+    os.environ["SONIC_MSM_TABLES"] = "0"
+    try:
+        plain = sonic.SRS.new(d, x, alpha)
+    finally:
+        del os.environ["SONIC_MSM_TABLES"]
+    pyr = random.Random(4242)
+    n, Q = 50, 3
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    ac = sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3])
+    tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+    want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+    for prepare in (False, True):
+        p = sonic.Prover(plain, ac, prepare=prepare)
+        p.set_assignment(sonic.Assignment(*asg))
+        assert p.prove_bytes(tr) == want, prepare
+        p.close()
+
+
 def test_reference_verifier_accepts_gpu_proofs(sonic, ref):
     """the reference's only end-to-end test, verify . prove (test/Test/Protocol.hs:14-23), with the proof made by
     the HIP path and the verifier restated with real pairings (oracle/pairing.py: pcV, hscVerify, verify)"""
