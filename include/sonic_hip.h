@@ -70,7 +70,9 @@ int sonic_device_sync(void);
  * empty (g^alpha is not shared, SRS.hs:38).  gNegativeX[k] = basis0[-(k+1)], gPositiveX[k] =
  * basis0[k], gNegativeAlphaX[k] = basis1[-(k+1)], gPositiveAlphaX[k] = basis1[k+1]. */
 int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out);
-/* the record constructor `SRS{..}`: caller-supplied points, (2d+1) * 96 bytes per basis */
+/* the record constructor `SRS{..}`: caller-supplied points, (2d+1) * 96 bytes per basis.  Every point is checked to be
+ * canonical and on the curve; that it lies in the prime-order subgroup G1 (as the powers of a generator do) is the
+ * caller's promise -- MSMs over an SRS use r P = O (scalars above r/2 run as r - s on the negated point). */
 int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out);
 void sonic_srs_free(sonic_srs_t* srs);
 int64_t sonic_srs_d(const sonic_srs_t* srs);        /* srsD */
@@ -94,7 +96,8 @@ int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms
                     const uint8_t* coeffs, uint8_t out_fz[32], uint8_t out_g1[96]);
 
 /* ---- the kernels behind them, exposed for parity tests and the MSM benchmark ---- */
-/* foldl' (\acc (P, v) -> acc <> P `mul` v) mempty  (the fold at CommitmentScheme.hs:26-29, 45-48) */
+/* foldl' (\acc (P, v) -> acc <> P `mul` v) mempty  (the fold at CommitmentScheme.hs:26-29, 45-48).  Points only have to be
+ * on the curve: s P is the literal multiple (no use of r P = O), also for cofactor points such as (0, 2). */
 int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]);
 /* same over an SRS slice e0 .. e0+n-1 of one basis; scalars on the host */
 int sonic_msm_g1_srs(const sonic_srs_t* srs, int basis, int64_t e0, const uint8_t* scalars, int64_t n,

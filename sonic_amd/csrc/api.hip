@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __rest
   const uint32_t* w = reinterpret_cast<const uint32_t*>(in + 96 * i);
   G1Affine p;
   for (int k = 0; k < 12; k++) { p.x.l[k] = w[k]; p.y.l[k] = w[12 + k]; }
+  if (!fp_is_canonical(p.x) || !fp_is_canonical(p.y)) { atomicOr(err, 1); out[i] = G1Affine::inf(); return; }   // before is_inf: (q, q) is not O
   if (p.is_inf()) { out[i] = p; return; }
-  if (!fp_is_canonical(p.x) || !fp_is_canonical(p.y)) { atomicOr(err, 1); out[i] = G1Affine::inf(); return; }
   p.x = fp_to_mont(p.x); p.y = fp_to_mont(p.y);
   Fq four = fp_dbl(fp_dbl(Fq::one()));
   if (fp_sqr(p.y) != fp_add(fp_mul(fp_sqr(p.x), p.x), four)) { atomicOr(err, 2); out[i] = G1Affine::inf(); return; }
@@ -360,7 +360,7 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) { set_error("sonic_msm_g1: non-canonical input or point not on curve"); return SONIC_ERR_BAD_ENCODING; }
-  msm_blocking(st, shared_msm_ws(), msm_plan(n > 0 ? n : 1), pts.as<G1Affine>(), sc.as<Fr>(), n, false, out_g1, nullptr);
+  msm_blocking(st, shared_msm_ws(), msm_plan(n > 0 ? n : 1, /*fold=*/false), pts.as<G1Affine>(), sc.as<Fr>(), n, false, out_g1, nullptr);
   API_END
 }
 

@@ -7,9 +7,22 @@
 // The modulus limbs are compile-time literals (no VGPRs spent on them).
 //
 // The same source compiles for the host (g++, tests/host/) so the limb logic is unit-tested on CPU.
+//
+// LAZY RANGE (Fq, device, assembly build): 4q < 2^384, so the Montgomery product of two values < 2q is again < 2q
+// without the final conditional subtraction ("almost Montgomery").  On the device Fq values therefore live in [0, 2q):
+// the product drops 30 instructions, add / sub correct by 2q, and 0 has the two representations 0 and q, which is_zero()
+// and == accept.  Canonical (< q) values are a special case, so canonical inputs need no conversion; what leaves the
+// device for the host's portable code is brought back below q (fp_canonical: slots, from_mont).  Fr (4r > 2^256) and
+// everything on the host stay canonical.
 #pragma once
 #include <stdint.h>
 #include "constants.hpp"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SONIC_NO_ASM_MUL)
+#define SONIC_FQ_LAZY 1
+#else
+#define SONIC_FQ_LAZY 0
+#endif
 
 #if defined(__HIPCC__)
 #define HD __host__ __device__ __forceinline__
@@ -27,14 +40,18 @@ namespace sonic {
 struct FqParams {
   static constexpr int N = FQ_LIMBS;
   static constexpr uint32_t INV = FQ_INV;
+  static constexpr bool LAZY = SONIC_FQ_LAZY != 0;
   static HD constexpr uint32_t p(int i) { constexpr uint32_t v[N] = FQ_P; return v[i]; }
+  static HD constexpr uint32_t p2(int i) { constexpr uint32_t v[N] = FQ_P2; return v[i]; }
   static HD constexpr uint32_t one(int i) { constexpr uint32_t v[N] = FQ_ONE; return v[i]; }
   static HD constexpr uint32_t r2(int i) { constexpr uint32_t v[N] = FQ_R2; return v[i]; }
 };
 struct FrParams {
   static constexpr int N = FR_LIMBS;
   static constexpr uint32_t INV = FR_INV;
+  static constexpr bool LAZY = false;
   static HD constexpr uint32_t p(int i) { constexpr uint32_t v[N] = FR_P; return v[i]; }
+  static HD constexpr uint32_t p2(int i) { constexpr uint32_t v[N] = FR_P2; return v[i]; }
   static HD constexpr uint32_t one(int i) { constexpr uint32_t v[N] = FR_ONE; return v[i]; }
   static HD constexpr uint32_t r2(int i) { constexpr uint32_t v[N] = FR_R2; return v[i]; }
 };
@@ -49,8 +66,18 @@ struct Fp {
   static HD Fp r2() { Fp r; for (int i = 0; i < N; i++) r.l[i] = P::r2(i); return r; }
   static HD Fp modulus() { Fp r; for (int i = 0; i < N; i++) r.l[i] = P::p(i); return r; }
 
-  HD bool is_zero() const { uint32_t t = 0; for (int i = 0; i < N; i++) t |= l[i]; return t == 0; }
-  HD bool operator==(const Fp& o) const { uint32_t t = 0; for (int i = 0; i < N; i++) t |= l[i] ^ o.l[i]; return t == 0; }
+  // congruent to 0: all limbs 0, or (lazy range) equal to the modulus
+  HD bool is_zero() const {
+    uint32_t t = 0;
+    for (int i = 0; i < N; i++) t |= l[i];
+    if constexpr (P::LAZY) {
+      uint32_t u = 0;
+      for (int i = 0; i < N; i++) u |= l[i] ^ P::p(i);
+      return t == 0 || u == 0;
+    }
+    return t == 0;
+  }
+  HD bool operator==(const Fp& o) const;
   HD bool operator!=(const Fp& o) const { return !(*this == o); }
 };
 
@@ -121,7 +148,8 @@ HD Fp<P> fp_neg(const Fp<P>& a) {
   uint32_t mask = nz ? 0xffffffffu : 0u;
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    uint64_t d = (uint64_t)(P::p(i) & mask) - a.l[i] - br;
+    // lazy range: 2p - a stays in [0, 2p) for 0 < a < 2p
+    uint64_t d = (uint64_t)((P::LAZY ? P::p2(i) : P::p(i)) & mask) - a.l[i] - br;
     r.l[i] = (uint32_t)d;
     br = (d >> 32) & 1;
   }
@@ -214,11 +242,28 @@ HD Fp<P> fp_sqr(const Fp<P>& a) { return fp_mul(a, a); }
 template <class P>
 HD Fp<P> fp_to_mont(const Fp<P>& a) { return fp_mul(a, Fp<P>::r2()); }
 
+// representative below the modulus (identity outside the lazy range)
+template <class P>
+HD Fp<P> fp_canonical(const Fp<P>& a) {
+  Fp<P> r = a;
+  if constexpr (P::LAZY) fp_reduce_once(r);
+  return r;
+}
+
+template <class P>
+HD bool Fp<P>::operator==(const Fp<P>& o) const {
+  if constexpr (P::LAZY) return fp_sub(*this, o).is_zero();
+  uint32_t t = 0;
+  for (int i = 0; i < N; i++) t |= l[i] ^ o.l[i];
+  return t == 0;
+}
+
+// standard form, canonical: (a + m p) / R <= p for a < 2p, and = p only for a in {0, p}
 template <class P>
 HD Fp<P> fp_from_mont(const Fp<P>& a) {
   Fp<P> o = Fp<P>::zero();
   o.l[0] = 1;
-  return fp_mul(a, o);
+  return fp_canonical(fp_mul(a, o));
 }
 
 // a^e, e a small non-negative integer (square-and-multiply, MSB first)

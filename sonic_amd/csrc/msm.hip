@@ -60,8 +60,9 @@ void msm_plan_set_segment(MsmPlan& p, int K) {
   p.nseg = p.NB / K;
 }
 
-MsmPlan msm_plan(long n) {
+MsmPlan msm_plan(long n, bool fold) {
   MsmPlan p;
+  p.fold = fold;
   int lg = 0;
   while ((1L << (lg + 1)) <= n) lg++;
   int c = lg - 4;
@@ -69,7 +70,9 @@ MsmPlan msm_plan(long n) {
   if (c > 16) c = 16;
   if (g_window_override >= 4 && g_window_override <= 16) c = g_window_override;
   p.c = c;
-  p.W = (255 + c - 1) / c;
+  // folded scalars are < 2^254, so the signed recoding never carries out of ceil(255 / c) windows; unfolded ones (< r < 2^255)
+  // need room for that carry
+  p.W = ((fold ? 255 : 256) + c - 1) / c;
   p.Wb = p.W;
   p.table_stride = 0;
   plan_finish(p, n);
@@ -81,6 +84,7 @@ MsmPlan msm_plan(long n) {
 // grow (fewer windows => fewer point additions) without multiplying the bucket count by W.
 MsmPlan msm_plan_tables(long n, int c, int W, long table_stride) {
   MsmPlan p;
+  p.fold = true;
   p.c = c;
   p.W = W;
   p.Wb = 1;
@@ -153,10 +157,10 @@ struct DigitStream {
   Fr s;
   bool neg;
   uint32_t carry;
-  __device__ __forceinline__ void init(const Fr* __restrict__ sc, long i, bool live, int mont) {
+  __device__ __forceinline__ void init(const Fr* __restrict__ sc, long i, bool live, int mont, int fold) {
     s = live ? sc[i] : Fr::zero();
     if (mont) s = fp_from_mont(s);
-    neg = fr_gt_half(s);
+    neg = fold && fr_gt_half(s);
     if (neg) s = fp_neg(s);          // r - s, still standard form
     carry = 0;
   }
@@ -199,7 +203,7 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* cnt, bool valid, uint32_t
 
 // Histogram layout: job-major, then partition, then the job's workgroups -- index (j, t, b) = P tile0[j] + t nblk_j + b, P =
 // partitions per job.  Its exclusive scan is the write cursor of every (partition, workgroup) pair.
-__global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int c, int W, int keystride, int mont, int P,
+__global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
                                                    uint32_t* __restrict__ hist) {
   extern __shared__ uint32_t h[];
   for (int t = threadIdx.x; t < P; t += 256) h[t] = 0;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int 
   for (int k = 0; k < PART_TILE / 256; k++) {
     const long i = (long)blk * PART_TILE + k * 256 + threadIdx.x;
     DigitStream ds;
-    ds.init(sc, i, i < n, mont);
+    ds.init(sc, i, i < n, mont, fold);
     for (int w = 0; w < W; w++) {
       uint32_t sign;
       const uint32_t d = ds.next(c, sign);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int 
   for (int t = threadIdx.x; t < P; t += 256) out[(size_t)t * nblk] = h[t];
 }
 
-__global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, int c, int W, int keystride, int mont, int P,
+__global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
                                                       const uint32_t* __restrict__ base, uint16_t* __restrict__ part_lo,
                                                       uint32_t* __restrict__ part_pay) {
   extern __shared__ uint32_t cur[];
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
   for (int k = 0; k < PART_TILE / 256; k++) {
     const long i = (long)blk * PART_TILE + k * 256 + threadIdx.x;
     DigitStream ds;
-    ds.init(sc, i, i < n, mont);
+    ds.init(sc, i, i < n, mont, fold);
     for (int w = 0; w < W; w++) {
       uint32_t sign;
       const uint32_t d = ds.next(c, sign);
@@ -544,7 +548,9 @@ __global__ __launch_bounds__(256, 2) void k_window_sum(const G1XYZZ* __restrict_
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    slot->win[w] = sh[0];
+    G1XYZZ r = sh[0];                 // leaves the device for the host tail: representatives below q (field.hpp, lazy range)
+    r.x = fp_canonical(r.x); r.y = fp_canonical(r.y); r.zz = fp_canonical(r.zz); r.zzz = fp_canonical(r.zzz);
+    slot->win[w] = r;
     if (w == 0) { slot->W = W; slot->c = c; }
   }
 }
@@ -621,11 +627,11 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     uint32_t* hbase = hist + hn + 1;
     const int ht = ceil_div((long)hn + 1, 2048);
     uint32_t* total = tiles + ht;
-    LAUNCH(k_part_hist, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, P, hist);
+    LAUNCH(k_part_hist, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, hist);
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
-    LAUNCH(k_part_scatter, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, P, (const uint32_t*)hbase,
+    LAUNCH(k_part_scatter, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, (const uint32_t*)hbase,
            ws.digits.as<uint16_t>(), ws.rank.as<uint32_t>());
     LAUNCH(k_part_sort, k * P, 256, 0, st, batch, (const uint16_t*)ws.digits.as<uint16_t>(), (const uint32_t*)ws.rank.as<uint32_t>(),
            (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>());

@@ -14,8 +14,12 @@ struct MsmPlan {
   int K;        // buckets per running-sum segment
   int nseg;     // segments per window
   uint32_t heavy_threshold;
+  // fold scalars s > (r-1)/2 into r - s on the negated point: valid iff r P = O.  Every SRS element is in the r-torsion;
+  // caller-supplied points of sonic_msm_g1 only have to be on the curve (E(Fq) has cofactor points, e.g. (0, 2) of order 3),
+  // and s P then means the literal multiple the reference's `mul` computes, so that entry point does not fold.
+  bool fold;
 };
-MsmPlan msm_plan(long n);
+MsmPlan msm_plan(long n, bool fold = true);
 MsmPlan msm_plan_tables(long n, int c, int W, long table_stride);
 // Trade latency for work in the bucket running sums: K buckets per segment.  A standalone MSM wants the shortest
 // dependent chain (K = 8); inside prove() the reduction of one MSM hides under the accumulation of others, so fewer,

@@ -181,6 +181,36 @@ def test_msm_rejects_bad_encoding(sonic, srs_pair):
     with pytest.raises(sonic.SonicError) as e:
         sonic.msm_g1(off, sc)
     assert e.value.code == 3
+    from sonic_amd.encoding import Q_MODULUS
+    qq = pts.copy(); qq[2] = np.frombuffer(Q_MODULUS.to_bytes(48, "little") * 2, np.uint8)   # (q, q): congruent to (0, 0) but not O
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.msm_g1(qq, sc)
+    assert e.value.code == 3
+    xq = pts.copy()                                    # x + q: the same residue, non-canonical bytes
+    xv = int.from_bytes(xq[3, :48].tobytes(), "little") + Q_MODULUS
+    if xv < 1 << 384:
+        xq[3, :48] = np.frombuffer(xv.to_bytes(48, "little"), np.uint8)
+        with pytest.raises(sonic.SonicError) as e:
+            sonic.msm_g1(xq, sc)
+        assert e.value.code == 3
+
+
+def test_msm_point_with_zero_coordinate(sonic, orc, srs_pair):
+    """(0, 2) is on y^2 = x^3 + 4 (not in the r-torsion, but the group law does not care): a coordinate congruent to 0 must
+    not be taken for the point at infinity, whichever representative of 0 the device arithmetic produces"""
+    d, _, _, g, o = srs_pair
+    pts = o.points(0, 0, 6).copy()
+    z2 = np.frombuffer((0).to_bytes(48, "little") + (2).to_bytes(48, "little"), np.uint8)
+    from sonic_amd.encoding import Q_MODULUS
+    z2n = np.frombuffer((0).to_bytes(48, "little") + (Q_MODULUS - 2).to_bytes(48, "little"), np.uint8)
+    pts[1] = z2; pts[4] = z2n
+    for seed in range(3):
+        sc = rand_fr_array(np.random.default_rng(40 + seed), 6)
+        assert sonic.msm_g1(pts, sc) == orc.msm(pts, sc, 1, NCPU)
+    sc = fr_bytes([0, 5, 0, 0, 5, 0])                  # 5*(0,2) + 5*(0,-2) = O
+    assert sonic.msm_g1(pts, sc) == bytes(96) == orc.msm(pts, sc, 1, NCPU)
+    sc = fr_bytes([0, 3, 0, 0, 0, 0])                  # 3*(0,2): (0,2) has order 3, so this is O as well
+    assert sonic.msm_g1(pts, sc) == orc.msm(pts, sc, 1, NCPU)
 
 
 @pytest.mark.parametrize("log2n", [0, 1, 3, 10, 11, 12, 14])

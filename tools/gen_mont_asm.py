@@ -40,7 +40,7 @@ class Ins:
         self.deps, self.users, self.prio = set(), set(), 0
 
 
-def build(N: int, p: int):
+def build(N: int, p: int, lazy: bool = False):
     A = lambda j: j
     B = lambda j: N + j
     TPlo = lambda j: 2 * N + 2 * j
@@ -101,6 +101,10 @@ def build(N: int, p: int):
         add_carry(TPlo(N - 1), c, TPlo(N), QB(N - 1) + 1)
         emit(f"v_addc_co_u32_e64 {v(TPlo(N))}, {c}, 0, 0, {c}", [c], [v(TPlo(N)), c], [c])
 
+    if lazy:
+        # "almost Montgomery": with 4p < R the CIOS result of operands < 2p is again < 2p (T_N == 0), so values simply live
+        # in [0, 2p) and the conditional subtraction disappears; the caller reads the result from the low halves of T
+        return pre, prog, 6 * N + 3, [TPlo(j) for j in range(N)]
     # final conditional subtraction: D = T - p; result = borrow ? T : D   (T < 2p, so T_N == 0)
     PV = lambda j: QA(0) + j                 # modulus limbs in VGPRs (the Q pairs are dead now)
     D = lambda j: QA(0) + N + j
@@ -113,7 +117,7 @@ def build(N: int, p: int):
             emit(f"v_subb_co_u32_e64 {v(D(j))}, {C3}, {v(TPlo(j))}, {v(PV(j))}, {C3}", [v(TPlo(j)), v(PV(j)), C3], [v(D(j)), C3], [C3])
     for j in range(N):
         emit(f"v_cndmask_b32_e64 {v(A(j))}, {v(D(j))}, {v(TPlo(j))}, {C3}", [v(D(j)), v(TPlo(j)), C3], [v(A(j))], [C3])
-    return pre, prog, 6 * N + 3
+    return pre, prog, 6 * N + 3, [A(j) for j in range(N)]
 
 
 def schedule(prog):
@@ -179,14 +183,14 @@ def schedule(prog):
     return out
 
 
-def function_text(name: str, N: int, p: int):
-    pre, prog, nv = build(N, p)
+def function_text(name: str, N: int, p: int, lazy: bool = False):
+    pre, prog, nv, res = build(N, p, lazy)
     body = pre + schedule(prog) + ["s_setpc_b64 s[30:31]"]
-    return body, nv
+    return body, nv, res
 
 
-def cxx(name: str, cls: str, N: int, p: int) -> str:
-    body, nv = function_text(name, N, p)
+def cxx(name: str, cls: str, N: int, p: int, lazy: bool = False) -> str:
+    body, nv, res = function_text(name, N, p, lazy)
     nops = sum(1 for l in body if l.startswith("s_nop"))
     mads = sum(1 for l in body if l.startswith("v_mad_u64"))
     lines = [f"// {name}: {len(body)} instructions ({mads} v_mad_u64_u32, {nops} s_nop), VGPRs v0..v{nv - 1}"]
@@ -222,7 +226,7 @@ def cxx(name: str, cls: str, N: int, p: int) -> str:
     lines.append(f'      "s_addc_u32 s57, s57, {name}@rel32@hi+12\\n\\t"')
     lines.append('      "s_swappc_b64 s[30:31], s[56:57]\\n\\t"')
     for j in range(N):
-        lines.append(f'      "v_mov_b32_e32 %{j}, v{j}' + ('\\n\\t"' if j < N - 1 else '"'))
+        lines.append(f'      "v_mov_b32_e32 %{j}, v{res[j]}' + ('\\n\\t"' if j < N - 1 else '"'))
     lines.append(f"      : {outs}")
     lines.append(f"      : {ins}")
     lines.append(f"      : {', '.join(clob)});")
@@ -232,9 +236,10 @@ def cxx(name: str, cls: str, N: int, p: int) -> str:
 
 
 def addsub_cxx(fname: str, cls: str, N: int, sub: bool) -> str:
-    """r = a -/+ b mod p as one asm block: two interleaved carry chains and a select.
-    sub:  d = a - b (borrow chain A), e = d + p (carry chain B, one link behind), r = borrow ? e : d
-    add:  d = a + b (carry chain A),  e = d - p (borrow chain B),                 r = borrow(e) ? d : e
+    """r = a -/+ b as one asm block: two interleaved carry chains and a select.  Operands and result live in [0, 2p)
+    (see the lazy Montgomery product), so the correction constant is 2p:
+    sub:  d = a - b (borrow chain A), e = d + 2p (carry chain B, one link behind), r = borrow ? e : d
+    add:  d = a + b (carry chain A),  e = d - 2p (borrow chain B),                 r = borrow(e) ? d : e
     Chain A carries in an SGPR pair, chain B in VCC; the v_mov that loads p_j is the filler that keeps two
     instructions between a carry write and its read (gfx950 VALU-carry hazard)."""
     opA0, opA = ("v_sub_co_u32_e64", "v_subb_co_u32_e64") if sub else ("v_add_co_u32_e64", "v_addc_co_u32_e64")
@@ -270,7 +275,7 @@ def addsub_cxx(fname: str, cls: str, N: int, sub: bool) -> str:
         else:     # add: carry-out of A cannot happen (a + b < 2^(32N)); borrow of chain B (vcc) set -> d < p -> take d
             L.append(f"v_cndmask_b32_e32 {R_(j)}, {R_(j)}, {D_(j)}, vcc")
     outs = [f'"=&v"(r.l[{j}])' for j in range(N)] + [f'"=&v"(d{j})' for j in range(N)] + [f'"=&v"(p{j})' for j in range(N)] + ['"=&s"(ca)']
-    ins = [f'"v"(a.l[{j}])' for j in range(N)] + [f'"v"(b.l[{j}])' for j in range(N)] + [f'"s"(P::p({j}))' for j in range(N)]
+    ins = [f'"v"(a.l[{j}])' for j in range(N)] + [f'"v"(b.l[{j}])' for j in range(N)] + [f'"s"(P::p2({j}))' for j in range(N)]
     body = "\\n\\t".join(L)
     decl = " ".join(f"uint32_t d{j}, p{j};" for j in range(N))
     return f"""template <class P> __device__ __forceinline__ {cls} {fname}(const {cls}& a, const {cls}& b) {{
@@ -289,7 +294,7 @@ def main():
            "#pragma once",
            "#if defined(__HIP_DEVICE_COMPILE__)",
            "namespace sonic {",
-           cxx("sonic_mont_mul_fq", "Fp<FqParams>", 12, Q),
+           cxx("sonic_mont_mul_fq", "Fp<FqParams>", 12, Q, lazy=True),
            "",
            cxx("sonic_mont_mul_fr", "Fp<FrParams>", 8, R),
            "",
@@ -299,7 +304,7 @@ def main():
            "#endif", ""]
     open("sonic_amd/csrc/mont_asm.hpp", "w").write("\n".join(out))
     for name, N, p in (("fq", 12, Q), ("fr", 8, R)):
-        body, nv = function_text(name, N, p)
+        body, nv, _ = function_text(name, N, p, lazy=(name == "fq"))
         print(name, "instructions:", len(body), "nops:", sum(1 for l in body if l.startswith("s_nop")), "vgprs:", nv)
 
 

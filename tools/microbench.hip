@@ -77,21 +77,47 @@ __global__ void k_mkpts(G1Affine* pts) {
   pts[t] = g1_to_affine(a);
 }
 
-// asm product vs the C++ loop on the device, bit for bit
+// asm product / sum / difference vs the C++ loops on the device: the canonical representative of the asm result must equal
+// the C++ result bit for bit (Fq results live in [0, 2q): field.hpp "lazy range"), also for operands taken from [q, 2q)
+template <class F> __device__ bool raw_eq(const F& a, const F& b) { uint32_t t = 0; for (int i = 0; i < F::N; i++) t |= a.l[i] ^ b.l[i]; return t == 0; }
+template <class F> __device__ bool below_2p(const F& a) {
+  F m = F::modulus(), d;                       // a - p must be < p
+  uint64_t br = 0;
+  for (int i = 0; i < F::N; i++) { uint64_t x = (uint64_t)a.l[i] - m.l[i] - br; d.l[i] = (uint32_t)x; br = (x >> 32) & 1; }
+  return br || fp_is_canonical(d);
+}
+template <class F> __device__ F plus_p(const F& a) {       // a + p as raw limbs: the other representative of a
+  F m = F::modulus(), r;
+  uint64_t c = 0;
+  for (int i = 0; i < F::N; i++) { c += (uint64_t)a.l[i] + m.l[i]; r.l[i] = (uint32_t)c; c >>= 32; }
+  return r;
+}
 template <class F>
 __global__ void k_check_mul(const F* in, int n, int* bad) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   F a = in[t], b = in[(t * 7 + 3) % n];
-  F x = fp_mul(a, b), y = fp_mul_generic(a, b);
-  if (x != y) atomicAdd(bad, 1);
-  F x2 = fp_mul(a, a), y2 = fp_mul_generic(a, a);
-  if (x2 != y2) atomicAdd(bad, 1);
-  if (fp_add(a, b) != fp_add_generic(a, b)) atomicAdd(bad, 1);
-  if (fp_sub(a, b) != fp_sub_generic(a, b)) atomicAdd(bad, 1);
-  if (fp_sub(b, a) != fp_sub_generic(b, a)) atomicAdd(bad, 1);
-  if (fp_add(a, a) != fp_add_generic(a, a)) atomicAdd(bad, 1);
-  if (fp_sub(a, a) != fp_sub_generic(a, a)) atomicAdd(bad, 1);
+  auto same = [&](const F& x, const F& want) { if (!below_2p(x) || !raw_eq(fp_canonical(x), want)) atomicAdd(bad, 1); };
+  same(fp_mul(a, b), fp_mul_generic(a, b));
+  same(fp_mul(a, a), fp_mul_generic(a, a));
+  same(fp_add(a, b), fp_add_generic(a, b));
+  same(fp_sub(a, b), fp_sub_generic(a, b));
+  same(fp_sub(b, a), fp_sub_generic(b, a));
+  same(fp_add(a, a), fp_add_generic(a, a));
+  same(fp_sub(a, a), fp_sub_generic(a, a));
+  same(fp_neg(a), fp_sub_generic(F::zero(), a));
+  if (fp_sub(a, a).is_zero() != true || (fp_mul(a, b) == fp_mul_generic(a, b)) != true) atomicAdd(bad, 1);
+  if constexpr (F::N == 12) {                  // operands from the upper half of the lazy range
+    F a2 = plus_p(a), b2 = plus_p(b);
+    same(fp_mul(a2, b2), fp_mul_generic(a, b));
+    same(fp_mul(a2, b), fp_mul_generic(a, b));
+    same(fp_add(a2, b2), fp_add_generic(a, b));
+    same(fp_sub(a2, b2), fp_sub_generic(a, b));
+    same(fp_sub(a, b2), fp_sub_generic(a, b));
+    same(fp_sub(a2, b), fp_sub_generic(a, b));
+    same(fp_neg(a2), fp_sub_generic(F::zero(), a));
+    if (!(a2 == a) || (a2 != a) || !fp_sub(a2, a).is_zero() || !raw_eq(fp_from_mont(a2), fp_from_mont(a))) atomicAdd(bad, 1);
+  }
 }
 template <class F> int check_mul(const char* name) {
   const int n = 1 << 16;
@@ -101,7 +127,11 @@ template <class F> int check_mul(const char* name) {
   for (int i = 0; i < n; i++) {
     for (int k = 0; k < F::N; k++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; h[i].l[k] = (uint32_t)(st >> 11); }
     h[i].l[F::N - 1] &= (F::N == 12 ? 0x0fffffffu : 0x3fffffffu);     // < p
-    if (i < 8) { for (int k = 0; k < F::N; k++) h[i].l[k] = (i & 1) ? pm.l[k] : 0; if (i & 1) h[i].l[0] -= (i >> 1) + 1; else h[i].l[0] = i >> 1; }
+    if (i < 8) {                                  // 0, 1, 2, 3 and p-1, p-2, p-3, p-4
+      for (int k = 0; k < F::N; k++) h[i].l[k] = (i & 1) ? pm.l[k] : 0;
+      if (i & 1) { uint64_t br = (i >> 1) + 1; for (int k = 0; k < F::N && br; k++) { uint64_t d = (uint64_t)h[i].l[k] - br; h[i].l[k] = (uint32_t)d; br = (d >> 32) & 1; } }
+      else h[i].l[0] = i >> 1;
+    }
     if (i >= 8 && i < 16) for (int k = 0; k < F::N; k++) h[i].l[k] = (k == F::N - 1) ? (pm.l[k] - 1) : 0xffffffffu;
   }
   F* d; int* bad; int hb = 0;
