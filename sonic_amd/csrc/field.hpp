@@ -77,6 +77,8 @@ struct Fp {
     }
     return t == 0;
   }
+  // all limbs zero: enough wherever zero only ever appears as the literal 0 (the infinity encodings)
+  HD bool is_zero_strict() const { uint32_t t = 0; for (int i = 0; i < N; i++) t |= l[i]; return t == 0; }
   HD bool operator==(const Fp& o) const;
   HD bool operator!=(const Fp& o) const { return !(*this == o); }
 };

@@ -14,13 +14,15 @@ namespace sonic {
 
 struct G1Affine {
   Fq x, y;
-  HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  // infinity is only ever written as literal zeros (never the result of arithmetic), so the strict test is exact even in
+  // the lazy range, where a coordinate congruent to 0 may be stored as q
+  HD bool is_inf() const { return x.is_zero_strict() && y.is_zero_strict(); }
   static HD G1Affine inf() { G1Affine p; p.x = Fq::zero(); p.y = Fq::zero(); return p; }
 };
 
 struct G1XYZZ {
   Fq x, y, zz, zzz;
-  HD bool is_inf() const { return zz.is_zero(); }
+  HD bool is_inf() const { return zz.is_zero_strict(); }     // ZZ = 0 is written, never computed: ZZ3 = ZZ1 * PP with PP != 0
   static HD G1XYZZ inf() {
     G1XYZZ p; p.x = Fq::zero(); p.y = Fq::zero(); p.zz = Fq::zero(); p.zzz = Fq::zero(); return p;
   }
