@@ -30,6 +30,13 @@
 
 namespace sonic {
 
+#ifndef SONIC_PART_LOW_BITS
+#define SONIC_PART_LOW_BITS 8
+#endif
+constexpr int PART_LOW_BITS = SONIC_PART_LOW_BITS;   // buckets per sort partition = 2^PART_LOW_BITS (8..10)
+constexpr int PART_TILE = 1024;            // scalars per workgroup in pass 1
+static_assert(PART_LOW_BITS >= 8 && PART_LOW_BITS <= 10, "k_part_sort scans 256 x {1, 2, 4} counters");
+
 static int g_window_override = 0;
 int msm_window_override() { return g_window_override; }
 void msm_set_window_override(int c) { g_window_override = c; }
@@ -97,7 +104,7 @@ void MsmWorkspace::reserve(long n, const MsmPlan& pl, int k) {
   const size_t sets = (size_t)k * pl.Wb;
   size_t M = sets * pl.NB;
   size_t NW = (size_t)n * pl.W;
-  const size_t part_hn = (size_t)ceil_div((long)pl.Wb * pl.NB, 1L << 10) * (size_t)(ceil_div(n, 1024) + k);   // partitions per job x pass-1 workgroups
+  const size_t part_hn = (size_t)ceil_div((long)pl.Wb * pl.NB, 1L << PART_LOW_BITS) * (size_t)(ceil_div(n, PART_TILE) + k);   // partitions per job x pass-1 workgroups
   count.ensure((2 * part_hn + 4) * 4);
   off.ensure((M + 1) * 4);
   digits.ensure(NW * 4);
@@ -131,12 +138,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // ---- digits + two-pass partition sort ---------------------------------------------------------
 // Every (scalar, window) pair becomes an entry (point index | window | sign) that must end up grouped by its
 // bucket key.  A global histogram with returning atomics plus a random scatter moved ~2 GB per 2^20-term MSM and
-// was bound by L2 atomic throughput.  Instead: pass 1 splits the keys by their high bits into <= 1024 partitions
-// with per-workgroup LDS histograms (k_part_hist, scan, k_part_scatter); pass 2 gives one workgroup per partition
-// (1024 consecutive buckets), which counts the low bits in LDS, scans them into the bucket offsets and places the
+// was bound by L2 atomic throughput.  Instead: pass 1 splits the keys by their high bits into partitions of
+// 2^PART_LOW_BITS consecutive buckets with per-workgroup LDS histograms (k_part_hist, scan, k_part_scatter); pass 2 gives
+// one workgroup per partition, which counts the low bits in LDS, scans them into the bucket offsets and places the
 // entries (k_part_sort).  Order inside a bucket is irrelevant (the sum is commutative), so nothing needs to be stable.
-constexpr int PART_LOW_BITS = 10;
-constexpr int PART_TILE = 1024;            // scalars per workgroup in pass 1
+// Measured at N = 2^20, 2^19 buckets (scatter + sort, ms): 1024-bucket partitions 0.21 + 0.28, 512: 0.26 + 0.20, 256: 0.30 + 0.13.
 
 // kernel-argument view of a batch (by value); tile0[j] = first pass-1 workgroup of job j
 struct MsmBatchDev {
@@ -279,16 +285,17 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
 #pragma unroll
     for (int j = 0; j < B; j++) { const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x; lo[j] = e < end ? part_lo[e] : 0xffffffffu; }
 #pragma unroll
-    for (int j = 0; j < B; j++) if (k0 + j < trips) lds_take(cnt, lo[j] != 0xffffffffu, lo[j] & 1023u);
+    for (int j = 0; j < B; j++) if (k0 + j < trips) lds_take(cnt, lo[j] != 0xffffffffu, lo[j] & ((1u << PART_LOW_BITS) - 1));
   }
   __syncthreads();
-  // exclusive scan of the 1024 counters: 4 per thread + a 256-wide scan
-  uint32_t v[4], ssum = 0;
-  for (int k = 0; k < 4; k++) { v[k] = cnt[threadIdx.x * 4 + k]; ssum += v[k]; }
+  // exclusive scan of the counters: CPT per thread + a 256-wide scan
+  constexpr int CPT = (1 << PART_LOW_BITS) / 256;
+  uint32_t v[CPT], ssum = 0;
+  for (int k = 0; k < CPT; k++) { v[k] = cnt[threadIdx.x * CPT + k]; ssum += v[k]; }
   uint32_t ex = block_exclusive_scan_256(ssum, sc4, nullptr);
-  for (int k = 0; k < 4; k++) {
-    const uint32_t local = (uint32_t)t * (1u << PART_LOW_BITS) + threadIdx.x * 4 + k;
-    cnt[threadIdx.x * 4 + k] = ex;                 // becomes the running cursor
+  for (int k = 0; k < CPT; k++) {
+    const uint32_t local = (uint32_t)t * (1u << PART_LOW_BITS) + threadIdx.x * CPT + k;
+    cnt[threadIdx.x * CPT + k] = ex;               // becomes the running cursor
     if (local < jobstride) off[(uint32_t)job * jobstride + local] = beg + ex;
     ex += v[k];
   }
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
     for (int j = 0; j < B; j++) {
       if (k0 + j >= trips) continue;
       const bool live = lo[j] != 0xffffffffu;
-      const uint32_t pos = lds_take(cnt, live, lo[j] & 1023u);
+      const uint32_t pos = lds_take(cnt, live, lo[j] & ((1u << PART_LOW_BITS) - 1));
       if (live) entries[beg + pos] = pay[j];
     }
   }
