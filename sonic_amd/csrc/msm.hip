@@ -44,7 +44,7 @@ void msm_set_window_override(int c) { g_window_override = c; }
 static constexpr uint32_t HEAVY_SEG = 16384;  // entries per heavy work item (256 threads x 64)
 // Usually there is nothing heavy and the launch only has to notice that; on a chip full of other MSMs' accumulation every
 // workgroup still waits for a free slot (1024 idle workgroups delayed the chain behind them by 1.4-3.4 ms in prove()).
-static int HEAVY_GRID = getenv("SONIC_HEAVY_GRID") ? atoi(getenv("SONIC_HEAVY_GRID")) : 128;
+static constexpr int HEAVY_GRID = 128;
 
 struct HeavyMeta { uint32_t n_items, n_heavy; };
 struct HeavyRec { uint32_t bucket, base, nseg; };
