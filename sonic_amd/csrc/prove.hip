@@ -23,12 +23,19 @@
 namespace sonic {
 
 enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
-// buckets per running-sum segment inside prove(): measured at n = 2^18 (ms per proof): K=2 77.6, 4 63.4, 8 57.0, 16 58.1,
-// 32 61.4, 64 69.7, 128 86.0 -- the reduction's dependent chain, not its work, is what the lanes wait for
-// Below 2^18 buckets the chain length matters more than the work (n = 2^16: K=2 21.5 ms, 4 21.8, 8 22.4; n = 2^14: 13.7, 13.6, 14.4).
+// Buckets per running-sum segment inside prove().  More buckets per segment = fewer small scalar multiplications (less work),
+// fewer = shorter dependent chains.  Batched groups hide their chains under other groups' accumulation, so they take the
+// work-optimal end; the group that finishes last has nothing left to hide under and takes a short chain.  Measured
+// (ms per proof, batched / last): n = 2^18 (2^19 buckets): 16/8 45.9, 32/8 44.3, 64/8 43.2, 64/16 42.6, 64/32 43.7, 128/16 44.6;
+// n = 2^16 (2^16 buckets): 4/4 15.7, 8/4 15.1, 16/4 14.95, 16/8 15.1; n = 2^14: 4/4 7.2, 8/4 6.7, 16/4 6.6.
 static int PROVE_SEGMENT = getenv("SONIC_PROVE_SEGMENT") ? atoi(getenv("SONIC_PROVE_SEGMENT")) : 0;
-// Batched chains (k jobs -> k times the threads) shift the optimum at 2^19 buckets: n = 2^18, K=8 50.3 ms, 16 47.9, 32 47.1, 64 49.1.
-static int prove_segment(const MsmPlan& pl, int k) { return PROVE_SEGMENT > 0 ? PROVE_SEGMENT : (pl.NB >= (1 << 18) ? (k > 1 ? 32 : 8) : 4); }
+static int PROVE_SEGMENT_LAST = getenv("SONIC_PROVE_SEGMENT_LAST") ? atoi(getenv("SONIC_PROVE_SEGMENT_LAST")) : 0;
+static int prove_segment(const MsmPlan& pl, int k, bool last) {
+  const bool big = pl.NB >= (1 << 18);
+  if (last) return PROVE_SEGMENT_LAST > 0 ? PROVE_SEGMENT_LAST : (big ? 16 : 4);
+  if (PROVE_SEGMENT > 0) return PROVE_SEGMENT;
+  return k > 1 ? (big ? 64 : 16) : (big ? 8 : 4);
+}
 
 struct Scratch {
   DevBuf D, q, scan, fz_discard;
@@ -62,13 +69,13 @@ static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, con
   MsmPlan pl = srs_msm_plan(srs, nmax);
   if (k > 1 && msm_can_batch(pl)) {
     // the group that finishes last reduces with nothing left to hide under: shortest chain instead of least work
-    msm_plan_set_segment(pl, last && PROVE_SEGMENT == 0 ? 8 : prove_segment(pl, k));
+    msm_plan_set_segment(pl, prove_segment(pl, k, last));
     msm_enqueue_batch(st, ws, pl, jobs, k, true);
     return;
   }
   for (int j = 0; j < k; j++) {
     MsmPlan p1 = srs_msm_plan(srs, jobs[j].n);
-    msm_plan_set_segment(p1, prove_segment(p1, 1));
+    msm_plan_set_segment(p1, prove_segment(p1, 1, false));
     msm_enqueue_batch(st, ws, p1, &jobs[j], 1, true);
   }
 }
