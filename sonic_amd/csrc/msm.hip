@@ -107,8 +107,7 @@ void MsmWorkspace::reserve(long n, const MsmPlan& pl, int k) {
   const size_t part_hn = (size_t)ceil_div((long)pl.Wb * pl.NB, 1L << PART_LOW_BITS) * (size_t)(ceil_div(n, PART_TILE) + k);   // partitions per job x pass-1 workgroups
   count.ensure((2 * part_hn + 4) * 4);
   off.ensure((M + 1) * 4);
-  digits.ensure(NW * 4);
-  rank.ensure(NW * 4);
+  digits.ensure(NW * 8);
   entries.ensure(NW * 4);
   buckets.ensure(M * sizeof(G1XYZZ));
   segres.ensure((sets * pl.nseg + sets * (pl.nseg / 256 + 1) + 2) * sizeof(G1XYZZ));
@@ -142,7 +141,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // 2^PART_LOW_BITS consecutive buckets with per-workgroup LDS histograms (k_part_hist, scan, k_part_scatter); pass 2 gives
 // one workgroup per partition, which counts the low bits in LDS, scans them into the bucket offsets and places the
 // entries (k_part_sort).  Order inside a bucket is irrelevant (the sum is commutative), so nothing needs to be stable.
-// Measured at N = 2^20, 2^19 buckets (scatter + sort, ms): 1024-bucket partitions 0.21 + 0.28, 512: 0.26 + 0.20, 256: 0.30 + 0.13.
+// Measured at N = 2^20, 2^19 buckets (scatter + sort, ms): 1024-bucket partitions 0.21 + 0.28, 512: 0.26 + 0.20, 256: 0.30 + 0.13;
+// then, at 256: XCD-contiguous tiles (xcd_tile) 0.25 + 0.13, and one 8-B (key, payload) record per entry instead of a 2-B and
+// a 4-B store 0.16 + 0.145.
 
 // kernel-argument view of a batch (by value); tile0[j] = first pass-1 workgroup of job j
 struct MsmBatchDev {
@@ -153,6 +154,15 @@ struct MsmBatchDev {
   long n[MSM_MAX_JOBS];
   MsmSlot* slot[MSM_MAX_JOBS];
 };
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Pass 1 appends to 2^11 partition cursors per
+// job and consecutive tiles append to ADJACENT addresses of every partition, so with tile = blockIdx the 64-B lines under the
+// cursors are shared by workgroups on different XCDs and leave their L2s as partial writes (measured: 0.9 GB of HBM writes for
+// 82 MB of entries).  Giving XCD x the contiguous tile range [x G/8, (x+1) G/8) keeps every line inside one L2.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t G) {
+  const uint32_t x = b & 7u, k = b >> 3, per = G >> 3, rem = G & 7u;
+  return x * per + (x < rem ? x : rem) + k;
+}
+
 __device__ __forceinline__ int batch_job_of_tile(const MsmBatchDev& b, uint32_t tile) {
   int j = 0;
   while (j + 1 < b.k && tile >= b.tile0[j + 1]) j++;
@@ -214,8 +224,9 @@ __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int 
   extern __shared__ uint32_t h[];
   for (int t = threadIdx.x; t < P; t += 256) h[t] = 0;
   __syncthreads();
-  const int job = batch_job_of_tile(batch, blockIdx.x);
-  const uint32_t blk = blockIdx.x - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
+  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int job = batch_job_of_tile(batch, tile);
+  const uint32_t blk = tile - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
   const Fr* __restrict__ sc = batch.scalars[job];
   const long n = batch.n[job];
   for (int k = 0; k < PART_TILE / 256; k++) {
@@ -235,11 +246,11 @@ __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int 
 }
 
 __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
-                                                      const uint32_t* __restrict__ base, uint16_t* __restrict__ part_lo,
-                                                      uint32_t* __restrict__ part_pay) {
+                                                      const uint32_t* __restrict__ base, uint2* __restrict__ part) {
   extern __shared__ uint32_t cur[];
-  const int job = batch_job_of_tile(batch, blockIdx.x);
-  const uint32_t blk = blockIdx.x - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
+  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int job = batch_job_of_tile(batch, tile);
+  const uint32_t blk = tile - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
   const Fr* __restrict__ sc = batch.scalars[job];
   const long n = batch.n[job];
   const uint32_t* in = base + (size_t)P * batch.tile0[job] + blk;
@@ -255,15 +266,15 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
       const uint32_t key = (uint32_t)w * keystride + d - 1;
       const uint32_t pos = lds_take(cur, d != 0, key >> PART_LOW_BITS);
       if (d) {
-        part_lo[pos] = (uint16_t)(key & ((1u << PART_LOW_BITS) - 1));
-        part_pay[pos] = (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (sign << 31);   // index | window (tables only) | sign
+        // one 8-B store per entry: (low key bits, payload = index | window (tables only) | sign)
+        part[pos] = make_uint2(key & ((1u << PART_LOW_BITS) - 1), (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (sign << 31));
       }
     }
   }
 }
 
 // one workgroup per (job, partition): keys [job * jobstride + t * 1024, +1024): bucket offsets and final placement
-__global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_pay,
+__global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, const uint2* __restrict__ part,
                                                    const uint32_t* __restrict__ base, const uint32_t* __restrict__ total, size_t hn, int P,
                                                    uint32_t jobstride, uint32_t* __restrict__ off, uint32_t* __restrict__ entries) {
   __shared__ uint32_t cnt[1 << PART_LOW_BITS];
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
   for (uint32_t k0 = 0; k0 < trips; k0 += B) {
     uint32_t lo[B];
 #pragma unroll
-    for (int j = 0; j < B; j++) { const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x; lo[j] = e < end ? part_lo[e] : 0xffffffffu; }
+    for (int j = 0; j < B; j++) { const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x; lo[j] = e < end ? part[e].x : 0xffffffffu; }
 #pragma unroll
     for (int j = 0; j < B; j++) if (k0 + j < trips) lds_take(cnt, lo[j] != 0xffffffffu, lo[j] & ((1u << PART_LOW_BITS) - 1));
   }
@@ -307,8 +318,9 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
     for (int j = 0; j < B; j++) {
       const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x;
       const bool live = e < end;
-      lo[j] = live ? part_lo[e] : 0xffffffffu;
-      pay[j] = live ? part_pay[e] : 0u;
+      const uint2 rec = live ? part[e] : make_uint2(0xffffffffu, 0u);
+      lo[j] = rec.x;
+      pay[j] = rec.y;
     }
 #pragma unroll
     for (int j = 0; j < B; j++) {
@@ -639,8 +651,8 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
     LAUNCH(k_part_scatter, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, (const uint32_t*)hbase,
-           ws.digits.as<uint16_t>(), ws.rank.as<uint32_t>());
-    LAUNCH(k_part_sort, k * P, 256, 0, st, batch, (const uint16_t*)ws.digits.as<uint16_t>(), (const uint32_t*)ws.rank.as<uint32_t>(),
+           ws.digits.as<uint2>());
+    LAUNCH(k_part_sort, k * P, 256, 0, st, batch, (const uint2*)ws.digits.as<uint2>(),
            (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>());
   }
   {
