@@ -2,6 +2,8 @@
 window plans and scalar patterns the protocol actually produces (zeros, +-1, long runs of one value, small values,
 values near r), every result compared byte for byte with the CPU oracle."""
 import random
+import os
+FUZZ_ROUNDS = int(os.environ.get("SONIC_FUZZ_ROUNDS", "1"))     # SONIC_FUZZ_ROUNDS=20 for a long sweep
 
 import numpy as np
 import pytest
@@ -33,7 +35,7 @@ def _scalars(pyr, n):
     return a
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * FUZZ_ROUNDS))
 def test_msm_fuzz(sonic, orc, seed):
     from sonic_amd import _lib
     from sonic_amd.commitment import msm_g1_srs
@@ -53,7 +55,7 @@ def test_msm_fuzz(sonic, orc, seed):
         _lib.lib().sonic_msm_set_window(0)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(3 * FUZZ_ROUNDS))
 def test_prove_fuzz(sonic, orc, ref, seed):
     """random (n, Q, d) in the range of the reference's own generator (rndCircuit: n <= 20, Q <= n; randomD) and beyond"""
     from util import circuit_arrays
