@@ -105,9 +105,11 @@ def main():
     srs = sonic_amd.SRS.new(d, x, alpha)
     t_srs = time.time() - t0
     from oracle import orc    # cpu_baseline leg + synthetic-input helper only (never in the timed GPU path)
-    circ = big_circuit(1000 + rank, n, Q, orc)
-    prover = sonic_amd.Prover(srs, sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
-    prover.set_assignment(sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"]))
+    prover = None
+    if not args.msm_only:       # --msm-only launches nothing but the stand-alone MSMs (so that a rocprofv3 summary of it is about them)
+        circ = big_circuit(1000 + rank, n, Q, orc)
+        prover = sonic_amd.Prover(srs, sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
+        prover.set_assignment(sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"]))
     tr_rng = np.random.default_rng(77 + rank)
     transcripts = [rand_fr_array(tr_rng, 8 + 2 * Q) for _ in range(K + W)]
     for t in transcripts:
@@ -214,7 +216,10 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_bucket_accum", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "modular-integer kernel: binding roof is v_mad_u64_u32 issue, see int_roofline"}
+                "rocprof_summary": "profiles/r01_msm_only_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --msm-only --no-cpu "
+                                   "--steps 5 --warmup 1: the same N = 2^20 launches and nothing else; profiles/r01_bench_kernel_stats.csv is the full "
+                                   "default run, where the kernel also serves the batched groups of prove())",
+                "note": "modular-integer kernel: the binding roof is VALU issue, see int_roofline"}
     # integer roof: W windows x N mixed additions x 10 Fq products x 288 MADs
     pc, pw_, pb = C.c_int(), C.c_int(), C.c_int()
     L.sonic_msm_plan(srs._h, msm_n, C.byref(pc), C.byref(pw_), C.byref(pb))
