@@ -54,7 +54,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=18, help="mult. gates n = 2^log2n (default: BASELINE configs[2])")
     ap.add_argument("--Q", type=int, default=2)
     ap.add_argument("--msm-log2", type=int, default=20)
-    ap.add_argument("--cpu-log2n", type=int, default=11, help="n of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-log2n", type=int, default=0, help="n of the bounded CPU-baseline sample (0: sized from a probe at n=2^11 "
+                                                              "so that one CPU proof takes <= ~5 s, at most n=2^15)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel HIP-event totals to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
@@ -236,24 +237,35 @@ def main():
 
     cpu_baseline = None
     if not args.no_cpu:
-        cn = 1 << args.cpu_log2n
         cores = os.cpu_count() or 1
         cr = np.random.default_rng(3)
         cx = int.from_bytes(rand_fr_array(cr, 1)[0].tobytes(), "little") | 1
         ca = int.from_bytes(rand_fr_array(cr, 1)[0].tobytes(), "little") | 1
-        osrs = orc.SRS(8 * cn, cx, ca, threads=cores)
-        cc = big_circuit(1, cn, Q, orc)
         ctr = rand_fr_array(cr, 8 + 2 * Q)
         ctr[:, 0] |= 1
         orc.set_mode(1, cores)
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
-            orc.prove(osrs, cn, Q, cc["wL"], cc["wR"], cc["wO"], cc["cs"], cc["aL"], cc["aR"], cc["aO"], ctr, True)
-            reps += 1
-            if time.perf_counter() - t0 > 8 or reps >= 5:
-                break
-        cdt = (time.perf_counter() - t0) / reps
+
+        def cpu_prove_time(lg, budget_s, max_reps):
+            m = 1 << lg
+            osrs_ = orc.SRS(8 * m, cx, ca, threads=cores)
+            cc = big_circuit(1, m, Q, orc)
+            t0_ = time.perf_counter()
+            reps_ = 0
+            while True:
+                orc.prove(osrs_, m, Q, cc["wL"], cc["wR"], cc["wO"], cc["cs"], cc["aL"], cc["aR"], cc["aO"], ctr, True)
+                reps_ += 1
+                if time.perf_counter() - t0_ > budget_s or reps_ >= max_reps:
+                    break
+            return (time.perf_counter() - t0_) / reps_, osrs_
+
+        cpu_lg = args.cpu_log2n
+        if cpu_lg <= 0:     # bounded sample whatever the host: probe at 2^11, then the largest n <= 2^15 whose proof stays under ~5 s
+            probe, _ = cpu_prove_time(11, 0.0, 1)
+            cpu_lg = 11
+            while cpu_lg < 15 and probe * (1 << (cpu_lg + 1 - 11)) <= 5.0:
+                cpu_lg += 1
+        cn = 1 << cpu_lg
+        cdt, osrs = cpu_prove_time(cpu_lg, 12.0, 4)
         cmsm_n = 1 << 16
         csc = rand_fr_array(cr, cmsm_n)
         t0 = time.perf_counter()
@@ -261,7 +273,7 @@ def main():
         cmsm_dt = time.perf_counter() - t0
         cmsm_terms = min(cmsm_n, 16 * cn)
         cpu_baseline = {"value": round(1.0 / cdt, 4), "unit": "proofs/s", "cores": cores, "kind": "port",
-                        "sample": f"oracle/sonic_oracle.c (Pippenger + NTT, {cores} threads) prove() at n=2^{args.cpu_log2n}, Q={Q}, d=8n; "
+                        "sample": f"oracle/sonic_oracle.c (Pippenger + NTT, {cores} threads) prove() at n=2^{cpu_lg}, Q={Q}, d=8n; "
                                   f"{cdt:.2f}s per proof; cost is ~linear in n, so n=2^{args.log2n} would be ~{cdt * (n / cn):.0f}s per proof",
                         "msm_scalar_muls_per_s": round(cmsm_terms / cmsm_dt, 1), "msm_sample": f"N={cmsm_terms} Pippenger, {cores} threads"}
 
