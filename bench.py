@@ -49,8 +49,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=18, help="mult. gates n = 2^log2n (default: BASELINE configs[2])")
     ap.add_argument("--Q", type=int, default=2)
     ap.add_argument("--msm-log2", type=int, default=20)
