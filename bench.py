@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MAD_PEAK_PER_S = 2.79e13       # measured v_mad_u64_u32 issue rate, tools/microbench.hip (profiles/r01_microbench.txt)
-ACCUM_INSTR_PER_ADD = 7485     # static ISA count of one bucket-walk iteration incl. 10 x the 650-instruction Montgomery routine (tools/count_accum_instrs.py; lower bound)
+ACCUM_INSTR_PER_ADD = 7139     # static ISA count of one bucket-walk iteration: 899 around 10 x the 624-instruction product core (tools/count_accum_instrs.py; lower bound)
 VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4    # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_msm.json")   # FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc)
 

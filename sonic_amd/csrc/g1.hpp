@@ -94,6 +94,19 @@ HD G1XYZZ g1_add_mixed(const G1XYZZ& acc, const G1Affine& q) {
   return r;
 }
 
+// The same addition for the bucket walks: on the device the whole formula is one generated asm statement around ten calls of
+// the product core (mont_asm.hpp, sonic_g1_madd_asm); lanes in an exceptional position come back flagged and unchanged and are
+// redone by the general function above.
+HD G1XYZZ g1_add_mixed_walk(G1XYZZ acc, const G1Affine& q) {
+#if SONIC_FQ_LAZY && !defined(SONIC_NO_FUSED_MADD)
+  const uint32_t special = (acc.is_inf() || q.is_inf()) ? 1u : 0u;
+  if (sonic_g1_madd_asm(acc, q.x, q.y, special)) acc = g1_add_mixed(acc, q);
+  return acc;
+#else
+  return g1_add_mixed(acc, q);
+#endif
+}
+
 // p + q, both XYZZ (add-2008-s): 12M + 2S
 HD G1XYZZ g1_add(const G1XYZZ& p, const G1XYZZ& q) {
   if (q.is_inf()) return p;

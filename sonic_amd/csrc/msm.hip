@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
       const uint32_t e_nn = entries[e + 2 <= last ? e + 2 : last];
       const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
       if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
-      acc = g1_add_mixed(acc, p_cur);
+      acc = g1_add_mixed_walk(acc, p_cur);
       p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
     }
   }
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void k_heavy_accum(const MsmBatchDev batch,
         const uint32_t e_nn = entries[e + 512 <= last ? e + 512 : last];
         const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
         if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
-        acc = g1_add_mixed(acc, p_cur);
+        acc = g1_add_mixed_walk(acc, p_cur);
         p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
       }
     }

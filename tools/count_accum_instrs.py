@@ -45,11 +45,14 @@ def main():
                     span = (t, k)
     body = [b for k, b in enumerate(blocks) if span[0] <= k <= span[1] and calls[k] in (0, 10)]   # drops the doubling side path
     outside = sum(len(b[1]) for b in body)
-    routine = next(int(re.search(r"(\d+) instructions", l).group(1)) for l in open(os.path.join(ROOT, "sonic_amd", "csrc", "mont_asm.hpp"))
-                   if "sonic_mont_mul_fq:" in l)
+    # length of the product routine the hot block calls (the core variant when the fused mixed addition is in use)
+    callee = "sonic_mont_mul_fq_core" if any("sonic_mont_mul_fq_core@rel32" in x for x in blocks[hot][1]) else "sonic_mont_mul_fq"
+    i0 = next(i for i, l in enumerate(L) if l.strip() == callee + ":")
+    i1 = next(i for i in range(i0, len(L)) if L[i].strip().startswith(".size\t" + callee) or L[i].strip().startswith(".size " + callee))
+    routine = sum(1 for l in L[i0 + 1:i1] if l.strip() and not l.strip().startswith((";", ".")))
     print("blocks on the hot path:", [(b[0], len(b[1])) for b in body])
     print("instructions outside the Montgomery routine per mixed addition:", outside)
-    print("routine:", routine, "x 10")
+    print("routine:", callee, routine, "x 10")
     print("total per mixed addition:", outside + 10 * routine)
 
 

@@ -40,7 +40,7 @@ class Ins:
         self.deps, self.users, self.prio = set(), set(), 0
 
 
-def build(N: int, p: int, lazy: bool = False):
+def build(N: int, p: int, lazy: bool = False, core: bool = False):
     A = lambda j: j
     B = lambda j: N + j
     TPlo = lambda j: 2 * N + 2 * j
@@ -73,9 +73,10 @@ def build(N: int, p: int, lazy: bool = False):
         else:
             emit(f"v_addc_co_u32_e64 {v(dst)}, {c}, {v(x)}, {v(y)}, {c}", [v(x), v(y), c], [v(dst), c], [c])
 
-    for j in range(N + 1):
-        emit(f"v_mov_b32_e32 {v(TPhi(j))}, 0", [], [v(TPhi(j))])
-    emit(f"v_mov_b32_e32 {v(TPlo(N))}, 0", [], [v(TPlo(N))])
+    if not core:       # the "core" variant is called with the zero halves (and T_N = 0, which every product leaves behind) in place
+        for j in range(N + 1):
+            emit(f"v_mov_b32_e32 {v(TPhi(j))}, 0", [], [v(TPhi(j))])
+        emit(f"v_mov_b32_e32 {v(TPlo(N))}, 0", [], [v(TPlo(N))])
 
     for i in range(N):
         # multiplication row: Q_j = a_j * b_i + T_j
@@ -183,10 +184,170 @@ def schedule(prog):
     return out
 
 
-def function_text(name: str, N: int, p: int, lazy: bool = False):
-    pre, prog, nv, res = build(N, p, lazy)
-    body = pre + schedule(prog) + ["s_setpc_b64 s[30:31]"]
+def function_text(name: str, N: int, p: int, lazy: bool = False, core: bool = False):
+    pre, prog, nv, res = build(N, p, lazy, core)
+    body = ([] if core else pre) + schedule(prog) + ["s_setpc_b64 s[30:31]"]
     return body, nv, res
+
+
+def routine_section(name: str, body, comment: str):
+    """An out-of-line routine emitted from inside an asm statement into its own text section (see cxx())."""
+    NL = "\\n\\t"
+    lines = [comment, f'extern "C" __device__ __attribute__((noinline, used)) void {name}_holder() {{', "  asm volatile(",
+             f'      ".pushsection .text.{name},\\"ax\\",@progbits{NL}"', f'      ".p2align 8{NL}"', f'      ".type {name},@function{NL}"',
+             f'      "{name}:{NL}"']
+    for l in body:
+        lines.append(f'      "{l}{NL}"')
+    lines += [f'      ".size {name}, .-{name}{NL}"', f'      ".popsection{NL}"', "  );", "}"]
+    return lines
+
+
+def limb32(v: int, j: int) -> int:
+    return (v >> (32 * j)) & 0xFFFFFFFF
+
+
+def emit_addsub(L, N, sub, out, a, b, D, Pv, CA, p2):
+    """out = a -/+ b in the lazy range, same two-chain pattern as addsub_cxx, on explicit register names (strings)."""
+    opA0, opA = ("v_sub_co_u32_e64", "v_subb_co_u32_e64") if sub else ("v_add_co_u32_e64", "v_addc_co_u32_e64")
+    opB0, opB = ("v_add_co_u32_e32", "v_addc_co_u32_e32") if sub else ("v_sub_co_u32_e32", "v_subb_co_u32_e32")
+    for j in range(N):
+        L.append(f"v_mov_b32_e32 {Pv[j]}, 0x{limb32(p2, j):08x}")
+        if j == 0:
+            L.append(f"{opA0} {D[0]}, {CA}, {a[0]}, {b[0]}")
+        else:
+            L.append(f"{opA} {D[j]}, {CA}, {a[j]}, {b[j]}, {CA}")
+        if j == 1:
+            L.append(f"{opB0} {out[0]}, vcc, {D[0]}, {Pv[0]}")
+        elif j >= 2:
+            L.append(f"{opB} {out[j - 1]}, vcc, {D[j - 1]}, {Pv[j - 1]}, vcc")
+        else:
+            L.append("s_nop 0")
+    L.append("s_nop 1")
+    L.append(f"{opB} {out[N - 1]}, vcc, {D[N - 1]}, {Pv[N - 1]}, vcc")
+    L.append("s_nop 1")
+    for j in range(N):
+        if sub:
+            L.append(f"v_cndmask_b32_e64 {out[j]}, {D[j]}, {out[j]}, {CA}")
+        else:
+            L.append(f"v_cndmask_b32_e32 {out[j]}, {out[j]}, {D[j]}, vcc")
+
+
+def fused_madd_cxx(p: int) -> str:
+    """acc += q (XYZZ + affine, madd-2008-s) as ONE asm statement around ten calls of the product core.
+    What it saves against ten separate product calls from C++ (per addition): the 25 zero-half initialisations of nine products
+    (the zero halves and the modulus SGPRs persist across the calls), ~200 of the ~450 marshalling / merge moves (operands are
+    routed between the core's fixed registers and four temporary banks by plan: the sub / add blocks write straight into the
+    core's A operand or into the accumulator's registers), and every compiler-made copy.
+    Lanes in an exceptional position (an infinity operand, or U2 = X1: doubling / cancellation) are switched off with EXEC before
+    anything is written back and reported in `exc`: the caller redoes them with the general C++ addition."""
+    N = 12
+    A = [f"v{j}" for j in range(N)]
+    B = [f"v{N + j}" for j in range(N)]
+    T = [f"v{2 * N + 2 * j}" for j in range(N)]
+    TPhi = [f"v{2 * N + 2 * j + 1}" for j in range(N + 1)]
+    TPloN = f"v{2 * N + 2 * N}"
+    SCR = [f"v{4 * N + 2 + j}" for j in range(2 * N)]          # the Q pairs: free between products
+    D, Pv = SCR[:N], SCR[N:]
+    base = 6 * N + 3                                           # 75
+    R1 = [f"v{base + j}" for j in range(N)]                    # R
+    R2 = [f"v{base + N + j}" for j in range(N)]                # PPP
+    R3 = [f"v{base + 2 * N + j}" for j in range(N)]            # Q
+    R4 = [f"v{base + 3 * N + j}" for j in range(N)]            # R * (Q - X3)
+    nv = base + 4 * N
+    ACCX = [f"%{j}" for j in range(N)]
+    ACCY = [f"%{N + j}" for j in range(N)]
+    ACCZZ = [f"%{2 * N + j}" for j in range(N)]
+    ACCZZZ = [f"%{3 * N + j}" for j in range(N)]
+    EXC = f"%{4 * N}"
+    QX = [f"%{4 * N + 1 + j}" for j in range(N)]
+    QY = [f"%{5 * N + 1 + j}" for j in range(N)]
+    SPECIAL = f"%{6 * N + 1}"
+    CA, SAVE, MASK, TMPM = "s[58:59]", "s[60:61]", "s[62:63]", "s[64:65]"
+    inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+    L = []
+    mov = lambda dst, src: [L.append(f"v_mov_b32_e32 {dst[j]}, {src[j]}") for j in range(N)]
+
+    def call():
+        L.append("s_getpc_b64 s[56:57]")
+        L.append("s_add_u32 s56, s56, sonic_mont_mul_fq_core@rel32@lo+4")
+        L.append("s_addc_u32 s57, s57, sonic_mont_mul_fq_core@rel32@hi+12")
+        L.append("s_swappc_b64 s[30:31], s[56:57]")
+
+    # prologue: modulus limbs / -p^-1 in SGPRs, zero halves of the T pairs, T_N = 0
+    for j in range(N):
+        L.append(f"s_mov_b32 s{36 + j}, 0x{limb32(p, j):08x}")
+    L.append(f"s_mov_b32 s{36 + N}, 0x{inv:08x}")
+    for r in TPhi:
+        L.append(f"v_mov_b32_e32 {r}, 0")
+    L.append(f"v_mov_b32_e32 {TPloN}, 0")
+    L.append(f"s_mov_b64 {SAVE}, exec")
+    # 1. S2 = q.y * ZZZ1;  R = S2 - Y1
+    mov(A, QY); mov(B, ACCZZZ); call()
+    emit_addsub(L, N, True, R1, T, ACCY, D, Pv, CA, 2 * p)
+    # 2. U2 = q.x * ZZ1;  P = U2 - X1 (into A), exceptional lanes off
+    mov(A, QX); mov(B, ACCZZ); call()
+    emit_addsub(L, N, True, A, T, ACCX, D, Pv, CA, 2 * p)
+    #    P == 0 (as 0 or as p)?  t = OR limbs, u = OR (limb ^ p_j)
+    L.append(f"v_or3_b32 {D[0]}, {A[0]}, {A[1]}, {A[2]}")
+    for k in range(3, N, 2):
+        L.append(f"v_or3_b32 {D[0]}, {D[0]}, {A[k]}, {A[k + 1]}" if k + 1 < N else f"v_or_b32_e32 {D[0]}, {D[0]}, {A[k]}")
+    for j in range(N):
+        L.append(f"v_xor_b32_e32 {Pv[j]}, 0x{limb32(p, j):08x}, {A[j]}")
+    L.append(f"v_or3_b32 {D[1]}, {Pv[0]}, {Pv[1]}, {Pv[2]}")
+    for k in range(3, N, 2):
+        L.append(f"v_or3_b32 {D[1]}, {D[1]}, {Pv[k]}, {Pv[k + 1]}" if k + 1 < N else f"v_or_b32_e32 {D[1]}, {D[1]}, {Pv[k]}")
+    L.append(f"v_cmp_eq_u32_e64 {MASK}, 0, {D[0]}")
+    L.append(f"v_cmp_eq_u32_e64 {TMPM}, 0, {D[1]}")
+    L.append("s_nop 4")
+    L.append(f"s_or_b64 {MASK}, {MASK}, {TMPM}")
+    L.append(f"v_cmp_ne_u32_e64 {TMPM}, 0, {SPECIAL}")
+    L.append("s_nop 4")
+    L.append(f"s_or_b64 {MASK}, {MASK}, {TMPM}")
+    L.append("s_nop 4")
+    L.append(f"v_cndmask_b32_e64 {EXC}, 0, 1, {MASK}")
+    L.append(f"s_andn2_b64 exec, exec, {MASK}")
+    mov(B, A)
+    # 3. PP = P^2
+    call()
+    mov(B, T)
+    # 4. PPP = P * PP
+    call()
+    mov(R2, T)
+    # 5. Q = X1 * PP
+    mov(A, ACCX); call()
+    mov(R3, T)
+    # 6. ZZ3 = ZZ1 * PP
+    mov(A, ACCZZ); call()
+    mov(ACCZZ, T)
+    # 7. ZZZ3 = ZZZ1 * PPP
+    mov(A, ACCZZZ); mov(B, R2); call()
+    mov(ACCZZZ, T)
+    # 8. X3 = R^2 - PPP - 2 Q  (into the accumulator);  Q - X3 (into A)
+    mov(A, R1); mov(B, R1); call()
+    emit_addsub(L, N, True, R4, T, R2, D, Pv, CA, 2 * p)            # R^2 - PPP       (R4 is free until step 9)
+    emit_addsub(L, N, False, B, R3, R3, D, Pv, CA, 2 * p)           # 2 Q             (B is rewritten in step 9)
+    emit_addsub(L, N, True, ACCX, R4, B, D, Pv, CA, 2 * p)          # X3
+    emit_addsub(L, N, True, A, R3, ACCX, D, Pv, CA, 2 * p)          # Q - X3
+    # 9. R * (Q - X3)
+    mov(B, R1); call()
+    mov(R4, T)
+    # 10. Y1 * PPP;  Y3 = R (Q - X3) - Y1 PPP
+    mov(A, ACCY); mov(B, R2); call()
+    emit_addsub(L, N, True, ACCY, R4, T, D, Pv, CA, 2 * p)
+    L.append(f"s_mov_b64 exec, {SAVE}")
+    n_mov = sum(1 for l in L if l.startswith("v_mov_b32"))
+    NLs = "\\n\\t"
+    outs = [f'"+v"(acc.x.l[{j}])' for j in range(N)] + [f'"+v"(acc.y.l[{j}])' for j in range(N)] + \
+           [f'"+v"(acc.zz.l[{j}])' for j in range(N)] + [f'"+v"(acc.zzz.l[{j}])' for j in range(N)] + ['"=&v"(exc)']
+    ins = [f'"v"(qx.l[{j}])' for j in range(N)] + [f'"v"(qy.l[{j}])' for j in range(N)] + ['"v"(special)']
+    clob = [f'"v{k}"' for k in range(nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 66))] + ['"vcc"', '"scc"']
+    head = [f"// sonic_g1_madd_asm: {len(L)} instructions around 10 calls of sonic_mont_mul_fq_core ({n_mov} v_mov), VGPRs v0..v{nv - 1}",
+            "template <class XYZZ, class F> __device__ __forceinline__ bool sonic_g1_madd_asm(XYZZ& acc, const F& qx, const F& qy, uint32_t special) {",
+            "  uint32_t exc;", "  asm volatile("]
+    body = [f'      "{l}{NLs}"' for l in L[:-1]] + [f'      "{L[-1]}"']
+    tail = [f"      : {', '.join(outs)}", f"      : {', '.join(ins)}", f"      : {', '.join(clob)});", "  return exc != 0;", "}"]
+    return "\n".join(head + body + tail)
+
 
 
 def cxx(name: str, cls: str, N: int, p: int, lazy: bool = False) -> str:
@@ -297,6 +458,11 @@ def main():
            cxx("sonic_mont_mul_fq", "Fp<FqParams>", 12, Q, lazy=True),
            "",
            cxx("sonic_mont_mul_fr", "Fp<FrParams>", 8, R),
+           "",
+           "\n".join(routine_section("sonic_mont_mul_fq_core", function_text("sonic_mont_mul_fq_core", 12, Q, lazy=True, core=True)[0],
+                                     "// sonic_mont_mul_fq_core: the lazy Fq product without its prologue (modulus SGPRs, zero halves): callers keep those in place")),
+           "",
+           fused_madd_cxx(Q),
            "",
            addsub_cxx("sonic_fq_sub_asm", "Fp<P>", 12, True),
            addsub_cxx("sonic_fq_add_asm", "Fp<P>", 12, False),

@@ -69,6 +69,12 @@ __global__ __launch_bounds__(256) void k_madd(G1XYZZ* out, const G1Affine* pts, 
   for (int i = 0; i < iters; i++) acc = g1_add_mixed(acc, pts[(t + i * 7919) & 4095]);
   out[t] = acc;
 }
+__global__ __launch_bounds__(256) void k_madd_walk(G1XYZZ* out, const G1Affine* pts, int iters) {
+  G1XYZZ acc = G1XYZZ::inf();
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; i < iters; i++) acc = g1_add_mixed_walk(acc, pts[(t + i * 7919) & 4095]);
+  out[t] = acc;
+}
 __global__ void k_mkpts(G1Affine* pts) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   G1Affine g; uint32_t gx[12] = G1_GEN_X_MONT, gy[12] = G1_GEN_Y_MONT;
@@ -143,7 +149,7 @@ template <class F> int check_mul(const char* name) {
   return hb;
 }
 
-__global__ void k_check_dbl(const G1Affine* pts, int n, int* bad, int c) {
+__global__ __launch_bounds__(256) void k_check_dbl(const G1Affine* pts, int n, int* bad, int c) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   G1Affine p = pts[t];
@@ -157,6 +163,27 @@ __global__ void k_check_dbl(const G1Affine* pts, int n, int* bad, int c) {
   G1XYZZ d2 = g1_dbl(G1XYZZ::from_affine(p));
   G1Affine u = g1_to_affine(c2), v = g1_to_affine(d2);
   if (u.x != v.x || u.y != v.y) atomicAdd(bad + 1, 1);
+  // the fused bucket-walk addition against the general one: general position (a few steps), and every exceptional position
+  auto same = [&](const G1XYZZ& a, const G1XYZZ& b) {
+    G1Affine s1 = g1_to_affine(a), s2 = g1_to_affine(b);
+    if (a.is_inf() != b.is_inf() || s1.x != s2.x || s1.y != s2.y) atomicAdd(bad + 2, 1);
+  };
+  G1XYZZ w1 = a, w2 = a;
+  for (int k = 0; k < 6; k++) {
+    G1Affine q = pts[(t * 5 + 7 * k + 1) % n];
+    if (k & 1) q = g1_neg(q);
+    w1 = g1_add_mixed_walk(w1, q); w2 = g1_add_mixed(w2, q);
+  }
+  same(w1, w2);
+  same(g1_add_mixed_walk(G1XYZZ::inf(), p), G1XYZZ::from_affine(p));            // accumulator at infinity
+  same(g1_add_mixed_walk(a, G1Affine::inf()), a);                               // point at infinity
+  same(g1_add_mixed_walk(G1XYZZ::from_affine(p), p), d2);                       // P + P
+  same(g1_add_mixed_walk(d2, g1_to_affine(d2)), g1_dbl(d2));                    // P + P with a non-trivial ZZ
+  same(g1_add_mixed_walk(G1XYZZ::from_affine(p), g1_neg(p)), G1XYZZ::inf());    // P + (-P)
+  same(g1_add_mixed_walk(d2, g1_neg(g1_to_affine(d2))), G1XYZZ::inf());
+  // half of the wave exceptional, half not (EXEC masking inside the statement)
+  G1Affine qm = (t & 1) ? p : pts[(t + 3) % n];
+  same(g1_add_mixed_walk(G1XYZZ::from_affine(p), qm), g1_add_mixed(G1XYZZ::from_affine(p), qm));
 }
 
 template <class F> float time_ms(F f, int reps) {
@@ -175,9 +202,9 @@ int main() {
   void* buf; CK(hipMalloc(&buf, (size_t)blocks * threads * sizeof(G1XYZZ)));
   G1Affine* pts; CK(hipMalloc(&pts, 4096 * sizeof(G1Affine)));
   hipLaunchKernelGGL(k_mkpts, 16, 256, 0, 0, pts); CK(hipDeviceSynchronize());
-  { int* bad; int hb[2] = {0, 0}; hipMalloc(&bad, 8); hipMemset(bad, 0, 8);
-    hipLaunchKernelGGL(k_check_dbl, 16, 256, 0, 0, (const G1Affine*)pts, 4096, bad, 11); hipMemcpy(hb, bad, 8, hipMemcpyDeviceToHost);
-    printf("dbl_affine^11 vs mul_small(2^11): %d mismatches; add_mixed(P,P) vs dbl: %d mismatches\n", hb[0], hb[1]); }
+  { int* bad; int hb[3] = {0, 0, 0}; hipMalloc(&bad, 12); hipMemset(bad, 0, 12);
+    hipLaunchKernelGGL(k_check_dbl, 16, 256, 0, 0, (const G1Affine*)pts, 4096, bad, 11); hipMemcpy(hb, bad, 12, hipMemcpyDeviceToHost);
+    printf("dbl_affine^11 vs mul_small(2^11): %d mismatches; add_mixed(P,P) vs dbl: %d mismatches; fused walk addition vs general (incl. exceptional lanes): %d mismatches\n", hb[0], hb[1], hb[2]); }
   const double lanes = (double)blocks * threads;
   { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_mad, blocks, threads, 0, 0, (uint64_t*)buf, 12345u, 67891u, it); }, 10);
     printf("v_mad_u64_u32: %.3f ms -> %.3e mad/s  (%.2f lane-ops/clk/CU at 2.4GHz)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
@@ -191,5 +218,7 @@ int main() {
     printf("fq_mul:        %.3f ms -> %.3e mul/s\n", ms, lanes * it * 2 / (ms * 1e-3)); }
   { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
     printf("g1_add_mixed:  %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
+  { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd_walk, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
+    printf("g1_add_mixed_walk (fused asm): %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
   return 0;
 }
