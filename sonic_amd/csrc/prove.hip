@@ -3,9 +3,10 @@
 // plus the C-ABI faces of Sonic.SRS.new, commitPoly and openPoly.
 //
 // Everything between "inputs in HBM" and "7+4Q window-sum slots + 3+2Q field elements in HBM" is
-// device work queued on one stream with no host synchronisation: the `rnd` draws are explicit
-// (transcript), so no step waits for a result.  The host then runs the O(W) tails of the MSMs
-// (msm_finish_host) and lays out the proof bytes.
+// device work queued with no host synchronisation: the `rnd` draws are explicit (transcript), so no
+// step waits for a result.  The main stream builds the polynomials, a side stream the t(X,y) product,
+// and the MSMs that depend on one polynomial run as one batched chain on an MSM lane.
+// The host then runs the O(W) tails of the MSMs (msm_finish_host) and lays out the proof bytes.
 //
 // Each reference step is done once: the reference re-evaluates evalY 1 polyR' three times
 // (Protocol.hs:63,79,80), evalY y tXY twice (:72,81) and evalY y_j sXY twice per j

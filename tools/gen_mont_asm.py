@@ -17,8 +17,10 @@ Algorithm (row-wise CIOS with "zero-high" accumulator pairs):
   and consume their outputs (list scheduling below), so no s_nop is needed in the steady state.
 
 Calling convention (private, not the C ABI): a in v[0:N), b in v[N:2N), result in v[0:N);
-return address s[30:31]; clobbers v[2N : 6N+3), s[36:57], vcc, scc.  The C++ wrapper marshals with
-physical-register constraints and calls with s_swappc_b64.
+return address s[30:31]; clobbers v[2N : 6N+3), s[36:57], vcc, scc.  The C++ wrapper binds operands with generic "v"
+constraints, moves them to / from the routine's fixed registers inside the asm text and calls with s_swappc_b64.
+Fq runs in the lazy range [0, 2q) (no final conditional subtraction; result in the low halves of T); the "core" variant
+leaves the prologue to its caller, the fused mixed addition sonic_g1_madd_asm (fused_madd_cxx below).
 
 Run from the repo root:  python tools/gen_mont_asm.py
 """
