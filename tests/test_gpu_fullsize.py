@@ -73,7 +73,15 @@ def test_prove_full_size_exponent_oracle(sonic, orc, log2n):
     tr = [pyr.randrange(2, R) for _ in range(8 + 2 * Q)]
     p = sonic.Prover(srs, sonic.ArithCircuit(sonic.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
     p.set_assignment(sonic.Assignment(circ["aL"], circ["aR"], circ["aO"]))
-    proof = sonic.Proof.from_bytes(p.prove_bytes(fr_bytes(tr)), Q)
+    raw = p.prove_bytes(fr_bytes(tr))
+    proof = sonic.Proof.from_bytes(raw, Q)
+    if log2n == 18:
+        # the same proof from a handle that did not commit the constraint rows: S_j then is one 3n-term MSM whose scalars are
+        # 2n copies of two values (rndCircuit's all-ones rows) -- 26 buckets of 2^18 entries through the heavy-bucket path
+        p2 = sonic.Prover(srs, sonic.ArithCircuit(sonic.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]), prepare=False)
+        p2.set_assignment(sonic.Assignment(circ["aL"], circ["aR"], circ["aO"]))
+        assert p2.prove_bytes(fr_bytes(tr)) == raw
+        p2.close()
 
     cns, y, z = tr[0:4], tr[4], tr[5]
     ys, zs, u, v = tr[6:6 + Q], tr[6 + Q:6 + 2 * Q], tr[6 + 2 * Q], tr[7 + 2 * Q]
