@@ -1,0 +1,270 @@
+"""CPU model of the generated gfx950 assembly (tools/gen_mont_asm.py -> sonic_amd/csrc/mont_asm.hpp).
+
+The Montgomery products, the add / sub blocks and the fused mixed addition are straight-line programs over a small
+instruction subset, so they can be executed here on python integers, one lane at a time, without a GPU:
+  * the product routines give a * b * R^-1 (mod p): canonical for Fr, in the lazy range [0, 2q) for Fq, also for
+    operands taken from [q, 2q); the "core" variant gives the same when its caller provides the zero halves;
+  * no VALU instruction reads a carry (VCC / SGPR pair) within two issue slots of the VALU write that produced it
+    (the gfx950 hazard the schedules are built around);
+  * the fused mixed addition equals the XYZZ formulas (madd-2008-s) on random operands in both representatives, leaves
+    the accumulator untouched and raises its flag for every exceptional lane (infinity operand, P = +-Q).
+What the real hardware does with these instructions is checked by tools/microbench.hip and the -m gpu tests."""
+import os
+import random
+import re
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import gen_mont_asm as G  # noqa: E402
+
+M32 = 0xFFFFFFFF
+
+
+class Lane:
+    """One lane of a wave: 32-bit VGPRs / SGPRs, 1-bit carries, EXEC as a boolean."""
+
+    def __init__(self, core_prog=None):
+        self.v, self.s, self.c, self.exec, self.saved = {}, {}, {}, True, {}
+        self.core_prog = core_prog
+        self.trace = []          # (kind, carry-register) per issued instruction, for the hazard check
+
+    def rd(self, tok):
+        tok = tok.strip()
+        if tok.startswith("0x"):
+            return int(tok, 16)
+        if tok.isdigit():
+            return int(tok)
+        if tok[0] == "s":
+            return self.s[tok]
+        return self.v.get(tok, 0xDEADBEEF) if tok not in self.v else self.v[tok]
+
+    def wr(self, tok, val):
+        if self.exec:
+            self.v[tok.strip()] = val & M32
+
+    def pair(self, tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok.strip())
+        return f"v{m.group(1)}", f"v{m.group(2)}"
+
+    def run(self, prog):
+        for ins in prog:
+            self.step(ins)
+
+    def step(self, ins):
+        op, _, rest = ins.partition(" ")
+        a = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)] if rest else []
+        carry_read, carry_write = None, None
+        if op == "s_nop":
+            self.trace.extend([("nop", None, None)] * (int(a[0]) + 1))
+            return
+        if op in ("s_setpc_b64", "s_getpc_b64", "s_add_u32", "s_addc_u32"):
+            return
+        if op == "s_swappc_b64":
+            assert self.core_prog is not None
+            self.run(self.core_prog)
+            return
+        if op == "s_mov_b32":
+            self.s[a[0]] = self.rd(a[1])
+            return
+        if op == "s_mov_b64":
+            if a[0] == "exec":
+                self.exec = self.saved[a[1]]
+            else:
+                self.saved[a[0]] = self.exec
+            return
+        if op == "s_or_b64":
+            self.c[a[0]] = self.c[a[1]] | self.c[a[2]]
+            return
+        if op == "s_andn2_b64":
+            assert a[0] == "exec" and a[1] == "exec"
+            self.exec = self.exec and not self.c[a[2]]
+            return
+        # ---- VALU ----
+        if op == "v_mov_b32_e32":
+            self.wr(a[0], self.rd(a[1]))
+        elif op == "v_mad_u64_u32":
+            lo, hi = self.pair(a[0])
+            add = 0 if a[4] == "0" else (self.rd(self.pair(a[4])[0]) | (self.rd(self.pair(a[4])[1]) << 32))
+            r = self.rd(a[2]) * self.rd(a[3]) + add
+            assert r < 1 << 64, "v_mad_u64_u32 overflow: the zero-high invariant is broken"
+            self.wr(lo, r)
+            self.wr(hi, r >> 32)
+        elif op == "v_mul_lo_u32":
+            self.wr(a[0], self.rd(a[1]) * self.rd(a[2]))
+        elif op in ("v_add_co_u32_e32", "v_add_co_u32_e64", "v_sub_co_u32_e32", "v_sub_co_u32_e64"):
+            x, y = self.rd(a[2]), self.rd(a[3])
+            r = x + y if "add" in op else x - y
+            self.wr(a[0], r)
+            if self.exec:
+                self.c[a[1]] = int(r > M32 or r < 0)
+            carry_write = a[1]
+        elif op in ("v_addc_co_u32_e32", "v_addc_co_u32_e64", "v_subb_co_u32_e32", "v_subb_co_u32_e64"):
+            x, y, cin = self.rd(a[2]), self.rd(a[3]), self.c[a[4]]
+            r = x + y + cin if "addc" in op else x - y - cin
+            self.wr(a[0], r)
+            if self.exec:
+                self.c[a[1]] = int(r > M32 or r < 0)
+            carry_read, carry_write = a[4], a[1]
+        elif op in ("v_cndmask_b32_e64", "v_cndmask_b32_e32"):
+            self.wr(a[0], self.rd(a[2]) if self.c[a[3]] else self.rd(a[1]))
+            carry_read = a[3]
+        elif op == "v_or3_b32":
+            self.wr(a[0], self.rd(a[1]) | self.rd(a[2]) | self.rd(a[3]))
+        elif op == "v_or_b32_e32":
+            self.wr(a[0], self.rd(a[1]) | self.rd(a[2]))
+        elif op == "v_xor_b32_e32":
+            self.wr(a[0], self.rd(a[1]) ^ self.rd(a[2]))
+        elif op in ("v_cmp_eq_u32_e64", "v_cmp_ne_u32_e64"):
+            eq = self.rd(a[1]) == self.rd(a[2])
+            self.c[a[0]] = int(self.exec and (eq if "eq" in op else not eq))
+            carry_write = a[0]
+        else:
+            raise AssertionError("instruction not modelled: " + ins)
+        self.trace.append(("valu", carry_read, carry_write))
+
+    def check_carry_hazard(self):
+        last_write = {}
+        for k, (kind, rd, wr) in enumerate(self.trace):
+            if kind == "valu" and rd is not None and rd in last_write:
+                assert k - last_write[rd] > G.CARRY_GAP, f"VALU reads {rd} {k - last_write[rd]} slots after its VALU write"
+            if wr is not None:
+                last_write[wr] = k
+
+
+def limbs(x, n):
+    return [(x >> (32 * i)) & M32 for i in range(n)]
+
+
+def unlimbs(ws):
+    return sum(w << (32 * i) for i, w in enumerate(ws))
+
+
+def run_mul(name, N, p, lazy, a, b, core=False):
+    body, nv, res = G.function_text(name, N, p, lazy=lazy, core=core)
+    lane = Lane()
+    if core:   # what the fused caller provides: modulus SGPRs, zero halves, T_N = 0
+        inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+        for j in range(N):
+            lane.s[f"s{36 + j}"] = (p >> (32 * j)) & M32
+        lane.s[f"s{36 + N}"] = inv
+        for j in range(N + 1):
+            lane.v[f"v{2 * N + 2 * j + 1}"] = 0
+        lane.v[f"v{2 * N + 2 * N}"] = 0
+    for j in range(N):
+        lane.v[f"v{j}"] = limbs(a, N)[j]
+        lane.v[f"v{N + j}"] = limbs(b, N)[j]
+    lane.run(body)
+    lane.check_carry_hazard()
+    return unlimbs([lane.v[f"v{r}"] for r in res]), lane
+
+
+def operands(rng, p, hi):
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 1 << 255, (1 << 32) - 1]
+    if hi > p:
+        edge += [p, p + 1, 2 * p - 1]
+    return [v for v in edge if v < hi] + [rng.randrange(hi) for _ in range(24)]
+
+
+@pytest.mark.parametrize("name,N,p,lazy,core", [("fq", 12, G.Q, True, False), ("fq_core", 12, G.Q, True, True), ("fr", 8, G.R, False, False)])
+def test_montgomery_product_model(name, N, p, lazy, core):
+    rng = random.Random(100 + N + core)
+    Rm = 1 << (32 * N)
+    hi = 2 * p if lazy else p
+    ops = operands(rng, p, hi)
+    for a in ops:
+        for b in (ops[rng.randrange(len(ops))], ops[rng.randrange(len(ops))], a):
+            r, _ = run_mul(name, N, p, lazy, a, b, core)
+            assert r % p == a * b * pow(Rm, -1, p) % p, (name, hex(a), hex(b))
+            assert r < (2 * p if lazy else p), (name, "range", hex(a), hex(b))
+
+
+@pytest.mark.parametrize("sub", [True, False])
+def test_add_sub_block_model(sub):
+    N, p = 12, G.Q
+    rng = random.Random(7 + sub)
+    out = [f"v{100 + j}" for j in range(N)]
+    ar = [f"v{j}" for j in range(N)]
+    br = [f"v{20 + j}" for j in range(N)]
+    D = [f"v{40 + j}" for j in range(N)]
+    Pv = [f"v{60 + j}" for j in range(N)]
+    L = []
+    G.emit_addsub(L, N, sub, out, ar, br, D, Pv, "s[58:59]", 2 * p)
+    ops = operands(rng, p, 2 * p)
+    for a in ops:
+        for b in ops[:12] + [a]:
+            lane = Lane()
+            for j in range(N):
+                lane.v[ar[j]], lane.v[br[j]] = limbs(a, N)[j], limbs(b, N)[j]
+            lane.run(L)
+            lane.check_carry_hazard()
+            r = unlimbs([lane.v[x] for x in out])
+            assert r < 2 * p and r % p == ((a - b) if sub else (a + b)) % p
+
+
+# ---- the fused mixed addition -------------------------------------------------------------------------------------
+def xyzz_madd(p, X1, Y1, ZZ1, ZZZ1, x2, y2):
+    """madd-2008-s on integers mod p (values are Montgomery residues: products carry R^-1)."""
+    Ri = pow(1 << 384, -1, p)
+    mul = lambda a, b: a * b * Ri % p
+    U2, S2 = mul(x2, ZZ1), mul(y2, ZZZ1)
+    P, Rr = (U2 - X1) % p, (S2 - Y1) % p
+    if P == 0:
+        return None
+    PP = mul(P, P)
+    PPP = mul(P, PP)
+    Qv = mul(X1, PP)
+    X3 = (mul(Rr, Rr) - PPP - 2 * Qv) % p
+    Y3 = (mul(Rr, (Qv - X3) % p) - mul(Y1, PPP)) % p
+    return X3, Y3, mul(ZZ1, PP), mul(ZZZ1, PPP)
+
+
+def run_fused(acc, q, special):
+    N, p = 12, G.Q
+    L, nv = G.fused_madd_program(p)
+    core, _, _ = G.function_text("core", N, p, lazy=True, core=True)
+    lane = Lane(core_prog=core)
+    for k in range(4):
+        for j in range(N):
+            lane.v[f"%{k * N + j}"] = limbs(acc[k], N)[j]
+    for k in range(2):
+        for j in range(N):
+            lane.v[f"%{4 * N + 1 + k * N + j}"] = limbs(q[k], N)[j]
+    lane.v[f"%{6 * N + 1}"] = special
+    lane.run(L)
+    assert lane.exec is True, "EXEC not restored"
+    out = [unlimbs([lane.v[f"%{k * N + j}"] for j in range(N)]) for k in range(4)]
+    return out, lane.v[f"%{4 * N}"]
+
+
+def test_fused_mixed_addition_model():
+    p = G.Q
+    rng = random.Random(2024)
+    rep = lambda v: v + p if (rng.random() < 0.5 and v + p < 2 * p) else v          # either representative of the residue
+    for _ in range(12):
+        acc = [rng.randrange(p) for _ in range(4)]
+        q = [rng.randrange(p) for _ in range(2)]
+        want = xyzz_madd(p, *acc, *q)
+        got, exc = run_fused([rep(v) for v in acc], [rep(v) for v in q], 0)
+        assert exc == 0 and all(g < 2 * p for g in got)
+        assert [g % p for g in got] == list(want)
+    # U2 == X1 (the doubling / cancellation position): flagged, accumulator untouched -- with U2 - X1 represented as 0 or as q
+    Ri = pow(1 << 384, -1, p)
+    for bump in (0, p):
+        acc = [rng.randrange(p) for _ in range(4)]
+        q = [rng.randrange(p) for _ in range(2)]
+        acc[0] = q[0] * acc[2] * Ri % p + bump if q[0] * acc[2] * Ri % p + bump < 2 * p else q[0] * acc[2] * Ri % p
+        got, exc = run_fused(acc, q, 0)
+        assert exc == 1 and got == acc
+    # an operand at infinity is announced by the caller: flagged, untouched
+    acc = [rng.randrange(p) for _ in range(4)]
+    q = [rng.randrange(p) for _ in range(2)]
+    got, exc = run_fused(acc, q, 1)
+    assert exc == 1 and got == acc
+
+
+def test_committed_header_is_generated():
+    """sonic_amd/csrc/mont_asm.hpp is what the generator produces today (nobody edited one without the other)"""
+    path = os.path.join(os.path.dirname(__file__), "..", "sonic_amd", "csrc", "mont_asm.hpp")
+    assert open(path).read() == G.render()

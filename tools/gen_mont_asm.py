@@ -234,7 +234,7 @@ def emit_addsub(L, N, sub, out, a, b, D, Pv, CA, p2):
             L.append(f"v_cndmask_b32_e32 {out[j]}, {out[j]}, {D[j]}, vcc")
 
 
-def fused_madd_cxx(p: int) -> str:
+def fused_madd_program(p: int):
     """acc += q (XYZZ + affine, madd-2008-s) as ONE asm statement around ten calls of the product core.
     What it saves against ten separate product calls from C++ (per addition): the 25 zero-half initialisations of nine products
     (the zero halves and the modulus SGPRs persist across the calls), ~200 of the ~450 marshalling / merge moves (operands are
@@ -337,6 +337,14 @@ def fused_madd_cxx(p: int) -> str:
     mov(A, ACCY); mov(B, R2); call()
     emit_addsub(L, N, True, ACCY, R4, T, D, Pv, CA, 2 * p)
     L.append(f"s_mov_b64 exec, {SAVE}")
+    return L, nv
+
+
+def fused_madd_cxx(p: int) -> str:
+    """The C++ wrapper around fused_madd_program: operands %0..%47 = accumulator (in/out), %48 = exceptional flag (out),
+    %49..%72 = the affine point, %73 = "an operand is at infinity" (in)."""
+    N = 12
+    L, nv = fused_madd_program(p)
     n_mov = sum(1 for l in L if l.startswith("v_mov_b32"))
     NLs = "\\n\\t"
     outs = [f'"+v"(acc.x.l[{j}])' for j in range(N)] + [f'"+v"(acc.y.l[{j}])' for j in range(N)] + \
@@ -451,7 +459,8 @@ def addsub_cxx(fname: str, cls: str, N: int, sub: bool) -> str:
 }}"""
 
 
-def main():
+def render() -> str:
+    """The text of sonic_amd/csrc/mont_asm.hpp (tests/test_asm_model.py checks that the committed file is this)."""
     out = ["// GENERATED by tools/gen_mont_asm.py -- do not edit.",
            "// Hand-scheduled gfx950 Montgomery products (see the generator for the algorithm and the schedule).",
            "#pragma once",
@@ -470,7 +479,11 @@ def main():
            addsub_cxx("sonic_fq_add_asm", "Fp<P>", 12, False),
            "}  // namespace sonic",
            "#endif", ""]
-    open("sonic_amd/csrc/mont_asm.hpp", "w").write("\n".join(out))
+    return "\n".join(out)
+
+
+def main():
+    open("sonic_amd/csrc/mont_asm.hpp", "w").write(render())
     for name, N, p in (("fq", 12, Q), ("fr", 8, R)):
         body, nv, _ = function_text(name, N, p, lazy=(name == "fq"))
         print(name, "instructions:", len(body), "nops:", sum(1 for l in body if l.startswith("s_nop")), "vgprs:", nv)
