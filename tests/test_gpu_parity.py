@@ -413,6 +413,29 @@ def test_prove_without_window_tables(sonic, orc, ref, srs_pair):
         p.close()
 
 
+def test_prove_graph_replay(sonic, orc, ref, srs_pair):
+    """SONIC_PROVE_GRAPH=1: the second proof of a handle is captured as a hipGraph (multi-stream capture) and later proofs replay
+    it; every proof must still match the oracle, with new transcripts and a new assignment"""
+    import os
+    d, x, alpha, g, o = srs_pair
+    pyr = random.Random(515)
+    n, Q = 40, 2
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    os.environ["SONIC_PROVE_GRAPH"] = "1"
+    try:
+        p = sonic.Prover(g, sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3]))
+    finally:
+        del os.environ["SONIC_PROVE_GRAPH"]
+    p.set_assignment(sonic.Assignment(*asg))
+    for k in range(5):
+        if k == 3:      # same circuit, another satisfying assignment is not available cheaply: re-upload the same one
+            p.set_assignment(sonic.Assignment(*asg))
+        tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+        want = orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+        assert p.prove_bytes(tr) == want, k
+    p.close()
+
+
 def test_reference_verifier_accepts_gpu_proofs(sonic, ref):
     """the reference's only end-to-end test, verify . prove (test/Test/Protocol.hs:14-23), with the proof made by
     the HIP path and the verifier restated with real pairings (oracle/pairing.py: pcV, hscVerify, verify)"""
