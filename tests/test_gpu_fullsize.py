@@ -116,6 +116,28 @@ def test_prove_full_size_exponent_oracle(sonic, orc, log2n):
         assert qj == G((s_ux - s_uy) * inv(x - ys[j]))                          # :55
 
 
+@pytest.mark.parametrize("log2n", [14, 16])      # BASELINE.json configs[1] (n = 2^14) and configs[4] (n = 2^16)
+def test_prove_bytes_vs_oracle_mid_sizes(sonic, orc, log2n):
+    """d = 8n because the reference rejects d < 7n: the complete proof, byte for byte, against the C oracle -- the sizes at which
+    the oracle itself (Pippenger + NTT on the host cores) still finishes in seconds"""
+    n, Q = 1 << log2n, 2
+    d = 8 * n
+    pyr = random.Random(414)
+    x, alpha = pyr.randrange(2, R), pyr.randrange(2, R)
+    g, o = sonic.SRS.new(d, x, alpha), orc.SRS(d, x, alpha, threads=NCPU)
+    circ = big_circuit(77, n, Q, orc)
+    tr = fr_bytes([pyr.randrange(2, R) for _ in range(8 + 2 * Q)])
+    orc.set_mode(1, NCPU)
+    want = orc.prove(o, n, Q, circ["wL"], circ["wR"], circ["wO"], circ["cs"], circ["aL"], circ["aR"], circ["aO"], tr, True)
+    p = sonic.Prover(g, sonic.ArithCircuit(sonic.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
+    p.set_assignment(sonic.Assignment(circ["aL"], circ["aR"], circ["aO"]))
+    assert p.prove_bytes(tr) == want
+    # a slice of the SRS itself at this size, both bases
+    for basis in (0, 1):
+        assert np.array_equal(g.points(basis, d - 300, 300), o.points(basis, d - 300, 300))
+        assert np.array_equal(g.points(basis, -d, 300), o.points(basis, -d, 300))
+
+
 def test_msm_full_size_properties(sonic, orc):
     """N = 2^20 MSM over an SRS slice: MSM(2a) == 2 MSM(a) (linearity), and the trapdoor value
     g^{alpha x sum_i (x0 x)^i} for the geometric scalar vector 1, x0, x0^2, ... in closed form"""
