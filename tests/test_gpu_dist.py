@@ -1,0 +1,87 @@
+"""The N > 1 path on a GPU box with one GPU: two ranks (gloo) share the device.  Each rank reduces its slice of a range-sharded
+MSM with the real kernels (sonic_msm_g1_srs_partial_dev), the 192-byte partials are all-gathered and summed, and the result must
+be the oracle's full MSM; then bench.py itself is run as the driver runs it for N = 2 (torch.distributed.run), with gloo because
+two RCCL ranks cannot share one device."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_terms, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import ctypes as C
+    import torch.distributed as dist
+    import sonic_amd
+    from oracle import orc
+    from sonic_amd import _lib, distributed as sd
+    from util import rand_fr_array
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = _lib.lib()
+        _lib.check(L.sonic_init(0))
+        d, x, alpha = 1 << 12, 0x1234567, 0x7654321
+        srs = sonic_amd.SRS.new(d, x, alpha)
+        sc = rand_fr_array(np.random.default_rng(4242), n_terms)
+        e0 = -d + 5
+        lo, hi = sd.split_range(n_terms, world, rank)
+        part = np.zeros(192, np.uint8)
+        if hi > lo:
+            dsc = C.c_void_p()
+            mine = np.ascontiguousarray(sc[lo:hi])
+            _lib.check(L.sonic_dev_alloc(32 * (hi - lo), C.byref(dsc)))
+            _lib.check(L.sonic_dev_upload(dsc, mine.ctypes.data, 32 * (hi - lo)))
+            _lib.check(L.sonic_msm_g1_srs_partial_dev(srs._h, 0, e0 + lo, dsc, hi - lo, part.ctypes.data))
+            L.sonic_dev_free(dsc)
+        got = sd.sum_partials(sd.allgather_partials(part, world), world)
+        osrs = orc.SRS(d, x, alpha, threads=4)
+        q.put((rank, got == orc.msm_srs(osrs, 0, e0, sc, 1, 4)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_terms", [5000, 3])
+def test_range_sharded_msm_two_ranks_one_gpu(n_terms):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_terms, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
+def test_bench_two_ranks_one_gpu():
+    """the driver's N = 2 launch line, small sizes, gloo: one JSON line from rank 0 with whole-job values"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--log2n", "10", "--msm-log2", "12", "--no-cpu"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["msm"]["value"] > 0
+    assert j["roofline"]["bound"] == "hbm" and j["cpu_baseline"] is None
