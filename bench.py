@@ -257,6 +257,7 @@ def main():
     # so the kernel pays for instructions, not latency: additions x static instructions per addition / (time x issue rate)
     n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value          # the first term of a bucket is a copy
     int_roofline["valu_issue"] = {"instr_per_mixed_add": ACCUM_INSTR_PER_ADD, "wave_instr_per_s_peak": VALU_WAVE_INSTR_PER_S,
+                                  "pmc": "SQ_INSTS_VALU = 1.468e9 per launch at N = 2^20 (profiles/r01_pmc_SQ_counter_collection.csv) vs 1.461e9 from the static count",
                                   "frac": round(n_adds * ACCUM_INSTR_PER_ADD / 64 / (accum_ms * 1e-3) / VALU_WAVE_INSTR_PER_S, 4) if accum_ms > 0 else 0.0}
 
     cpu_baseline = None
