@@ -129,7 +129,7 @@ using namespace sonic;
 
 struct sonic_srs {
   int64_t d;
-  // basis b, window table w, exponent e  ->  tab[b][w * (2d+1) + e + d] = 2^(tab_c w) * g^{(alpha^b) x^e}
+  // basis b, window table w, exponent e  ->  tab[b][w * (2d+1) + e + d] = 2^(msm_even_shift(tab_W, w)) * g^{(alpha^b) x^e}
   // (w = 0 is the basis itself; tab_W = 1 when the window tables are switched off)
   int tab_c = 0, tab_W = 1;
   DevBuf g, ga;
@@ -159,13 +159,10 @@ sonic_srs* srs_alloc(int64_t d) {
   // (c = 17: one to two waves per SIMD, short reduction); from d = 2^21 the two windows saved by c = 20 win.
   int c = lg >= 21 ? 20 : (lg > 17 ? 17 : lg);
   if (const char* tc = getenv("SONIC_MSM_TABLE_C")) { int v = atoi(tc); if (v >= 9 && v <= 22) c = v; }   // tuning knob
-  // The scalars are folded below 2^254, so the top window holds only t = 254 - (W-1) c bits.  With shared buckets a
-  // nearly empty top window piles a quarter of all terms onto buckets 1..3 (atomics on three addresses); step c
-  // down until it has at least 6 bits (the 2^t buckets it fills are then merely "heavy" and take the workgroup path).
-  auto top_bits = [](int cc) { return 254 - ((254 + cc - 1) / cc - 1) * cc; };
-  while (c > 9 && top_bits(c) < (c - 6 < 6 ? c - 6 : 6)) c--;
   if (c < 9) c = 9;
-  int W = (254 + c - 1) / c;
+  // W windows of even width (msm.hpp): the widest is ceil(255 / W) <= c
+  int W = (255 + c - 1) / c;
+  c = (255 + W - 1) / W;
   const char* env = getenv("SONIC_MSM_TABLES");
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int 
     ds.init(sc, i, i < n, mont, fold);
     for (int w = 0; w < W; w++) {
       uint32_t sign;
-      const uint32_t d = ds.next(c, sign);
+      const uint32_t d = ds.next(keystride ? c : msm_even_width(W, w), sign);       // shared buckets over tables: even widths
       const uint32_t key = (uint32_t)w * keystride + d - 1;
       lds_take(h, d != 0, key >> PART_LOW_BITS);
     }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
     ds.init(sc, i, i < n, mont, fold);
     for (int w = 0; w < W; w++) {
       uint32_t sign;
-      const uint32_t d = ds.next(c, sign);
+      const uint32_t d = ds.next(keystride ? c : msm_even_width(W, w), sign);       // shared buckets over tables: even widths
       const uint32_t key = (uint32_t)w * keystride + d - 1;
       const uint32_t pos = lds_take(cur, d != 0, key >> PART_LOW_BITS);
       if (d) {

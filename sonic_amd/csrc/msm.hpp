@@ -5,11 +5,19 @@
 
 namespace sonic {
 
+// Window tables: W windows over the 255 bits a folded scalar and its recoding carries can occupy, with widths that differ by at
+// most one bit (the first 255 % W windows are the wide ones).  With W = 13: eight 20-bit and five 19-bit windows.  A uniform
+// width c would leave the top window 254 - (W-1) c bits: its 2^14 buckets then hold N / 2^14 extra terms each, the walks over
+// them are 3x longer than the rest and set the duration of the whole accumulation (average residency 1.5 of 2 waves per SIMD).
+HD int msm_even_width(int W, int w) { return 255 / W + (w < 255 % W ? 1 : 0); }
+HD int msm_even_shift(int W, int w) { const int base = 255 / W, extra = 255 % W; return w * base + (w < extra ? w : extra); }
+
 struct MsmPlan {
   int c;        // window bits
   int W;        // windows: ceil(255 / c) (scalars are first folded into [0, (r-1)/2])
   int Wb;       // bucket sets: W (one per window), or 1 when the windows share buckets over precomputed tables
-  long table_stride;   // points per window table (0: no tables, every window reads the same points)
+  long table_stride;   // points per window table (0: no tables, every window reads the same points); with tables the windows
+                       // have the even widths above and c is the widest
   int NB;       // buckets per set: digit magnitudes 1 .. 2^(c-1)
   int K;        // buckets per running-sum segment
   int nseg;     // segments per window

@@ -101,7 +101,8 @@ void srs_build_tables(hipStream_t st, sonic_srs* s) {
     for (int w = 1; w < W; w++) {
       for (long base = 0; base < n; base += SLAB) {
         const long m = n - base < SLAB ? n - base : SLAB;
-        LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (const G1Affine*)(tab + (size_t)(w - 1) * n + base), x.as<G1XYZZ>(), m, c);
+        LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (const G1Affine*)(tab + (size_t)(w - 1) * n + base), x.as<G1XYZZ>(), m,
+               msm_even_width(W, w - 1));
         LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), tab + (size_t)w * n + base, pref.as<Fq>(), m);
       }
     }
