@@ -34,7 +34,8 @@ namespace sonic {
 #define SONIC_PART_LOW_BITS 8
 #endif
 constexpr int PART_LOW_BITS = SONIC_PART_LOW_BITS;   // buckets per sort partition = 2^PART_LOW_BITS (8..10)
-constexpr int PART_TILE = 1024;            // scalars per workgroup in pass 1
+constexpr int PART_TILE = 1024;            // scalars per tile in pass 1
+constexpr uint32_t PASS1_GRID = 1024;      // workgroups of pass 1 (grid-stride over the tiles)
 static_assert(PART_LOW_BITS >= 8 && PART_LOW_BITS <= 10, "k_part_sort scans 256 x {1, 2, 4} counters");
 
 static int g_window_override = 0;
@@ -157,10 +158,15 @@ struct MsmBatchDev {
 // Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Pass 1 appends to 2^11 partition cursors per
 // job and consecutive tiles append to ADJACENT addresses of every partition, so with tile = blockIdx the 64-B lines under the
 // cursors are shared by workgroups on different XCDs and leave their L2s as partial writes (measured: 0.9 GB of HBM writes for
-// 82 MB of entries).  Giving XCD x the contiguous tile range [x G/8, (x+1) G/8) keeps every line inside one L2.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t G) {
-  const uint32_t x = b & 7u, k = b >> 3, per = G >> 3, rem = G & 7u;
-  return x * per + (x < rem ? x : rem) + k;
+// 82 MB of entries).  Giving XCD x the contiguous tile range [x T/8, (x+1) T/8) keeps every line inside one L2.
+// The pass-1 kernels run grid-stride over a capped grid (long-lived workgroups are not starved of wave slots beside another
+// MSM's accumulation, see ntt.hip): workgroup b, on XCD b & 7, walks its share of that XCD's contiguous tile range.
+struct TileWalk { uint32_t cur, end, step; };
+__device__ __forceinline__ TileWalk xcd_tile_walk(uint32_t b, uint32_t G, uint32_t T) {
+  if (G < 8) return TileWalk{b, T, G};
+  const uint32_t x = b & 7u, k = b >> 3, Gx = (G + 7u - x) >> 3, per = T >> 3, rem = T & 7u;
+  const uint32_t start = x * per + (x < rem ? x : rem), cnt = per + (x < rem ? 1u : 0u);
+  return TileWalk{start + k, start + cnt, Gx};
 }
 
 __device__ __forceinline__ int batch_job_of_tile(const MsmBatchDev& b, uint32_t tile) {
@@ -222,9 +228,10 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* cnt, bool valid, uint32_t
 __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
                                                    uint32_t* __restrict__ hist) {
   extern __shared__ uint32_t h[];
+  for (TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, batch.tile0[batch.k]); tw.cur < tw.end; tw.cur += tw.step) {
   for (int t = threadIdx.x; t < P; t += 256) h[t] = 0;
   __syncthreads();
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile = tw.cur;
   const int job = batch_job_of_tile(batch, tile);
   const uint32_t blk = tile - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
   const Fr* __restrict__ sc = batch.scalars[job];
@@ -243,12 +250,15 @@ __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int 
   __syncthreads();
   uint32_t* out = hist + (size_t)P * batch.tile0[job] + blk;
   for (int t = threadIdx.x; t < P; t += 256) out[(size_t)t * nblk] = h[t];
+  __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
                                                       const uint32_t* __restrict__ base, uint2* __restrict__ part) {
   extern __shared__ uint32_t cur[];
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  for (TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, batch.tile0[batch.k]); tw.cur < tw.end; tw.cur += tw.step) {
+  const uint32_t tile = tw.cur;
   const int job = batch_job_of_tile(batch, tile);
   const uint32_t blk = tile - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
   const Fr* __restrict__ sc = batch.scalars[job];
@@ -270,6 +280,8 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
         part[pos] = make_uint2(key & ((1u << PART_LOW_BITS) - 1), (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (sign << 31));
       }
     }
+  }
+  __syncthreads();
   }
 }
 
@@ -646,11 +658,12 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     uint32_t* hbase = hist + hn + 1;
     const int ht = ceil_div((long)hn + 1, 2048);
     uint32_t* total = tiles + ht;
-    LAUNCH(k_part_hist, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, hist);
+    const uint32_t pgrid = pblk < PASS1_GRID ? pblk : PASS1_GRID;
+    LAUNCH(k_part_hist, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, hist);
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
-    LAUNCH(k_part_scatter, pblk, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, (const uint32_t*)hbase,
+    LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, (const uint32_t*)hbase,
            ws.digits.as<uint2>());
     LAUNCH(k_part_sort, k * P, 256, 0, st, batch, (const uint2*)ws.digits.as<uint2>(),
            (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>());
