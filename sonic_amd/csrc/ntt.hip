@@ -13,7 +13,6 @@
 namespace sonic {
 
 static constexpr int TILE_LOG = 11;
-static constexpr int TILE = 1 << TILE_LOG;
 
 __device__ __forceinline__ Fr root_2_32(bool inverse) {
   constexpr uint32_t w[8] = FR_ROOT_2_32_MONT;
