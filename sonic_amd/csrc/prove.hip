@@ -117,17 +117,6 @@ __global__ void k_prep_scalars(const Fr* __restrict__ S, long Q, Fr* __restrict_
   if (t < 2 * Q) IN[5 + t] = S[6 + t];
 }
 
-// k * P on the host, k in standard form (the Q per-constraint commitments of a prepared handle, Q <= HOST_CQ_MAX)
-constexpr long HOST_CQ_MAX = 4;
-static G1XYZZ g1_mul_fr_host(const G1Affine& p, const Fr& k_std) {
-  G1XYZZ acc = G1XYZZ::inf();
-  for (int i = 254; i >= 0; i--) {
-    acc = g1_dbl(acc);
-    if ((k_std.l[i >> 5] >> (i & 31)) & 1u) acc = g1_add_mixed(acc, p);
-  }
-  return acc;
-}
-
 static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
 }  // namespace sonic
@@ -175,7 +164,6 @@ struct sonic_prover {
   long proofs_done = 0;
   bool prepared = false;
   DevBuf cq;
-  std::vector<G1Affine> cq_host;
   std::vector<DevBuf> diag, yq;
   hipEvent_t ev_r1 = nullptr, ev_sy0 = nullptr, ev_t = nullptr, ev_su = nullptr;
   std::vector<hipEvent_t> ev_syj;
@@ -341,8 +329,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   int* flags = p->flags.as<int>();
   memcpy(p->h_tr, transcript, 32 * (8 + 2 * Q));
   const int K = (int)(7 + 4 * Q);
-  const bool host_cq = p->prepared && Q <= HOST_CQ_MAX;
-  const int KS = K + (p->prepared && !host_cq ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
+  const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
   // first one grows the workspaces), every address in it is owned by the handle.
   const bool want_graph = p->use_graph && p->proofs_done >= 1 && !profiler().on;
@@ -446,7 +433,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
     open(syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);                        // (s_j, W_j)    :43
     open(syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                          // W'_j          :54
     flush_group();
-    if (p->prepared && !host_cq)                                                      // sum_q y_j^{n+q} C_q, Q-term MSM
+    if (p->prepared)                                                                  // sum_q y_j^{n+q} C_q, Q-term MSM
       msm_enqueue(cur->st, cur->ws, msm_plan(Q), p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
   }
   begin_group(p->ev_su);
@@ -497,17 +484,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
         for (int i = w; i < K; i += nt) {
           G1XYZZ s = msm_finish_host(hs[i]);
           const int j = (i - 5) / 2;
-          if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) {
-            if (host_cq) {                                   // few constraints: the Q scalar multiplications cost less here than a launch chain
-              Fr yj;
-              memcpy(yj.l, transcript + 32 * (6 + j), 32);
-              Fr yp = fp_pow_u64(fp_to_mont(yj), (uint64_t)n + 1);
-              const Fr ym = fp_to_mont(yj);
-              for (long q = 0; q < Q; q++) { s = g1_add(s, g1_mul_fr_host(p->cq_host[q], fp_from_mont(yp))); yp = fp_mul(yp, ym); }
-            } else {
-              s = g1_add(s, msm_finish_host(hs[K + j]));
-            }
-          }
+          if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) s = g1_add(s, msm_finish_host(hs[K + j]));
           g1_canonical_bytes_host(s, &pts[96 * (size_t)i]);
         }
       });
@@ -565,7 +542,6 @@ int sonic_prover_prepare(sonic_prover_t* p) {
       th.emplace_back([&, w] { for (long q = w; q < Q; q += nt) cq[q] = g1_to_affine(msm_finish_host(hs[q])); });
     for (auto& x : th) x.join();
   }
-  p->cq_host = cq;
   p->cq.alloc(sizeof(G1Affine) * Q);
   HIP_OK(hipMemcpy(p->cq.p, cq.data(), sizeof(G1Affine) * Q, hipMemcpyHostToDevice));
   p->diag.resize(Q); p->yq.resize(Q);
