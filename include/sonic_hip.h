@@ -71,21 +71,27 @@ int sonic_device_sync(void);
  * basis0[k], gNegativeAlphaX[k] = basis1[-(k+1)], gPositiveAlphaX[k] = basis1[k+1]. */
 int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out);
 /* the record constructor `SRS{..}`: caller-supplied points, (2d+1) * 96 bytes per basis.  Every point is checked to be
- * canonical and on the curve; that it lies in the prime-order subgroup G1 (as the powers of a generator do) is the
- * caller's promise -- MSMs over an SRS use r P = O (scalars above r/2 run as r - s on the negated point). */
+ * canonical, on the curve and in the prime-order subgroup G1 (r P = O, as the powers of a generator are): MSMs over an
+ * SRS rely on it (scalars above r/2 run as r - s on the negated point).  SONIC_ERR_BAD_ENCODING otherwise. */
 int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out);
 void sonic_srs_free(sonic_srs_t* srs);
 int64_t sonic_srs_d(const sonic_srs_t* srs);        /* srsD */
 int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out);
-/* on-disk SRS (the reference has no persistence): "SONICSRS", u32 version = 1, u32 flags, i64 d, then the two G1
- * bases as (2d+1) x 96 canonical bytes each.  Loading validates every point (on curve) like sonic_srs_from_points. */
-int sonic_srs_save(const sonic_srs_t* srs, const char* path);
-int sonic_srs_load(const char* path, sonic_srs_t** out);
-/* the G2 half (SRS.hs:35-36,40-41), generated on the GPU on first use: basis 0 = h^{x^e}, basis 1 = h^{alpha x^e},
- * e in [-d, d]; hNegativeX[k] = basis0[-(k+1)], hPositiveX[k] = basis0[k], hPositiveAlphaX[k] = basis1[k],
- * hNegativeAlphaX[k] = basis1[-(k+1)].  G2 encoding: 192 bytes x.c0 || x.c1 || y.c0 || y.c1 (48-byte
- * little-endian each, x = c0 + c1 u), infinity = zeros.  Only for handles made by sonic_srs_new. */
+/* the G2 half (SRS.hs:35-36,40-41): basis 0 = h^{x^e}, basis 1 = h^{alpha x^e}, e in [-d, d]; hNegativeX[k] = basis0[-(k+1)],
+ * hPositiveX[k] = basis0[k], hPositiveAlphaX[k] = basis1[k], hNegativeAlphaX[k] = basis1[-(k+1)].  G2 encoding: 192 bytes
+ * x.c0 || x.c1 || y.c0 || y.c1 (48-byte little-endian each, x = c0 + c1 u), infinity = zeros.  A handle made by
+ * sonic_srs_new generates it on the GPU on first use and then forgets x and alpha; other handles have it only after
+ * sonic_srs_set_g2_points or a load from a file that carries it (SONIC_ERR_INVALID_ARG otherwise). */
 int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out);
+/* attaches caller-supplied G2 vectors, (2d+1) * 192 bytes per basis, checked like the G1 side (canonical, on the twist,
+ * r P = O); the prover never reads them, the verifier reads three elements (CommitmentScheme.hs:58-68). */
+int sonic_srs_set_g2_points(sonic_srs_t* srs, const uint8_t* basis0, const uint8_t* basis1);
+/* on-disk SRS (the reference has no persistence): "SONICSRS", u32 version = 2, u32 flags (bit 0: G2 half present), i64 d,
+ * the two G1 bases as (2d+1) x 96 canonical bytes each, then -- with_g2 != 0 -- the two G2 bases as (2d+1) x 192 bytes
+ * each.  Loading validates every point like sonic_srs_from_points / sonic_srs_set_g2_points; version-1 files (G1 only)
+ * still load.  A file never holds x or alpha. */
+int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2);
+int sonic_srs_load(const char* path, sonic_srs_t** out);
 
 /* ---- Sonic.CommitmentScheme ---- */
 /* commitPoly :: SRS -> Int -> VLaurent Fr -> G1  (CommitmentScheme.hs:20-33) */

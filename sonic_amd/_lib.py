@@ -47,7 +47,8 @@ def lib() -> C.CDLL:
         "sonic_srs_from_points": [i64, vp, vp, C.POINTER(vp)],
         "sonic_srs_get_points": [vp, i32, i64, i64, vp],
         "sonic_srs_get_g2_points": [vp, i32, i64, i64, vp],
-        "sonic_srs_save": [vp, cp],
+        "sonic_srs_save": [vp, cp, i32],
+        "sonic_srs_set_g2_points": [vp, vp, vp],
         "sonic_srs_load": [cp, C.POINTER(vp)],
         "sonic_commit_poly": [vp, i64, i64, vp, vp, vp],
         "sonic_open_poly": [vp, cp, i64, vp, vp, vp, vp],
@@ -97,7 +98,7 @@ def lib() -> C.CDLL:
 
 EXPORTED = [
     "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_srs_new", "sonic_srs_from_points",
-    "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_save", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
+    "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
     "sonic_g1_sum_partials", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",

@@ -72,6 +72,25 @@ __global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __rest
   if (fp_sqr(p.y) != fp_add(fp_mul(fp_sqr(p.x), p.x), four)) { atomicOr(err, 2); out[i] = G1Affine::inf(); return; }
   out[i] = p;
 }
+// r P == O for every point (literal double-and-add over the bits of r): SRS elements must lie in the order-r subgroup because
+// MSMs over an SRS fold scalars with r P = O (msm.hpp).  Sets err bit 4 otherwise.
+__global__ __launch_bounds__(256) void k_points_subgroup_check(const G1Affine* __restrict__ in, long n, int* err) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G1Affine p = in[i];
+  if (p.is_inf()) return;
+  constexpr uint32_t rl[8] = FR_P;
+  G1XYZZ acc = G1XYZZ::from_affine(p);       // top bit (254) of r
+#pragma unroll 1
+  for (int b = 253; b >= 0; b--) {
+    acc = g1_dbl(acc);
+    uint32_t w = 0;                            // constant-index reads keep rl[] out of scratch
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k == (b >> 5)) w = rl[k];
+    if ((w >> (b & 31)) & 1u) acc = g1_add_mixed(acc, p);
+  }
+  if (!acc.is_inf()) atomicOr(err, 4);
+}
 __global__ __launch_bounds__(256) void k_points_to_bytes(const G1Affine* __restrict__ in, uint8_t* __restrict__ out, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -133,11 +152,18 @@ struct sonic_srs {
   // (w = 0 is the basis itself; tab_W = 1 when the window tables are switched off)
   int tab_c = 0, tab_W = 1;
   DevBuf g, ga;
-  // verifier half, generated on first use from the trapdoor SRS.new was given (absent for from_points handles)
-  bool have_trapdoor = false;
-  Fr x_std, alpha_std;
+  // verifier half: generated on first use from the trapdoor SRS.new was given -- which is wiped as soon as that has
+  // happened -- or attached by sonic_srs_set_g2_points / read from a version-2 file
+  mutable bool have_trapdoor = false;
+  mutable Fr x_std, alpha_std;
   mutable std::mutex g2_mu;
   mutable DevBuf h, ha;      // G2Affine[2d+1] each
+  ~sonic_srs() { wipe_trapdoor(); }
+  void wipe_trapdoor() const {
+    volatile uint32_t* a = x_std.l; volatile uint32_t* b = alpha_std.l;
+    for (int i = 0; i < 8; i++) { a[i] = 0; b[i] = 0; }
+    have_trapdoor = false;
+  }
   const G1Affine* basis(int b) const { return (b ? ga : g).as<G1Affine>(); }
 };
 
@@ -230,11 +256,16 @@ int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis
   for (int b = 0; b < 2; b++) {
     HIP_OK(hipMemcpyAsync(raw.p, b ? basis1 : basis0, 96 * n, hipMemcpyHostToDevice, st));
     LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), srs_basis_mut(s, b), n, err.as<int>());
+    LAUNCH(k_points_subgroup_check, ceil_div(n, 256), 256, 0, st, (const G1Affine*)srs_basis_mut(s, b), n, err.as<int>());
   }
   int herr = 0;
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
-  if (herr) { delete s; set_error("sonic_srs_from_points: %s", (herr & 1) ? "non-canonical coordinate" : "point not on curve"); return SONIC_ERR_BAD_ENCODING; }
+  if (herr) {
+    delete s;
+    set_error("sonic_srs_from_points: %s", (herr & 1) ? "non-canonical coordinate" : (herr & 2) ? "point not on curve" : "point outside the order-r subgroup");
+    return SONIC_ERR_BAD_ENCODING;
+  }
   srs_build_tables(st, s);
   *out = s;
   API_END
@@ -260,23 +291,28 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
   API_END
 }
 
+// makes sure the G2 half is resident; caller holds call_mutex
+static int srs_ensure_g2(const sonic_srs_t* srs, hipStream_t st, const char* who) {
+  std::lock_guard<std::mutex> g2(srs->g2_mu);
+  if (srs->h.p) return SONIC_OK;
+  if (!srs->have_trapdoor) { set_error("%s: this SRS has no G2 half (built from G1 points only)", who); return SONIC_ERR_INVALID_ARG; }
+  const size_t cnt = (size_t)(2 * srs->d + 1);
+  srs->h.alloc(sizeof(G2Affine) * cnt);
+  srs->ha.alloc(sizeof(G2Affine) * cnt);
+  srs_generate_g2(st, srs->d, srs->x_std, srs->alpha_std, srs->h.as<G2Affine>(), srs->ha.as<G2Affine>());
+  srs->wipe_trapdoor();          // x and alpha have served their last purpose
+  return SONIC_OK;
+}
+
 int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out) {
   API_BEGIN
   if (!srs || !out || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
   if (e0 < -srs->d || e0 + n - 1 > srs->d) { set_error("sonic_srs_get_g2_points: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
-  if (!srs->have_trapdoor) { set_error("sonic_srs_get_g2_points: this SRS was built from points and has no G2 half"); return SONIC_ERR_INVALID_ARG; }
-  if (n == 0) return SONIC_OK;
   std::lock_guard<std::mutex> g(call_mutex());
   hipStream_t st = default_stream();
-  {
-    std::lock_guard<std::mutex> g2(srs->g2_mu);
-    if (!srs->h.p) {
-      const size_t cnt = (size_t)(2 * srs->d + 1);
-      srs->h.alloc(sizeof(G2Affine) * cnt);
-      srs->ha.alloc(sizeof(G2Affine) * cnt);
-      srs_generate_g2(st, srs->d, srs->x_std, srs->alpha_std, srs->h.as<G2Affine>(), srs->ha.as<G2Affine>());
-    }
-  }
+  int rc = srs_ensure_g2(srs, st, "sonic_srs_get_g2_points");
+  if (rc) return rc;
+  if (n == 0) return SONIC_OK;
   DevBuf raw(192 * n);
   g2_points_to_bytes_enqueue(st, (basis ? srs->ha : srs->h).as<G2Affine>() + (e0 + srs->d), raw.as<uint8_t>(), n);
   HIP_OK(hipMemcpyAsync(out, raw.p, 192 * n, hipMemcpyDeviceToHost, st));
@@ -284,26 +320,59 @@ int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64
   API_END
 }
 
-// ---- on-disk SRS: "SONICSRS" | u32 version | u32 flags | i64 d | basis0 (2d+1) x 96 B | basis1 (2d+1) x 96 B,
-// canonical affine encodings.  The reference has no persistence at all; this amortises SRS.new across runs.
+int sonic_srs_set_g2_points(sonic_srs_t* srs, const uint8_t* basis0, const uint8_t* basis1) {
+  API_BEGIN
+  if (!srs || !basis0 || !basis1) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  const long n = 2 * srs->d + 1;
+  DevBuf raw(192 * n), err(4), h0(sizeof(G2Affine) * n), h1(sizeof(G2Affine) * n);
+  HIP_OK(hipMemsetAsync(err.p, 0, 4, st));
+  for (int b = 0; b < 2; b++) {
+    HIP_OK(hipMemcpyAsync(raw.p, b ? basis1 : basis0, 192 * n, hipMemcpyHostToDevice, st));
+    g2_points_from_bytes_enqueue(st, raw.as<uint8_t>(), (b ? h1 : h0).as<G2Affine>(), n, err.as<int>());
+  }
+  int herr = 0;
+  HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  if (herr) {
+    set_error("sonic_srs_set_g2_points: %s", (herr & 1) ? "non-canonical coordinate" : (herr & 2) ? "point not on the twist" : "point outside the order-r subgroup");
+    return SONIC_ERR_BAD_ENCODING;
+  }
+  std::lock_guard<std::mutex> g2(srs->g2_mu);
+  srs->h = std::move(h0);
+  srs->ha = std::move(h1);
+  srs->wipe_trapdoor();
+  API_END
+}
+
+// ---- on-disk SRS: "SONICSRS" | u32 version = 2 | u32 flags (bit 0: G2 half follows) | i64 d | basis0, basis1: (2d+1) x 96 B |
+// [h basis0, h basis1: (2d+1) x 192 B], canonical affine encodings.  The reference has no persistence at all; this
+// amortises SRS.new across runs, and with the G2 half a loaded SRS verifies as well as proves -- without the trapdoor.
 static const char SRS_MAGIC[8] = {'S', 'O', 'N', 'I', 'C', 'S', 'R', 'S'};
 
-int sonic_srs_save(const sonic_srs_t* srs, const char* path) {
+int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2) {
   API_BEGIN
   if (!srs || !path) return SONIC_ERR_INVALID_ARG;
+  if (with_g2) {
+    std::lock_guard<std::mutex> g(call_mutex());
+    int rc = srs_ensure_g2(srs, default_stream(), "sonic_srs_save");
+    if (rc) return rc;
+  }
   FILE* f = fopen(path, "wb");
   if (!f) { set_error("sonic_srs_save: cannot open %s", path); return SONIC_ERR_INVALID_ARG; }
-  uint32_t ver = 1, flags = 0;
+  uint32_t ver = 2, flags = with_g2 ? 1u : 0u;
   int64_t d = srs->d;
   bool ok = fwrite(SRS_MAGIC, 1, 8, f) == 8 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&flags, 4, 1, f) == 1 && fwrite(&d, 8, 1, f) == 1;
   const int64_t n = 2 * d + 1, CH = 1 << 16;
-  std::vector<uint8_t> buf(96 * (size_t)CH);
-  for (int b = 0; b < 2 && ok; b++)
+  std::vector<uint8_t> buf(192 * (size_t)CH);
+  for (int b = 0; b < (with_g2 ? 4 : 2) && ok; b++)
     for (int64_t i = 0; i < n && ok; i += CH) {
       int64_t m = n - i < CH ? n - i : CH;
-      int rc = sonic_srs_get_points(srs, b, -d + i, m, buf.data());
+      const size_t sz = b < 2 ? 96 : 192;
+      int rc = b < 2 ? sonic_srs_get_points(srs, b, -d + i, m, buf.data()) : sonic_srs_get_g2_points(srs, b - 2, -d + i, m, buf.data());
       if (rc) { fclose(f); return rc; }
-      ok = fwrite(buf.data(), 96, (size_t)m, f) == (size_t)m;
+      ok = fwrite(buf.data(), sz, (size_t)m, f) == (size_t)m;
     }
   ok = (fclose(f) == 0) && ok;
   if (!ok) { set_error("sonic_srs_save: write to %s failed", path); return SONIC_ERR_INVALID_ARG; }
@@ -317,14 +386,23 @@ int sonic_srs_load(const char* path, sonic_srs_t** out) {
   if (!f) { set_error("sonic_srs_load: cannot open %s", path); return SONIC_ERR_INVALID_ARG; }
   char magic[8]; uint32_t ver = 0, flags = 0; int64_t d = 0;
   bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, SRS_MAGIC, 8) == 0 && fread(&ver, 4, 1, f) == 1 && fread(&flags, 4, 1, f) == 1 &&
-            fread(&d, 8, 1, f) == 1 && ver == 1 && d >= 1 && d < (1LL << 40);
-  if (!ok) { fclose(f); set_error("sonic_srs_load: %s is not a version-1 SRS file", path); return SONIC_ERR_BAD_ENCODING; }
+            fread(&d, 8, 1, f) == 1 && (ver == 1 || ver == 2) && d >= 1 && d < (1LL << 40) && (flags & ~1u) == 0 && !(ver == 1 && flags);
+  if (!ok) { fclose(f); set_error("sonic_srs_load: %s is not a version-1/2 SRS file", path); return SONIC_ERR_BAD_ENCODING; }
   const size_t n = (size_t)(2 * d + 1);
-  std::vector<uint8_t> b0(96 * n), b1(96 * n);
+  std::vector<uint8_t> b0(96 * n), b1(96 * n), h0, h1;
   ok = fread(b0.data(), 96, n, f) == n && fread(b1.data(), 96, n, f) == n;
+  if (ok && (flags & 1u)) { h0.resize(192 * n); h1.resize(192 * n); ok = fread(h0.data(), 192, n, f) == n && fread(h1.data(), 192, n, f) == n; }
+  if (ok) ok = fgetc(f) == EOF;                                   // nothing may follow
   fclose(f);
-  if (!ok) { set_error("sonic_srs_load: %s is truncated", path); return SONIC_ERR_BAD_ENCODING; }
-  return sonic_srs_from_points(d, b0.data(), b1.data(), out);     // validates every point, rebuilds the window tables
+  if (!ok) { set_error("sonic_srs_load: %s is truncated or has trailing bytes", path); return SONIC_ERR_BAD_ENCODING; }
+  sonic_srs_t* s = nullptr;
+  int rc = sonic_srs_from_points(d, b0.data(), b1.data(), &s);     // validates every point, rebuilds the window tables
+  if (rc) return rc;
+  if (flags & 1u) {
+    rc = sonic_srs_set_g2_points(s, h0.data(), h1.data());
+    if (rc) { delete s; return rc; }
+  }
+  *out = s;
   API_END
 }
 

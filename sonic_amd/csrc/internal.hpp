@@ -34,6 +34,7 @@ struct G2Affine;
 // G2 half (srs_g2.hip)
 void srs_generate_g2(hipStream_t st, long d, const Fr& x_std, const Fr& alpha_std, G2Affine* h0, G2Affine* h1);
 void g2_points_to_bytes_enqueue(hipStream_t st, const G2Affine* in, uint8_t* d_out, long n);
+void g2_points_from_bytes_enqueue(hipStream_t st, const uint8_t* d_in, G2Affine* out, long n, int* d_err);
 
 // SRS generation (srs.hip): fills both bases of `s` from x, alpha (standard-form Fr on the host)
 void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha_std);

@@ -64,6 +64,7 @@ static void plan_finish(MsmPlan& p, long n) {
 void msm_plan_set_segment(MsmPlan& p, int K) {
   if (K > p.NB) K = p.NB;
   if (K < 1) K = 1;
+  while (K & (K - 1)) K &= K - 1;      // k_bucket_segments needs a power of two (NB is one, so K then divides it): round down
   p.K = K;
   p.nseg = p.NB / K;
 }

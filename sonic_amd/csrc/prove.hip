@@ -110,6 +110,19 @@ static MsmJob open_job(hipStream_t st, const sonic_srs* srs, Scratch& sc, const 
   return MsmJob{srs_basis(srs, 0) + (lo + i0 + d), q + i0, i1 - i0, slot};
 }
 
+// openPoly at z = 0 of a polynomial without negative exponents (lo == 0): f(0) = c_0 and (f - c_0)/X is the coefficient
+// array shifted down by one (CommitmentScheme.hs:43-44 with z = 0).  The prefix-sum form above multiplies by z^{-1-j} and
+// cannot express it (0^-1 is not defined; k_fr_with_inverse returns 0 for it).
+static MsmJob open_job_at_zero(hipStream_t st, const sonic_srs* srs, const Fr* poly, long len, Fr* d_fz, MsmSlot* slot, int* d_flags) {
+  const long d = srs_d(srs);
+  HIP_OK(hipMemcpyAsync(d_fz, poly, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  const long qn = len - 1;                 // quotient exponents [0, len - 2]
+  long i1 = d + 1;
+  if (i1 > qn) i1 = qn;
+  flag_nonzero_enqueue(st, poly + 1 + i1, qn - i1, d_flags, FLAG_SRS_INDEX);
+  return MsmJob{srs_basis(srs, 0) + d, poly + 1, i1, slot};
+}
+
 // IN = [y, z, y*z, u, v, y_1..y_Q, z_1..z_Q] from the transcript S = [c1..c4, y, z, ys, zs, u, v]
 __global__ void k_prep_scalars(const Fr* __restrict__ S, long Q, Fr* __restrict__ IN) {
   long t = threadIdx.x + (long)blockIdx.x * blockDim.x;
@@ -630,7 +643,9 @@ int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms
   fr_to_mont_enqueue(st, zin.as<Fr>(), 1, flags.as<int>());
   fr_with_inverse_enqueue(st, zin.as<Fr>(), 1, zpair.as<Fr>());
   Scratch sc;
-  MsmJob job = open_job(st, srs, sc, f.c.as<Fr>(), f.lo, f.len, zpair.as<Fr>(), fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>());
+  MsmJob job = bytes_are_zero(z, 32)
+                   ? open_job_at_zero(st, srs, f.c.as<Fr>(), f.len, fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>())
+                   : open_job(st, srs, sc, f.c.as<Fr>(), f.lo, f.len, zpair.as<Fr>(), fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>());
   run_jobs(st, srs, shared_msm_ws(), &job, 1);
   fr_from_mont_enqueue(st, fz.as<Fr>(), 1);
   MsmSlot h;

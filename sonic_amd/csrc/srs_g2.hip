@@ -96,6 +96,41 @@ __global__ __launch_bounds__(256) void k_g2_points_to_bytes(const G2Affine* __re
   for (int k = 0; k < 12; k++) { w[k] = a.l[k]; w[12 + k] = b.l[k]; w[24 + k] = c.l[k]; w[36 + k] = e.l[k]; }
 }
 
+// Caller-supplied G2 elements (an SRS file, sonic_srs_set_g2_points): canonical coordinates, on the twist
+// y^2 = x^3 + 4(u + 1), and r P = O (E'(Fq2) has a large cofactor and the pairing is bilinear only on the order-r
+// subgroup).  err bits as on the G1 side: 1 non-canonical, 2 off the curve, 4 outside the subgroup.
+__global__ __launch_bounds__(64, 1) void k_g2_points_from_bytes(const uint8_t* __restrict__ in, G2Affine* __restrict__ out, long n, int* err) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(in + 192 * i);
+  G2Affine p;
+  for (int k = 0; k < 12; k++) { p.x.c0.l[k] = w[k]; p.x.c1.l[k] = w[12 + k]; p.y.c0.l[k] = w[24 + k]; p.y.c1.l[k] = w[36 + k]; }
+  if (!fp_is_canonical(p.x.c0) || !fp_is_canonical(p.x.c1) || !fp_is_canonical(p.y.c0) || !fp_is_canonical(p.y.c1)) {
+    atomicOr(err, 1); out[i] = G2Affine::inf(); return;
+  }
+  uint32_t nz = 0;
+  for (int k = 0; k < 48; k++) nz |= w[k];
+  if (!nz) { out[i] = G2Affine::inf(); return; }
+  p.x.c0 = fp_to_mont(p.x.c0); p.x.c1 = fp_to_mont(p.x.c1); p.y.c0 = fp_to_mont(p.y.c0); p.y.c1 = fp_to_mont(p.y.c1);
+  Fq2 b; b.c0 = fp_dbl(fp_dbl(Fq::one())); b.c1 = b.c0;
+  if (!(f2_sqr(p.y) == f2_add(f2_mul(f2_sqr(p.x), p.x), b))) { atomicOr(err, 2); out[i] = G2Affine::inf(); return; }
+  constexpr uint32_t rl[8] = FR_P;
+  G2Jac acc; acc.x = p.x; acc.y = p.y; acc.z = Fq2::one();       // top bit (254) of r
+#pragma unroll 1
+  for (int bit = 253; bit >= 0; bit--) {
+    acc = g2_dbl(acc);
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k == (bit >> 5)) word = rl[k];
+    if ((word >> (bit & 31)) & 1u) acc = g2_add_mixed(acc, p);
+  }
+  if (!acc.is_inf()) { atomicOr(err, 4); out[i] = G2Affine::inf(); return; }
+  out[i] = p;
+}
+void g2_points_from_bytes_enqueue(hipStream_t st, const uint8_t* d_in, G2Affine* out, long n, int* d_err) {
+  if (n > 0) LAUNCH(k_g2_points_from_bytes, ceil_div(n, 64), 64, 0, st, d_in, out, n, d_err);
+}
+
 // fills h0 / h1 (2d+1 affine points each)
 void srs_generate_g2(hipStream_t st, long d, const Fr& x_std, const Fr& alpha_std, G2Affine* h0, G2Affine* h1) {
   const long n = 2 * d + 1;

@@ -184,7 +184,12 @@ bool load_g1(const uint8_t* b, G1Affine& p) {
   if (!fp_is_canonical(p.x) || !fp_is_canonical(p.y)) return false;
   p.x = fp_to_mont(p.x); p.y = fp_to_mont(p.y);
   Fq four = fp_dbl(fp_dbl(Fq::one()));
-  return fp_sqr(p.y) == fp_add(fp_mul(fp_sqr(p.x), p.x), four);
+  if (!(fp_sqr(p.y) == fp_add(fp_mul(fp_sqr(p.x), p.x), four))) return false;
+  // E(Fq) has cofactor points (e.g. (0, 2), order 3) and the pairing is bilinear only on the order-r subgroup: points that
+  // come from a prover must satisfy r P = O before they reach the Miller loop
+  constexpr uint32_t rl[8] = FR_P;
+  Fr r_std; for (int i = 0; i < 8; i++) r_std.l[i] = rl[i];
+  return g1_mul_fr(p, r_std).is_inf();
 }
 bool load_g2(const uint8_t* b, G2Affine& p) {
   memcpy(p.x.c0.l, b, 48); memcpy(p.x.c1.l, b + 48, 48); memcpy(p.y.c0.l, b + 96, 48); memcpy(p.y.c1.l, b + 144, 48);
@@ -262,7 +267,7 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
     for (int64_t j = 0; j < Q; j++) enc = enc && F(spj[j]) && G(Wpj[j]) && G(Qj[j]);
     enc = enc && G(Qv) && G(C) && F(u) && F(v) && load_fr(y, ym) && load_fr(z, zm);
     for (int64_t j = 0; j < Q; j++) enc = enc && load_fr(yzs + 64 * j, ys[j]) && load_fr(yzs + 64 * j + 32, zs[j]);
-    if (!enc) { set_error("verify: non-canonical field element or point off the curve"); return SONIC_ERR_BAD_ENCODING; }
+    if (!enc) { set_error("verify: non-canonical field element, or point off the curve or outside the order-r subgroup"); return SONIC_ERR_BAD_ENCODING; }
     // k(y) = sum_q cs[q] y^{n+q}                                  (Constraints.hs:67-68)
     Fr ky = Fr::zero(), pw = fr_pow(ym, (uint64_t)n);
     for (int64_t q = 0; q < Q; q++) { Fr c; if (!load_fr(cs + 32 * q, c)) return SONIC_ERR_BAD_ENCODING; pw = fp_mul(pw, ym); ky = fp_add(ky, fp_mul(c, pw)); }

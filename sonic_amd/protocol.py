@@ -4,13 +4,13 @@ from __future__ import annotations
 
 import ctypes as C
 import secrets
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
 import numpy as np
 
 from . import _lib
-from .encoding import R_MODULUS, fr_array, fr_matrix, g1_from_bytes
+from .encoding import R_MODULUS, fr_array, fr_matrix, fr_to_bytes, g1_from_bytes, g1_to_bytes
 from .srs import SRS
 
 
@@ -56,13 +56,30 @@ class Proof:                 # Protocol.hs:28-38
     prWt: object
     prS: int
     prHscProof: HscProof
-    raw: bytes = field(default=b"", repr=False, compare=False)
 
     def to_bytes(self) -> bytes:
-        return self.raw
+        """canonical proof bytes (include/sonic_hip.h): the record order of `Proof` then `HscProof`, serialised from the
+        fields -- an edited or hand-built Proof is what gets verified, never a cached copy of the prover's output"""
+        h = self.prHscProof
+        if len(h.hscS) != len(h.hscW):
+            raise ValueError("HscProof: hscS and hscW must have one entry per linear constraint")
+
+        def fr_to_bytes(v):          # as is: a non-canonical field element must reach the verifier (which rejects it) unreduced
+            return int(v).to_bytes(32, "little")
+        out = [g1_to_bytes(self.prR), g1_to_bytes(self.prT), fr_to_bytes(self.prA), g1_to_bytes(self.prWa), fr_to_bytes(self.prB),
+               g1_to_bytes(self.prWb), g1_to_bytes(self.prWt), fr_to_bytes(self.prS)]
+        for cm, (sj, wj) in h.hscS:
+            out += [g1_to_bytes(cm), fr_to_bytes(sj), g1_to_bytes(wj)]
+        for sjp, wjp, qj in h.hscW:
+            out += [fr_to_bytes(sjp), g1_to_bytes(wjp), g1_to_bytes(qj)]
+        out += [g1_to_bytes(h.hscQv), g1_to_bytes(h.hscC), fr_to_bytes(h.hscU), fr_to_bytes(h.hscV)]
+        return b"".join(out)
 
     @classmethod
     def from_bytes(cls, b: bytes, Q: int) -> "Proof":
+        b = bytes(b)
+        if len(b) != (7 + 4 * Q) * 96 + (5 + 2 * Q) * 32:
+            raise ValueError(f"proof for Q = {Q} is {(7 + 4 * Q) * 96 + (5 + 2 * Q) * 32} bytes, got {len(b)}")
         pos = 0
 
         def g():
@@ -85,8 +102,7 @@ class Proof:                 # Protocol.hs:28-38
             sjp, wjp, qj = f(), g(), g()
             hscW.append((sjp, wjp, qj))
         qv, c, u, v = g(), g(), f(), f()
-        assert pos == len(b)
-        return cls(prR, prT, prA, prWa, prB, prWb, prWt, prS, HscProof(hscS, hscW, qv, c, u, v), bytes(b))
+        return cls(prR, prT, prA, prWa, prB, prWb, prWt, prS, HscProof(hscS, hscW, qv, c, u, v))
 
 
 @dataclass
@@ -159,7 +175,7 @@ def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: O
         raise _lib.SonicError(1, f"Parameter d is not large enough: {srs.srsD} should be greater than {7 * n}")
     if transcript is None:
         transcript = draw_transcript(Q, rng)
-    p = Prover(srs, circuit)
+    p = Prover(srs, circuit, prepare=False)   # one proof: committing the constraint rows first would only add MSMs
     try:
         p.set_assignment(assignment)
         raw = p.prove_bytes(transcript)
@@ -172,14 +188,25 @@ def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: O
 
 def verify(srs: SRS, circuit: ArithCircuit, proof: Proof, y: int, z: int, yzs) -> bool:
     """verify :: SRS -> ArithCircuit Fr -> Proof -> Fr -> Fr -> [(Fr, Fr)] -> Bool (Protocol.hs:111-130), with
-    hscVerify (Signature.hs:74-90).  Runs on the host CPU (pairings); the SRS must come from SRS.new (G2 half)."""
-    from .encoding import fr_to_bytes
+    hscVerify (Signature.hs:74-90).  Runs on the host CPU (pairings); the SRS needs its G2 half (SRS.new, or a file
+    that carries it).  Shapes are checked here because the C side reads 64 Q bytes of yzs and sonic_proof_size(Q)
+    bytes of proof; a Proof whose hsc lists do not have Q entries is rejected (False), like any other malformed proof."""
     w = circuit.weights
     wL, wR, wO = fr_matrix(w.wL), fr_matrix(w.wR), fr_matrix(w.wO)
     cs = fr_array(circuit.cs)
     Q = cs.shape[0]
+    if Q < 1 or wL.shape[0] % Q or wL.shape[0] == 0 or wR.shape != wL.shape or wO.shape != wL.shape:
+        raise ValueError("verify: need Q >= 1 weight rows of equal length n >= 1 in wL, wR, wO")
     n = wL.shape[0] // Q
+    yzs = list(yzs)
+    if len(yzs) != Q or any(len(pair) != 2 for pair in yzs):
+        raise ValueError(f"verify: yzs must hold {Q} (y_j, z_j) pairs, got {len(yzs)}")
+    h = proof.prHscProof
+    if len(h.hscS) != Q or len(h.hscW) != Q:
+        return False
     raw = proof.to_bytes()
+    if len(raw) != _lib.lib().sonic_proof_size(Q):
+        return False
     flat = fr_array([v for pair in yzs for v in pair])
     ok = C.c_int(0)
     _lib.check(_lib.lib().sonic_verify(srs._h, n, Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data, cs.ctypes.data, raw,

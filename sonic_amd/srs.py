@@ -13,7 +13,8 @@ class SRS:
     """`data SRS` (SRS.hs:11-22), prover half.  Device layout: two arrays of 2d+1 affine points,
     basis 0 = g^{x^e}, basis 1 = g^{alpha x^e}, slot e + d; the reference's four G1 vectors are views:
     gNegativeX[k] = basis0[-(k+1)], gPositiveX[k] = basis0[k], gNegativeAlphaX[k] = basis1[-(k+1)],
-    gPositiveAlphaX[k] = basis1[k+1].  The G2 vectors (verifier only) are generated lazily on first access."""
+    gPositiveAlphaX[k] = basis1[k+1].  The G2 vectors (verifier only) are generated lazily on first access, after which
+    the handle forgets x and alpha."""
 
     def __init__(self, handle: C.c_void_p, d: int):
         self._h = handle
@@ -36,9 +37,17 @@ class SRS:
         _lib.check(_lib.lib().sonic_srs_from_points(d, b0.ctypes.data, b1.ctypes.data, C.byref(h)))
         return cls(h, d)
 
-    def save(self, path: str) -> None:
-        """write the G1 bases to disk (format in include/sonic_hip.h)"""
-        _lib.check(_lib.lib().sonic_srs_save(self._h, str(path).encode()))
+    def set_g2_points(self, basis0: np.ndarray, basis1: np.ndarray) -> None:
+        """attach the verifier half to a handle built from G1 points: uint8 [(2d+1), 192] per basis, validated"""
+        b0 = np.ascontiguousarray(basis0, np.uint8)
+        b1 = np.ascontiguousarray(basis1, np.uint8)
+        assert b0.size == 192 * (2 * self.srsD + 1) and b1.size == 192 * (2 * self.srsD + 1)
+        _lib.check(_lib.lib().sonic_srs_set_g2_points(self._h, b0.ctypes.data, b1.ctypes.data))
+
+    def save(self, path: str, g2: bool = True) -> None:
+        """write the SRS to disk (format in include/sonic_hip.h): the G1 bases and, with g2, the G2 bases, so that the
+        loaded handle can verify as well as prove.  The file never holds the trapdoor."""
+        _lib.check(_lib.lib().sonic_srs_save(self._h, str(path).encode(), 1 if g2 else 0))
 
     @classmethod
     def load(cls, path: str) -> "SRS":

@@ -63,22 +63,41 @@ def test_msm_srs_slices(sonic, orc, srs_pair, n, kind):
 
 
 def test_srs_file_round_trip(sonic, orc, srs_pair, tmp_path):
-    """SRS on disk: save -> load gives the same points (validated on load), the same commitments; corrupt files are refused"""
+    """SRS on disk: save -> load gives the same points (validated on load), the same commitments, and -- with the G2 half in
+    the file -- a handle that verifies without ever having seen x or alpha; corrupt files are refused"""
     d, x, alpha, g, o = srs_pair
     path = tmp_path / "srs.bin"
     g.save(path)
-    assert path.stat().st_size == 24 + 2 * (2 * d + 1) * 96
+    n = 2 * d + 1
+    assert path.stat().st_size == 24 + 2 * n * 96 + 2 * n * 192
     l = sonic.SRS.load(path)
     assert l.srsD == d
     for basis in (0, 1):
-        assert np.array_equal(l.points(basis, -d, 2 * d + 1), g.points(basis, -d, 2 * d + 1))
+        assert np.array_equal(l.points(basis, -d, n), g.points(basis, -d, n))
+        assert np.array_equal(l.g2_points(basis, -d, n), g.g2_points(basis, -d, n))
     f = {e: (e * e + 7) % R for e in range(-300, 200) if e != 0}
-    assert sonic.commit_poly(l, d, f) == sonic.commit_poly(g, d, f)
+    F = sonic.commit_poly(l, d, f)
+    assert F == sonic.commit_poly(g, d, f)
+    op = sonic.open_poly(l, 12345, f)
+    assert sonic.pc_v(l, d, F, 12345, op) and not sonic.pc_v(l, d, F, 12346, op)       # pairing check on the loaded handle
+    g1only = tmp_path / "g1.bin"
+    g.save(g1only, g2=False)
+    assert g1only.stat().st_size == 24 + 2 * n * 96
+    l1 = sonic.SRS.load(g1only)
+    assert sonic.commit_poly(l1, d, f) == F
     with pytest.raises(sonic.SonicError):
-        l.hPositiveX(0)                              # a loaded SRS has no trapdoor, hence no G2 half
+        l1.hPositiveX(0)                             # G1-only file: no G2 half, and no trapdoor to make one from
+    l1.set_g2_points(g.g2_points(0, -d, n), g.g2_points(1, -d, n))
+    assert l1.hPositiveX(1) == g.hPositiveX(1) and sonic.pc_v(l1, d, F, 12345, op)
     raw = bytearray(path.read_bytes())
-    raw[24 + 96 * 5] ^= 1                            # a point off the curve
+    raw[24 + 96 * 5] ^= 1                            # a G1 point off the curve
     bad = tmp_path / "bad.bin"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.SRS.load(bad)
+    assert e.value.code == 3
+    raw = bytearray(path.read_bytes())
+    raw[24 + 2 * n * 96 + 192 * 7 + 3] ^= 1          # a G2 point off the twist
     bad.write_bytes(bytes(raw))
     with pytest.raises(sonic.SonicError) as e:
         sonic.SRS.load(bad)
@@ -86,6 +105,68 @@ def test_srs_file_round_trip(sonic, orc, srs_pair, tmp_path):
     bad.write_bytes(bytes(raw[:1000]))
     with pytest.raises(sonic.SonicError):
         sonic.SRS.load(bad)
+    bad.write_bytes(path.read_bytes() + b"\0")
+    with pytest.raises(sonic.SonicError):
+        sonic.SRS.load(bad)
+
+
+def test_srs_points_must_be_in_the_subgroup(sonic, srs_pair):
+    """E(Fq) has cofactor points -- (0, 2) has order 3 -- and MSMs over an SRS fold scalars with r P = O, so the record
+    constructor refuses points outside the order-r subgroup; the same for the G2 vectors (a point on the twist is almost
+    never in G2: the cofactor is ~2^508)"""
+    d, x, alpha, g, o = srs_pair
+    n = 2 * d + 1
+    b0, b1 = g.points(0, -d, n), g.points(1, -d, n)
+    ok = sonic.SRS.from_points(d, b0, b1)
+    assert np.array_equal(ok.points(0, -d, n), b0)
+    bad = b0.copy()
+    bad[17] = np.frombuffer((0).to_bytes(48, "little") + (2).to_bytes(48, "little"), np.uint8)
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.SRS.from_points(d, bad, b1)
+    assert e.value.code == 3 and "subgroup" in e.value.message
+    # a point on the twist y^2 = x^3 + 4(u+1) outside G2: scan x = k (in Fq) until x^3 + 4(u+1) is a square in Fq2
+    from oracle import pairing as pg
+    Qm = pg.Q
+
+    def fq_sqrt(a):                                  # q = 3 mod 4
+        s_ = pow(a, (Qm + 1) // 4, Qm)
+        return s_ if s_ * s_ % Qm == a % Qm else None
+
+    def f2_sqrt(a):
+        s_ = fq_sqrt((a[0] * a[0] + a[1] * a[1]) % Qm)
+        if s_ is None:
+            return None
+        inv2 = pow(2, -1, Qm)
+        for t in ((a[0] + s_) * inv2 % Qm, (a[0] - s_) * inv2 % Qm):
+            x0 = fq_sqrt(t)
+            if x0:
+                y_ = (x0, a[1] * pow(2 * x0, -1, Qm) % Qm)
+                if pg.f2_sqr(y_) == (a[0] % Qm, a[1] % Qm):
+                    return y_
+        return None
+
+    pt = None
+    for k in range(1, 200):
+        y = f2_sqrt(pg.f2_add(pg.f2_mul(pg.f2_sqr((k, 0)), (k, 0)), (4, 4)))
+        if y is not None:
+            pt = ((k, 0), y)
+            break
+    assert pt is not None
+    h0, h1 = g.g2_points(0, -d, n), g.g2_points(1, -d, n)
+    enc = b"".join(int(v).to_bytes(48, "little") for v in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]))
+    h0b = h0.copy()
+    h0b[3] = np.frombuffer(enc, np.uint8)
+    with pytest.raises(sonic.SonicError) as e:
+        ok.set_g2_points(h0b, h1)
+    assert e.value.code == 3 and "subgroup" in e.value.message
+    h0b[3, 5] ^= 1
+    with pytest.raises(sonic.SonicError) as e:
+        ok.set_g2_points(h0b, h1)
+    assert e.value.code == 3 and "twist" in e.value.message
+    with pytest.raises(sonic.SonicError):
+        ok.hPositiveX(0)                             # nothing was attached by the refused calls
+    ok.set_g2_points(h0, h1)
+    assert ok.hPositiveAlphaX(1) == g.hPositiveAlphaX(1)
 
 
 def test_srs_g2_half(sonic, srs_pair):
@@ -478,6 +559,22 @@ def test_product_verifier(sonic, ref, srs_pair):
     bad = sonic.Proof.from_bytes(bytes(raw), Q)
     assert not sonic.verify(g, circuit, bad, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
     assert not sonic.verify(g, circuit, proof, ro.rndOracleY, (ro.rndOracleZ + 1) % R, ro.rndOracleYZs)
+    # the Proof object is what gets verified: edited fields are serialised, not a cached copy of the prover's bytes
+    import dataclasses
+    assert not sonic.verify(g, circuit, dataclasses.replace(proof, prB=(proof.prB + 1) % R), ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    assert sonic.verify(g, circuit, dataclasses.replace(proof, prB=proof.prB), ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    # shapes are checked before the C side reads 64 Q bytes of yzs / sonic_proof_size(Q) bytes of proof
+    with pytest.raises(ValueError):
+        sonic.verify(g, circuit, proof, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs[:1])
+    short = dataclasses.replace(proof, prHscProof=dataclasses.replace(proof.prHscProof, hscS=proof.prHscProof.hscS[:1], hscW=proof.prHscProof.hscW[:1]))
+    assert not sonic.verify(g, circuit, short, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    # proof points must lie in the order-r subgroup: the cofactor point (0, 2) is on the curve and is refused
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.verify(g, circuit, dataclasses.replace(proof, prWa=(0, 2)), ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    assert e.value.code == 3
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.verify(g, circuit, dataclasses.replace(proof, prA=R + 5), ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)   # non-canonical Fr
+    assert e.value.code == 3
     # pcV on r(X,1) with max = n (test/Test/CommitmentScheme.hs:58-71), against the oracle's pairing check
     rX1 = ref.eval_y(1, ref.r_poly(*asg))
     z = pyr.randrange(1, R)
@@ -518,6 +615,23 @@ def test_commit_open_degenerate_inputs(sonic, orc, ref, srs_pair):
                 sonic.open_poly(g, z, f)
             continue
         assert sonic.open_poly(g, z, f) == want
+
+
+def test_open_poly_at_zero(sonic, ref, srs_pair):
+    """openPoly at z = 0 of a polynomial without negative exponents: f(0) = c_0 and W = Commit_plain((f - c_0)/X)
+    (CommitmentScheme.hs:43-48); with negative exponents `eval` would need 0^-1"""
+    d, x, alpha, g, o = srs_pair
+    s = ref.SRS(d, x, alpha)
+    fz, W = sonic.open_poly(g, 0, {1: 5})
+    assert fz == 0 and W == ref.g1_mul(ref.G1_GEN, 5)                    # (5X - 0)/X = 5 -> g^5
+    pyr = random.Random(11)
+    for f in ({0: 7}, {0: 7, 1: 3}, {3: 9}, {0: 1, 1: 2, 2: 3, 40: R - 1}, _sparse_poly(pyr, 0, 300), _sparse_poly(pyr, 1, 90)):
+        assert sonic.open_poly(g, 0, f) == ref.open_poly(s, 0, f)
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.open_poly(g, 0, {0: 1, d + 2: 5})                           # quotient term X^{d+1}: past gPositiveX
+    assert e.value.code == 2
+    fz, W = sonic.open_poly(g, 0, {0: 1, d + 1: 5})                       # X^d is the last element: fine
+    assert (fz, W) == ref.open_poly(s, 0, {0: 1, d + 1: 5})
 
 
 def test_msm_zero_and_identity_scalars(sonic, orc, srs_pair):
