@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel HIP-event totals to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
+    ap.add_argument("--no-two-handles", action="store_true", help="skip the two-handle throughput leg (timelines of one solo proof)")
     ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
     args = ap.parse_args()
 
@@ -154,7 +155,7 @@ def main():
 
     # ---------------- extra (rank 0, reported beside the headline, never as `value`): two prover handles on two host threads ----
     two_handles = None
-    if prover is not None and rank == 0 and K_prove >= 2 and not args.kernel_table:
+    if prover is not None and rank == 0 and K_prove >= 2 and not args.kernel_table and not args.no_two_handles:
         import threading
         p2 = sonic_amd.Prover(srs, sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
         p2.set_assignment(sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"]))

@@ -216,6 +216,11 @@ def lp_divide_linear(p: dict, z: int) -> dict:
     p = lp_norm(p)
     if not p:
         return {}
+    if z % R == 0:
+        # X - 0 = X is a unit of the Laurent ring: the quotient is the shift by one, always exact.  (The shift-and-Horner
+        # restatement below needs z != 0: X^-lo is only a unit at z != 0.)  openPoly reaches this with a polynomial without
+        # negative exponents only -- `eval` at 0 of a negative power has already failed (lp_eval: 0^-1).
+        return lp_norm({e - 1: c for e, c in p.items()})
     lo, hi = min(p), max(p)
     coeffs = [p.get(e, 0) for e in range(lo, hi + 1)]  # ascending, degree D = hi-lo
     D = hi - lo

@@ -238,8 +238,16 @@ HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
 template <class P>
 HD Fp<P> fp_dbl(const Fp<P>& a) { return fp_add(a, a); }
 
+// a^2: on the device Fq has its own routine (78 instead of 144 partial products, mont_asm.hpp)
 template <class P>
-HD Fp<P> fp_sqr(const Fp<P>& a) { return fp_mul(a, a); }
+HD Fp<P> fp_sqr(const Fp<P>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SONIC_NO_ASM_MUL)
+  if constexpr (P::N == FQ_LIMBS) return sonic_mont_sqr_fq_call(a);
+  else return fp_mul(a, a);
+#else
+  return fp_mul(a, a);
+#endif
+}
 
 template <class P>
 HD Fp<P> fp_to_mont(const Fp<P>& a) { return fp_mul(a, Fp<P>::r2()); }

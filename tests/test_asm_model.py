@@ -27,7 +27,8 @@ class Lane:
 
     def __init__(self, core_prog=None):
         self.v, self.s, self.c, self.exec, self.saved = {}, {}, {}, True, {}
-        self.core_prog = core_prog
+        self.core_prog = core_prog      # one routine, or {symbol: routine}
+        self.target, self.calls = None, []
         self.trace = []          # (kind, carry-register) per issued instruction, for the hazard check
 
     def rd(self, tok):
@@ -59,11 +60,17 @@ class Lane:
         if op == "s_nop":
             self.trace.extend([("nop", None, None)] * (int(a[0]) + 1))
             return
-        if op in ("s_setpc_b64", "s_getpc_b64", "s_add_u32", "s_addc_u32"):
+        if op == "s_add_u32":                        # the call sequence names its target routine here
+            m = re.search(r"(sonic_mont_\w+)@rel32", rest)
+            if m:
+                self.target = m.group(1)
+            return
+        if op in ("s_setpc_b64", "s_getpc_b64", "s_addc_u32"):
             return
         if op == "s_swappc_b64":
             assert self.core_prog is not None
-            self.run(self.core_prog)
+            self.run(self.core_prog[self.target] if isinstance(self.core_prog, dict) else self.core_prog)
+            self.calls.append(self.target)
             return
         if op == "s_mov_b32":
             self.s[a[0]] = self.rd(a[1])
@@ -101,7 +108,7 @@ class Lane:
                 self.c[a[1]] = int(r > M32 or r < 0)
             carry_write = a[1]
         elif op in ("v_addc_co_u32_e32", "v_addc_co_u32_e64", "v_subb_co_u32_e32", "v_subb_co_u32_e64"):
-            x, y, cin = self.rd(a[2]), self.rd(a[3]), self.c[a[4]]
+            x, y, cin = self.rd(a[2]), self.rd(a[3]), (self.c[a[4]] if self.exec else self.c.get(a[4], 0))   # a masked lane's carry is never used
             r = x + y + cin if "addc" in op else x - y - cin
             self.wr(a[0], r)
             if self.exec:
@@ -110,6 +117,10 @@ class Lane:
         elif op in ("v_cndmask_b32_e64", "v_cndmask_b32_e32"):
             self.wr(a[0], self.rd(a[2]) if self.c[a[3]] else self.rd(a[1]))
             carry_read = a[3]
+        elif op == "v_alignbit_b32":
+            self.wr(a[0], (((self.rd(a[1]) << 32) | self.rd(a[2])) >> (self.rd(a[3]) & 31)))
+        elif op == "v_lshlrev_b32_e32":
+            self.wr(a[0], self.rd(a[2]) << (self.rd(a[1]) & 31))
         elif op == "v_or3_b32":
             self.wr(a[0], self.rd(a[1]) | self.rd(a[2]) | self.rd(a[3]))
         elif op == "v_or_b32_e32":
@@ -141,9 +152,16 @@ def unlimbs(ws):
     return sum(w << (32 * i) for i, w in enumerate(ws))
 
 
-def run_mul(name, N, p, lazy, a, b, core=False):
-    body, nv, res = G.function_text(name, N, p, lazy=lazy, core=core)
+CD_BASE = G.CD_BASE       # where the fused mixed addition keeps c and d of the two-product routine (its banks R3 and R2)
+
+
+def run_mul(name, N, p, lazy, a, b, core=False, kind="mul", c=0, d=0):
+    body, nv, res = G.function_text(name, N, p, lazy=lazy, core=core, kind=kind, cd_base=CD_BASE if kind == "mul2" else None)
     lane = Lane()
+    if kind == "mul2":
+        for j in range(N):
+            lane.v[f"v{CD_BASE[0] + j}"] = limbs(c, N)[j]
+            lane.v[f"v{CD_BASE[1] + j}"] = limbs(d, N)[j]
     if core:   # what the fused caller provides: modulus SGPRs, zero halves, T_N = 0
         inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
         for j in range(N):
@@ -178,6 +196,38 @@ def test_montgomery_product_model(name, N, p, lazy, core):
             r, _ = run_mul(name, N, p, lazy, a, b, core)
             assert r % p == a * b * pow(Rm, -1, p) % p, (name, hex(a), hex(b))
             assert r < (2 * p if lazy else p), (name, "range", hex(a), hex(b))
+
+
+@pytest.mark.parametrize("core", [False, True])
+def test_montgomery_square_model(core):
+    """the 78-product squaring: a * a * R^-1 in the lazy range, for every representative a < 2q; B registers are scratch"""
+    N, p = 12, G.Q
+    rng = random.Random(300 + core)
+    Rm = 1 << (32 * N)
+    extra = [2 * p - 1, 2 * p - 2, (1 << 381) - 1, (1 << 381), p + (1 << 380), 0x80000000, 0xFFFFFFFF << 32, int("80000000" * 11, 16)]
+    for a in operands(rng, p, 2 * p) + [v for v in extra if v < 2 * p] + [rng.randrange(2 * p) for _ in range(40)]:
+        junk = rng.randrange(1 << 384)                  # whatever the B registers held before
+        r, lane = run_mul("sqr", N, p, True, a, junk, core, kind="sqr")
+        assert r % p == a * a * pow(Rm, -1, p) % p, hex(a)
+        assert r < 2 * p
+        assert unlimbs([lane.v[f"v{j}"] for j in range(N)]) == a          # the operand survives
+
+
+def test_montgomery_two_product_model():
+    """a * b + c * d with one reduction: congruent to (ab + cd) R^-1 and below 2q for a, b, c, d < 2q and for c = 2q (the negated
+    Y1 = 0 of the fused addition); T_N ends as 0 (what the next core call relies on)"""
+    N, p = 12, G.Q
+    rng = random.Random(411)
+    Rm = 1 << (32 * N)
+    ops = operands(rng, p, 2 * p)
+    cases = [(2 * p - 1,) * 4, (2 * p - 1, 2 * p - 1, 2 * p, 2 * p - 1), (0, 0, 0, 0), (1, 1, 2 * p, 1), (0, 5, 2 * p, 2 * p - 1)]
+    cases += [tuple(ops[rng.randrange(len(ops))] for _ in range(4)) for _ in range(40)]
+    cases += [tuple(rng.randrange(2 * p) for _ in range(4)) for _ in range(40)]
+    for a, b, c, d in cases:
+        r, lane = run_mul("mul2", N, p, True, a, b, True, kind="mul2", c=c, d=d)
+        assert r % p == (a * b + c * d) * pow(Rm, -1, p) % p, (hex(a), hex(b), hex(c), hex(d))
+        assert r < 2 * p
+        assert lane.v[f"v{2 * N + 2 * N}"] == 0
 
 
 @pytest.mark.parametrize("sub", [True, False])
@@ -223,8 +273,10 @@ def xyzz_madd(p, X1, Y1, ZZ1, ZZZ1, x2, y2):
 def run_fused(acc, q, special):
     N, p = 12, G.Q
     L, nv = G.fused_madd_program(p)
-    core, _, _ = G.function_text("core", N, p, lazy=True, core=True)
-    lane = Lane(core_prog=core)
+    cores = {"sonic_mont_mul_fq_core": G.function_text("core", N, p, lazy=True, core=True)[0],
+             "sonic_mont_sqr_fq_core": G.function_text("core", N, p, lazy=True, core=True, kind="sqr")[0],
+             "sonic_mont_mul2_fq_core": G.function_text("core", N, p, lazy=True, core=True, kind="mul2", cd_base=G.CD_BASE)[0]}
+    lane = Lane(core_prog=cores)
     for k in range(4):
         for j in range(N):
             lane.v[f"%{k * N + j}"] = limbs(acc[k], N)[j]
@@ -234,6 +286,8 @@ def run_fused(acc, q, special):
     lane.v[f"%{6 * N + 1}"] = special
     lane.run(L)
     assert lane.exec is True, "EXEC not restored"
+    lane.check_carry_hazard()
+    assert sorted(lane.calls) == ["sonic_mont_mul2_fq_core"] + ["sonic_mont_mul_fq_core"] * 6 + ["sonic_mont_sqr_fq_core"] * 2
     out = [unlimbs([lane.v[f"%{k * N + j}"] for j in range(N)]) for k in range(4)]
     return out, lane.v[f"%{4 * N}"]
 
@@ -242,9 +296,11 @@ def test_fused_mixed_addition_model():
     p = G.Q
     rng = random.Random(2024)
     rep = lambda v: v + p if (rng.random() < 0.5 and v + p < 2 * p) else v          # either representative of the residue
-    for _ in range(12):
+    for it in range(16):
         acc = [rng.randrange(p) for _ in range(4)]
         q = [rng.randrange(p) for _ in range(2)]
+        if it == 0:
+            acc[1] = 0                               # Y1 = 0: the negated operand of the two-product core is 2q itself
         want = xyzz_madd(p, *acc, *q)
         got, exc = run_fused([rep(v) for v in acc], [rep(v) for v in q], 0)
         assert exc == 0 and all(g < 2 * p for g in got)

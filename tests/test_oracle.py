@@ -182,6 +182,29 @@ def test_error_contract(orc, ref):
     assert e.value.code == 2
 
 
+def test_open_poly_at_zero_both_oracles(orc, ref):
+    """openPoly at z = 0 (CommitmentScheme.hs:43-48): f(0) = c_0 and the quotient is (f - c_0)/X -- X is a unit of the
+    Laurent ring, so `divide` is exact; the python restatement, the C oracle and a direct group computation agree"""
+    d, x, alpha = 40, 1234567, 7654321
+    s, o = ref.SRS(d, x, alpha), orc.SRS(d, x, alpha, threads=2)
+    assert ref.open_poly(s, 0, {1: 5}) == (0, ref.g1_mul(ref.G1_GEN, 5))
+    pyr = random.Random(17)
+    for f in ({0: 7}, {0: 7, 1: 3}, {3: 9}, {2: 1, 5: R - 1, 30: 12345}, {e: pyr.randrange(1, R) for e in range(0, 35, 3)}):
+        fz, W = ref.open_poly(s, 0, f)
+        assert fz == f.get(0, 0)
+        want = ref.INF
+        for e, c in f.items():
+            if e > 0:
+                want = ref.g1_add(want, ref.g1_mul(s.gPositiveX(e - 1), c))
+        assert W == want
+        exps = np.array(sorted(f), np.int64)
+        ofz, oW = orc.open_poly(o, 0, exps, fr_bytes([f[e] for e in sorted(f)]))
+        assert ofz == fz and oW == (bytes(96) if W is None else W[0].to_bytes(48, "little") + W[1].to_bytes(48, "little"))
+    with pytest.raises(orc.OracleError) as e:
+        orc.open_poly(o, 0, np.array([-2, 1], np.int64), fr_bytes([5, 1]))
+    assert e.value.code == 4
+
+
 def test_oracle_msm_flavours_agree(orc):
     """reference-shaped fold == threaded Pippenger, incl. structured scalars"""
     srs = orc.SRS(600, 3, 5, threads=4)

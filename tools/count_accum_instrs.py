@@ -6,6 +6,7 @@ model of the kernel (every VALU instruction of a wave64 occupies its SIMD for 4 
 back to back, so instructions, not latency, are what the kernel pays for).
 
     python tools/count_accum_instrs.py          # compiles sonic_amd/csrc/msm.hip to ISA in /tmp and prints the counts"""
+import collections
 import os
 import re
 import subprocess
@@ -34,7 +35,9 @@ def main():
     blocks.append(cur)
     calls = [sum(1 for x in b[1] if x.startswith("s_swappc")) for b in blocks]
     index = {b[0]: k for k, b in enumerate(blocks)}
-    hot = calls.index(10)
+    # the hot block is the fused mixed addition: the one that calls the two-product core (else: the block with ten product calls)
+    fused = [k for k, b in enumerate(blocks) if any("sonic_mont_mul2_fq_core@rel32" in x for x in b[1])]
+    hot = fused[0] if fused else calls.index(10)
     # innermost loop around the hot block: smallest [target, source] span of a backward branch that contains it
     span = None
     for k, b in enumerate(blocks):
@@ -43,17 +46,25 @@ def main():
                 t = index.get(x.split()[-1])
                 if t is not None and t <= hot <= k and (span is None or k - t < span[1] - span[0]):
                     span = (t, k)
-    body = [b for k, b in enumerate(blocks) if span[0] <= k <= span[1] and calls[k] in (0, 10)]   # drops the doubling side path
+    body = [b for k, b in enumerate(blocks) if span[0] <= k <= span[1] and (k == hot or calls[k] == 0)]   # drops the doubling side path
     outside = sum(len(b[1]) for b in body)
-    # length of the product routine the hot block calls (the core variant when the fused mixed addition is in use)
-    callee = "sonic_mont_mul_fq_core" if any("sonic_mont_mul_fq_core@rel32" in x for x in blocks[hot][1]) else "sonic_mont_mul_fq"
-    i0 = next(i for i, l in enumerate(L) if l.strip() == callee + ":")
-    i1 = next(i for i in range(i0, len(L)) if L[i].strip().startswith(".size\t" + callee) or L[i].strip().startswith(".size " + callee))
-    routine = sum(1 for l in L[i0 + 1:i1] if l.strip() and not l.strip().startswith((";", ".")))
+    # the routines the hot block calls, by symbol, and their lengths
+    targets = collections.Counter(m.group(1) for x in blocks[hot][1] for m in [re.search(r"(sonic_mont_\w+)@rel32@lo", x)] if m)
+
+    def routine_len(callee):
+        i0 = next(i for i, l in enumerate(L) if l.strip() == callee + ":")
+        i1 = next(i for i in range(i0, len(L)) if L[i].strip().startswith(".size\t" + callee) or L[i].strip().startswith(".size " + callee))
+        body_ = [l.strip() for l in L[i0 + 1:i1] if l.strip() and not l.strip().startswith((";", "."))]
+        return len(body_), sum(1 for l in body_ if l.startswith("v_mad_u64_u32"))
+    total, mads = outside, sum(1 for b in body for x in b[1] if x.startswith("v_mad_u64_u32"))
     print("blocks on the hot path:", [(b[0], len(b[1])) for b in body])
-    print("instructions outside the Montgomery routine per mixed addition:", outside)
-    print("routine:", callee, routine, "x 10")
-    print("total per mixed addition:", outside + 10 * routine)
+    print("instructions outside the Montgomery routines per mixed addition:", outside)
+    for callee, cnt in sorted(targets.items()):
+        n, m = routine_len(callee)
+        print(f"routine: {callee} {n} instructions ({m} v_mad_u64_u32) x {cnt}")
+        total += n * cnt
+        mads += m * cnt
+    print("total per mixed addition:", total, "of which v_mad_u64_u32:", mads)
 
 
 if __name__ == "__main__":

@@ -42,7 +42,19 @@ class Ins:
         self.deps, self.users, self.prio = set(), set(), 0
 
 
-def build(N: int, p: int, lazy: bool = False, core: bool = False):
+def build(N: int, p: int, lazy: bool = False, core: bool = False, kind: str = "mul", cd_base=None):
+    """kind "mul": a * b.
+    kind "sqr": a * a with 78 instead of 144 partial products: row i multiplies a_i by the limbs of
+        a_i 2^(32 i) + 2 (a >> 32 (i+1)) 2^(32 (i+1)),  i.e. a_i itself at position i, (a_(i+1) << 1) at position i + 1 and the
+        limbs x_j = (a_j << 1) | (a_(j-1) >> 31) of 2a above (the doubled high part differs from 2a only in the bit that the
+        shift moves in from a_i); sum_i of these rows is a^2, every product is still 32 x 32 + 32 bits, and position k has all its
+        terms by the time row k reduces it (they come from rows <= k / 2).  Needs a < 2^(32 N - 1) (lazy Fq: a < 2q < 2^382).
+        The x_j live in the B registers (B is not an input); positions below i get no product in row i, so the first carry chain
+        of row i starts at position i.
+    kind "mul2": a * b + c * d with ONE reduction (c in v[cd_base[0] ...], d in v[cd_base[1] ...]): every row adds both
+        products (two carry chains) before its reduction row.  With a, c <= 2q and b, d < 2q the running value stays below
+        5q + epsilon < 2^383.1 (13 limbs suffice) and the result is < q (8 q / R + 1) < 1.82 q: inside the lazy range."""
+    assert kind in ("mul", "sqr", "mul2") and (kind == "mul" or lazy)
     A = lambda j: j
     B = lambda j: N + j
     TPlo = lambda j: 2 * N + 2 * j
@@ -80,20 +92,56 @@ def build(N: int, p: int, lazy: bool = False, core: bool = False):
             emit(f"v_mov_b32_e32 {v(TPhi(j))}, 0", [], [v(TPhi(j))])
         emit(f"v_mov_b32_e32 {v(TPlo(N))}, 0", [], [v(TPlo(N))])
 
-    for i in range(N):
-        # multiplication row: Q_j = a_j * b_i + T_j
-        for j in range(N):
-            if i == 0:
-                emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(A(j))}, {v(B(i))}, 0", [v(A(j)), v(B(i))], [v(QA(j)), v(QA(j) + 1)])
+    Cr = (lambda j: cd_base[0] + j) if kind == "mul2" else None
+    Dr = (lambda j: cd_base[1] + j) if kind == "mul2" else None
+    X = B                                    # "sqr": limbs of 2a (j >= 2); X(0) / X(1) alternate as the (a_(i+1) << 1) temporary
+    if kind == "sqr":
+        for j in range(2, N):
+            emit(f"v_alignbit_b32 {v(X(j))}, {v(A(j))}, {v(A(j - 1))}, 31", [v(A(j)), v(A(j - 1))], [v(X(j))])
+
+    def product_row(i, first, xs, mult, lo=0):
+        """Q_j = xs[j] * mult + T_j for j in [lo, N) (addend 0 when `first`), then the carry chain that folds the Q pairs back
+        into T: T_lo = lo(Q_lo), T_j = lo(Q_j) + hi(Q_(j-1)) + c, T_N += hi(Q_(N-1)) + c."""
+        for j in range(lo, N):
+            if first:
+                emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(xs[j])}, {v(mult)}, 0", [v(xs[j]), v(mult)], [v(QA(j)), v(QA(j) + 1)])
             else:
-                emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(A(j))}, {v(B(i))}, {vp(TPlo(j))}",
-                     [v(A(j)), v(B(i)), v(TPlo(j)), v(TPhi(j))], [v(QA(j)), v(QA(j) + 1)])
-        emit(f"v_mul_lo_u32 {v(M)}, {v(QA(0))}, s{SINV}", [v(QA(0))], [v(M)])
-        emit(f"v_mov_b32_e32 {v(TPlo(0))}, {v(QA(0))}", [v(QA(0))], [v(TPlo(0))])
-        c = C1
-        for j in range(1, N):
-            (add_first if j == 1 else add_carry)(TPlo(j), c, QA(j), QA(j - 1) + 1)
-        add_carry(TPlo(N), c, TPlo(N), QA(N - 1) + 1)
+                emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(xs[j])}, {v(mult)}, {vp(TPlo(j))}",
+                     [v(xs[j]), v(mult), v(TPlo(j)), v(TPhi(j))], [v(QA(j)), v(QA(j) + 1)])
+
+    def fold_chain(c, lo=0):
+        emit(f"v_mov_b32_e32 {v(TPlo(lo))}, {v(QA(lo))}", [v(QA(lo))], [v(TPlo(lo))])
+        started = False
+        for j in range(lo + 1, N):
+            (add_carry if started else add_first)(TPlo(j), c, QA(j), QA(j - 1) + 1)
+            started = True
+        (add_carry if started else add_first)(TPlo(N), c, TPlo(N), QA(N - 1) + 1)
+
+    for i in range(N):
+        if kind == "sqr":
+            xs = {i: A(i)}
+            if i + 1 < N:
+                y = X(i & 1)
+                emit(f"v_lshlrev_b32_e32 {v(y)}, 1, {v(A(i + 1))}", [v(A(i + 1))], [v(y)])
+                xs[i + 1] = y
+            for j in range(i + 2, N):
+                xs[j] = X(j)
+            product_row(i, i == 0, xs, A(i), lo=i)
+            # position 0 of row i > 0 got no product: m comes from T_0 as the previous reduction row left it
+            msrc = QA(0) if i == 0 else TPlo(0)
+            emit(f"v_mul_lo_u32 {v(M)}, {v(msrc)}, s{SINV}", [v(msrc)], [v(M)])
+            fold_chain(C1, lo=i)
+        elif kind == "mul2":
+            product_row(i, i == 0, [A(j) for j in range(N)], B(i))
+            fold_chain(C1)
+            product_row(i, False, [Cr(j) for j in range(N)], Dr(i))
+            emit(f"v_mul_lo_u32 {v(M)}, {v(QA(0))}, s{SINV}", [v(QA(0))], [v(M)])
+            fold_chain(C3)
+        else:
+            # multiplication row: Q_j = a_j * b_i + T_j
+            product_row(i, i == 0, [A(j) for j in range(N)], B(i))
+            emit(f"v_mul_lo_u32 {v(M)}, {v(QA(0))}, s{SINV}", [v(QA(0))], [v(M)])
+            fold_chain(C1)
         # reduction row: R_j = m * p_j + T_j, then shift down one limb
         for j in range(N):
             emit(f"v_mad_u64_u32 {vp(QB(j))}, {JUNK}, {v(M)}, s{SP(j)}, {vp(TPlo(j))}",
@@ -186,8 +234,8 @@ def schedule(prog):
     return out
 
 
-def function_text(name: str, N: int, p: int, lazy: bool = False, core: bool = False):
-    pre, prog, nv, res = build(N, p, lazy, core)
+def function_text(name: str, N: int, p: int, lazy: bool = False, core: bool = False, kind: str = "mul", cd_base=None):
+    pre, prog, nv, res = build(N, p, lazy, core, kind, cd_base)
     body = ([] if core else pre) + schedule(prog) + ["s_setpc_b64 s[30:31]"]
     return body, nv, res
 
@@ -234,6 +282,26 @@ def emit_addsub(L, N, sub, out, a, b, D, Pv, CA, p2):
             L.append(f"v_cndmask_b32_e32 {out[j]}, {out[j]}, {D[j]}, vcc")
 
 
+def emit_negate(L, N, out, a, const, Pv, fillers):
+    """out = const - a (const: python integer): one borrow chain in VCC.  A literal and VCC cannot both feed one VOP2 (one
+    constant-bus read), so the limbs of const above the first go through the scratch registers Pv; those moves and `fillers`
+    (instructions that touch neither VCC nor out / a / Pv) are spent on the two slots the hardware wants between a carry write
+    and its read, s_nop when they run out."""
+    f = [f"v_mov_b32_e32 {Pv[j]}, 0x{limb32(const, j):08x}" for j in range(1, N)] + list(fillers)
+    for j in range(N):
+        if j == 0:
+            L.append(f"v_sub_co_u32_e32 {out[0]}, vcc, 0x{limb32(const, 0):08x}, {a[0]}")
+        else:
+            L.append(f"v_subb_co_u32_e32 {out[j]}, vcc, {Pv[j]}, {a[j]}, vcc")
+        if j < N - 1:
+            for _ in range(2):
+                L.append(f.pop(0) if f else "s_nop 0")
+    L.extend(f)
+
+
+CD_BASE = (99, 87)       # c / d operands of the two-product core: the fused addition's banks R3 and R2
+
+
 def fused_madd_program(p: int):
     """acc += q (XYZZ + affine, madd-2008-s) as ONE asm statement around ten calls of the product core.
     What it saves against ten separate product calls from C++ (per addition): the 25 zero-half initialisations of nine products
@@ -269,10 +337,10 @@ def fused_madd_program(p: int):
     L = []
     mov = lambda dst, src: [L.append(f"v_mov_b32_e32 {dst[j]}, {src[j]}") for j in range(N)]
 
-    def call():
+    def call(kind="mul"):
         L.append("s_getpc_b64 s[56:57]")
-        L.append("s_add_u32 s56, s56, sonic_mont_mul_fq_core@rel32@lo+4")
-        L.append("s_addc_u32 s57, s57, sonic_mont_mul_fq_core@rel32@hi+12")
+        L.append(f"s_add_u32 s56, s56, sonic_mont_{kind}_fq_core@rel32@lo+4")
+        L.append(f"s_addc_u32 s57, s57, sonic_mont_{kind}_fq_core@rel32@hi+12")
         L.append("s_swappc_b64 s[30:31], s[56:57]")
 
     # prologue: modulus limbs / -p^-1 in SGPRs, zero halves of the T pairs, T_N = 0
@@ -308,9 +376,8 @@ def fused_madd_program(p: int):
     L.append("s_nop 4")
     L.append(f"v_cndmask_b32_e64 {EXC}, 0, 1, {MASK}")
     L.append(f"s_andn2_b64 exec, exec, {MASK}")
-    mov(B, A)
-    # 3. PP = P^2
-    call()
+    # 3. PP = P^2  (the squaring core: 78 partial products; clobbers B, keeps A)
+    call("sqr")
     mov(B, T)
     # 4. PPP = P * PP
     call()
@@ -325,17 +392,17 @@ def fused_madd_program(p: int):
     mov(A, ACCZZZ); mov(B, R2); call()
     mov(ACCZZZ, T)
     # 8. X3 = R^2 - PPP - 2 Q  (into the accumulator);  Q - X3 (into A)
-    mov(A, R1); mov(B, R1); call()
-    emit_addsub(L, N, True, R4, T, R2, D, Pv, CA, 2 * p)            # R^2 - PPP       (R4 is free until step 9)
+    mov(A, R1); call("sqr")
+    emit_addsub(L, N, True, R4, T, R2, D, Pv, CA, 2 * p)            # R^2 - PPP       (R4 is free from here on)
     emit_addsub(L, N, False, B, R3, R3, D, Pv, CA, 2 * p)           # 2 Q             (B is rewritten in step 9)
     emit_addsub(L, N, True, ACCX, R4, B, D, Pv, CA, 2 * p)          # X3
     emit_addsub(L, N, True, A, R3, ACCX, D, Pv, CA, 2 * p)          # Q - X3
-    # 9. R * (Q - X3)
-    mov(B, R1); call()
-    mov(R4, T)
-    # 10. Y1 * PPP;  Y3 = R (Q - X3) - Y1 PPP
-    mov(A, ACCY); mov(B, R2); call()
-    emit_addsub(L, N, True, ACCY, R4, T, D, Pv, CA, 2 * p)
+    # 9. Y3 = R (Q - X3) + (2q - Y1) PPP: both products under ONE reduction (the two-product core reads c = 2q - Y1 from bank R3,
+    #    whose Q is spent, and d = PPP where it already lives, bank R2)
+    assert [f"v{CD_BASE[0] + j}" for j in range(N)] == R3 and [f"v{CD_BASE[1] + j}" for j in range(N)] == R2
+    emit_negate(L, N, R3, ACCY, 2 * p, Pv, [f"v_mov_b32_e32 {B[j]}, {R1[j]}" for j in range(N)])
+    call("mul2")
+    mov(ACCY, T)
     L.append(f"s_mov_b64 exec, {SAVE}")
     return L, nv
 
@@ -351,7 +418,8 @@ def fused_madd_cxx(p: int) -> str:
            [f'"+v"(acc.zz.l[{j}])' for j in range(N)] + [f'"+v"(acc.zzz.l[{j}])' for j in range(N)] + ['"=&v"(exc)']
     ins = [f'"v"(qx.l[{j}])' for j in range(N)] + [f'"v"(qy.l[{j}])' for j in range(N)] + ['"v"(special)']
     clob = [f'"v{k}"' for k in range(nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 66))] + ['"vcc"', '"scc"']
-    head = [f"// sonic_g1_madd_asm: {len(L)} instructions around 10 calls of sonic_mont_mul_fq_core ({n_mov} v_mov), VGPRs v0..v{nv - 1}",
+    head = [f"// sonic_g1_madd_asm: {len(L)} instructions around 6 calls of sonic_mont_mul_fq_core, 2 of sonic_mont_sqr_fq_core and 1 of "
+            f"sonic_mont_mul2_fq_core ({n_mov} v_mov), VGPRs v0..v{nv - 1}",
             "template <class XYZZ, class F> __device__ __forceinline__ bool sonic_g1_madd_asm(XYZZ& acc, const F& qx, const F& qy, uint32_t special) {",
             "  uint32_t exc;", "  asm volatile("]
     body = [f'      "{l}{NLs}"' for l in L[:-1]] + [f'      "{L[-1]}"']
@@ -360,8 +428,9 @@ def fused_madd_cxx(p: int) -> str:
 
 
 
-def cxx(name: str, cls: str, N: int, p: int, lazy: bool = False) -> str:
-    body, nv, res = function_text(name, N, p, lazy)
+def cxx(name: str, cls: str, N: int, p: int, lazy: bool = False, kind: str = "mul") -> str:
+    body, nv, res = function_text(name, N, p, lazy, kind=kind)
+    nin = 1 if kind == "sqr" else 2
     nops = sum(1 for l in body if l.startswith("s_nop"))
     mads = sum(1 for l in body if l.startswith("v_mad_u64"))
     lines = [f"// {name}: {len(body)} instructions ({mads} v_mad_u64_u32, {nops} s_nop), VGPRs v0..v{nv - 1}"]
@@ -385,12 +454,12 @@ def cxx(name: str, cls: str, N: int, p: int, lazy: bool = False) -> str:
     # text.  (Binding them with physical-register constraints, "{v0}" ..., made ROCm 7.2's clang silently drop
     # copies between consecutive calls -- wrong products in some kernels -- and crash its scheduler in others.)
     outs = ", ".join(f'"=v"(r.l[{j}])' for j in range(N))
-    ins = ", ".join([f'"v"(a.l[{j}])' for j in range(N)] + [f'"v"(b.l[{j}])' for j in range(N)])
+    ins = ", ".join([f'"v"(a.l[{j}])' for j in range(N)] + ([f'"v"(b.l[{j}])' for j in range(N)] if nin == 2 else []))
     clob = [f'"v{k}"' for k in range(0, nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 58))] + ['"vcc"', '"scc"']
-    lines.append(f"__device__ __forceinline__ {cls} {name}_call(const {cls}& a, const {cls}& b) {{")
+    lines.append(f"__device__ __forceinline__ {cls} {name}_call(const {cls}& a" + (f", const {cls}& b" if nin == 2 else "") + ") {")
     lines.append(f"  {cls} r;")
     lines.append("  asm volatile(")
-    for j in range(2 * N):
+    for j in range(nin * N):
         lines.append(f'      "v_mov_b32_e32 v{j}, %{N + j}\\n\\t"')
     lines.append('      "s_getpc_b64 s[56:57]\\n\\t"')
     lines.append(f'      "s_add_u32 s56, s56, {name}@rel32@lo+4\\n\\t"')
@@ -468,10 +537,18 @@ def render() -> str:
            "namespace sonic {",
            cxx("sonic_mont_mul_fq", "Fp<FqParams>", 12, Q, lazy=True),
            "",
+           cxx("sonic_mont_sqr_fq", "Fp<FqParams>", 12, Q, lazy=True, kind="sqr"),
+           "",
            cxx("sonic_mont_mul_fr", "Fp<FrParams>", 8, R),
            "",
            "\n".join(routine_section("sonic_mont_mul_fq_core", function_text("sonic_mont_mul_fq_core", 12, Q, lazy=True, core=True)[0],
                                      "// sonic_mont_mul_fq_core: the lazy Fq product without its prologue (modulus SGPRs, zero halves): callers keep those in place")),
+           "",
+           "\n".join(routine_section("sonic_mont_sqr_fq_core", function_text("sonic_mont_sqr_fq_core", 12, Q, lazy=True, core=True, kind="sqr")[0],
+                                     "// sonic_mont_sqr_fq_core: a * a with 78 partial products (a in v0..v11 survives, v12..v23 are scratch), same contract as the core above")),
+           "",
+           "\n".join(routine_section("sonic_mont_mul2_fq_core", function_text("sonic_mont_mul2_fq_core", 12, Q, lazy=True, core=True, kind="mul2", cd_base=CD_BASE)[0],
+                                     f"// sonic_mont_mul2_fq_core: a * b + c * d under one reduction (c in v{CD_BASE[0]}.., d in v{CD_BASE[1]}..), same contract as the core above")),
            "",
            fused_madd_cxx(Q),
            "",

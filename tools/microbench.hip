@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256) void k_fqmul(Fq* out, int iters) {
   for (int i = 0; i < iters; i++) { a = fp_mul(a, b); b = fp_mul(b, a); }
   out[blockIdx.x * blockDim.x + threadIdx.x] = fp_add(a, b);
 }
+__global__ __launch_bounds__(256) void k_fqsqr(Fq* out, int iters) {
+  Fq a = Fq::one(), b = Fq::r2();
+  a.l[0] += threadIdx.x; b.l[1] ^= blockIdx.x;
+  for (int i = 0; i < iters; i++) { a = fp_sqr(a); b = fp_sqr(b); }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fp_add(a, b);
+}
 __global__ __launch_bounds__(256) void k_madd(G1XYZZ* out, const G1Affine* pts, int iters) {
   G1XYZZ acc = G1XYZZ::inf();
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,6 +112,8 @@ __global__ void k_check_mul(const F* in, int n, int* bad) {
   auto same = [&](const F& x, const F& want) { if (!below_2p(x) || !raw_eq(fp_canonical(x), want)) atomicAdd(bad, 1); };
   same(fp_mul(a, b), fp_mul_generic(a, b));
   same(fp_mul(a, a), fp_mul_generic(a, a));
+  same(fp_sqr(a), fp_mul_generic(a, a));          // Fq: the 78-product squaring routine
+  same(fp_sqr(b), fp_mul_generic(b, b));
   same(fp_add(a, b), fp_add_generic(a, b));
   same(fp_sub(a, b), fp_sub_generic(a, b));
   same(fp_sub(b, a), fp_sub_generic(b, a));
@@ -117,6 +125,8 @@ __global__ void k_check_mul(const F* in, int n, int* bad) {
     F a2 = plus_p(a), b2 = plus_p(b);
     same(fp_mul(a2, b2), fp_mul_generic(a, b));
     same(fp_mul(a2, b), fp_mul_generic(a, b));
+    same(fp_sqr(a2), fp_mul_generic(a, a));
+    same(fp_sqr(b2), fp_mul_generic(b, b));
     same(fp_add(a2, b2), fp_add_generic(a, b));
     same(fp_sub(a2, b2), fp_sub_generic(a, b));
     same(fp_sub(a, b2), fp_sub_generic(a, b));
@@ -216,6 +226,8 @@ int main() {
     printf("add+xor+shift: %.3f ms -> %.3e triple/s (%.2f lane-triples/clk/CU)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
   { int it = 256; float ms = time_ms([&] { hipLaunchKernelGGL(k_fqmul, blocks, threads, 0, 0, (Fq*)buf, it); }, 3);
     printf("fq_mul:        %.3f ms -> %.3e mul/s\n", ms, lanes * it * 2 / (ms * 1e-3)); }
+  { int it = 256; float ms = time_ms([&] { hipLaunchKernelGGL(k_fqsqr, blocks, threads, 0, 0, (Fq*)buf, it); }, 3);
+    printf("fq_sqr:        %.3f ms -> %.3e sqr/s\n", ms, lanes * it * 2 / (ms * 1e-3)); }
   { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
     printf("g1_add_mixed:  %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
   { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd_walk, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
