@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsonic_hip.so")
+LIB_PATH = os.environ.get("SONIC_HIP_LIB") or os.path.join(_HERE, "csrc", "libsonic_hip.so")   # SONIC_HIP_LIB: another build of the same library (tuning experiments)
 
 ERR_NAMES = {
     1: "D_TOO_SMALL", 2: "SRS_INDEX_OUT_OF_RANGE", 3: "BAD_ENCODING", 4: "INEXACT_DIVISION",

@@ -458,10 +458,17 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
   G1XYZZ acc = G1XYZZ::inf();
   if (cnt) {
     const uint32_t last = end - 1;
-    uint32_t e_cur = entries[beg];
-    uint32_t e_nxt = entries[beg + 1 <= last ? beg + 1 : last];
+    // The first entry only initialises the accumulator (the fused addition would run all its products with every lane
+    // switched off: one wasted addition per bucket, 4 % of the kernel at 26 entries per bucket, 7 % at 15); the walk starts at
+    // the second entry with the pipeline already primed.
+    const uint32_t e_first = entries[beg];
+    uint32_t e_cur = entries[beg + 1 <= last ? beg + 1 : last];
+    uint32_t e_nxt = entries[beg + 2 <= last ? beg + 2 : last];
+    G1Affine p_first = pts[entry_point(e_first, stride)];
     G1Affine p_cur = pts[entry_point(e_cur, stride)];
-    for (uint32_t e = beg; e < end; e++) {
+    if (e_first >> 31) p_first.y = fp_neg(p_first.y);
+    acc = G1XYZZ::from_affine(p_first);
+    for (uint32_t e = beg + 1; e < end; e++) {
       const uint32_t e_nn = entries[e + 2 <= last ? e + 2 : last];
       const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
       if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
@@ -488,7 +495,12 @@ __global__ __launch_bounds__(256, 2) void k_heavy_accum(const MsmBatchDev batch,
     if (beg + threadIdx.x < end) {
       const uint32_t last = beg + threadIdx.x + ((end - 1 - beg - threadIdx.x) / 256) * 256;   // this lane's last entry
       uint32_t e = beg + threadIdx.x;
-      uint32_t e_cur = entries[e];
+      const uint32_t e_first = entries[e];
+      G1Affine p_first = pts[entry_point(e_first, stride)];
+      if (e_first >> 31) p_first.y = fp_neg(p_first.y);
+      acc = G1XYZZ::from_affine(p_first);                       // as in k_bucket_accum: the first entry is a copy, not an addition
+      e += 256;
+      uint32_t e_cur = entries[e <= last ? e : last];
       uint32_t e_nxt = entries[e + 256 <= last ? e + 256 : last];
       G1Affine p_cur = pts[entry_point(e_cur, stride)];
       for (; e < end; e += 256) {

@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I sonic_amd/csrc tools/microbench.hip -o tools/microbench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <string.h>
 #include "g1.hpp"
 using namespace sonic;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -203,7 +204,8 @@ template <class F> float time_ms(F f, int reps) {
   float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool check_only = argc > 1 && !strcmp(argv[1], "--check");      // self-checks only (tests/test_gpu_asm.py)
   int dev = 0; CK(hipSetDevice(dev));
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, dev));
   printf("device: %s CUs=%d clock=%d kHz\n", pr.name, pr.multiProcessorCount, pr.clockRate);
@@ -214,7 +216,9 @@ int main() {
   hipLaunchKernelGGL(k_mkpts, 16, 256, 0, 0, pts); CK(hipDeviceSynchronize());
   { int* bad; int hb[3] = {0, 0, 0}; hipMalloc(&bad, 12); hipMemset(bad, 0, 12);
     hipLaunchKernelGGL(k_check_dbl, 16, 256, 0, 0, (const G1Affine*)pts, 4096, bad, 11); hipMemcpy(hb, bad, 12, hipMemcpyDeviceToHost);
-    printf("dbl_affine^11 vs mul_small(2^11): %d mismatches; add_mixed(P,P) vs dbl: %d mismatches; fused walk addition vs general (incl. exceptional lanes): %d mismatches\n", hb[0], hb[1], hb[2]); }
+    printf("dbl_affine^11 vs mul_small(2^11): %d mismatches; add_mixed(P,P) vs dbl: %d mismatches; fused walk addition vs general (incl. exceptional lanes): %d mismatches\n", hb[0], hb[1], hb[2]);
+    if (hb[0] | hb[1] | hb[2]) return 3; }
+  if (check_only) { printf("self-checks ok\n"); return 0; }
   const double lanes = (double)blocks * threads;
   { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_mad, blocks, threads, 0, 0, (uint64_t*)buf, 12345u, 67891u, it); }, 10);
     printf("v_mad_u64_u32: %.3f ms -> %.3e mad/s  (%.2f lane-ops/clk/CU at 2.4GHz)\n", ms, lanes * it * 8 / (ms * 1e-3), lanes * it * 8 / (ms * 1e-3) / 2.4e9 / pr.multiProcessorCount); }
