@@ -141,6 +141,13 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
  * S_j = commitPoly(s(X, y_j)) (Signature.hs:42) costs an n-term MSM instead of a 3n-term one.  Same proof bytes. */
 int sonic_prover_prepare(sonic_prover_t* p);
 int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_proof);
+/* the same in two halves: submit queues the whole proof on the handle's streams and returns without waiting for the GPU;
+ * collect waits for it, finishes it on the host and writes the bytes (prove = submit + collect).  One proof in flight per
+ * handle.  A host thread that alternates between two handles -- submit(A, t0), submit(B, t1), collect(A), submit(A, t2),
+ * collect(B), ... -- streams proofs with the next proof's start-up under the previous proof's tail (the reference's
+ * `mapM prove` over a list of statements; BASELINE config "batch of independent proofs, throughput mode"). */
+int sonic_prover_submit(sonic_prover_t* p, const uint8_t* transcript);
+int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof);
 void sonic_prover_free(sonic_prover_t* p);
 
 /* ---- the verifier side of the API (host CPU; outside the accelerated path) ---- */

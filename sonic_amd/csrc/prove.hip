@@ -175,6 +175,8 @@ struct sonic_prover {
   hipGraphExec_t graph = nullptr;
   bool graph_tried = false;
   long proofs_done = 0;
+  bool in_flight = false;                    // between sonic_prover_submit and sonic_prover_collect
+  std::chrono::steady_clock::time_point t_begin, t_enq;
   bool prepared = false;
   DevBuf cq;
   std::vector<DevBuf> diag, yq;
@@ -316,6 +318,7 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
   API_BEGIN
   if (!p || !aL || !aR || !aO) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
+  if (p->in_flight) { set_error("sonic_prover_set_assignment: a submitted proof is still reading the current assignment (collect it first)"); return SONIC_ERR_INVALID_ARG; }
   hipStream_t st = p->st;
   HIP_OK(hipMemsetAsync(p->flags.p, 0, 4, st));
   upload_fr_mont(st, p->aL, aL, p->n, p->flags.as<int>());
@@ -327,12 +330,16 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
   API_END
 }
 
-int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_proof) {
+}  // extern "C"
+
+// prove = prove_enqueue (queues the whole proof on the handle's streams, no host synchronisation) + prove_finish (waits, runs
+// the host tails, lays out the bytes).  sonic_prover_prove runs them back to back; sonic_prover_submit / sonic_prover_collect
+// expose the halves, so that ONE host thread can keep two handles busy: while it waits for and finishes proof i on one handle,
+// proof i + 1 is already running on the other (its polynomial building and sorts fill the first proof's reduction tail).
+// Both run under p->mu.
+static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   API_BEGIN
-  if (!p || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
-  if (!p->have_assignment) { set_error("sonic_prover_prove: no assignment set"); return SONIC_ERR_INVALID_ARG; }
-  std::lock_guard<std::mutex> g(p->mu);
-  const auto t_begin = std::chrono::steady_clock::now();
+  p->t_begin = std::chrono::steady_clock::now();
   const long n = p->n, Q = p->Q;
   const sonic_srs* srs = p->srs;
   hipStream_t st = p->st;
@@ -474,9 +481,18 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
     if (ge != hipSuccess) { p->graph = nullptr; set_error("prove: hipGraphInstantiate failed: %s", hipGetErrorString(ge)); return SONIC_ERR_HIP; }
   }
   if (replay || capturing) HIP_OK(hipGraphLaunch(p->graph, st));
+  p->t_enq = std::chrono::steady_clock::now();
+  API_END
+}
 
+static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
+  API_BEGIN
+  const long Q = p->Q;
+  const int K = (int)(7 + 4 * Q);
+  hipStream_t st = p->st;
+  const uint8_t* transcript = p->h_tr;
+  const auto t_begin = p->t_begin, t_enq = p->t_enq;
   const bool timing = getenv("SONIC_DEBUG_TIMING") != nullptr;
-  const auto t_enq = std::chrono::steady_clock::now();
   HIP_OK(hipStreamSynchronize(st));
   p->proofs_done++;
   const MsmSlot* hs = p->h_slots;
@@ -517,6 +533,42 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   API_END
 }
 
+extern "C" {
+
+static int prove_args_ok(sonic_prover_t* p, const char* who) {
+  if (!p->have_assignment) { set_error("%s: no assignment set", who); return SONIC_ERR_INVALID_ARG; }
+  if (p->in_flight) { set_error("%s: a submitted proof has not been collected yet", who); return SONIC_ERR_INVALID_ARG; }
+  return SONIC_OK;
+}
+
+int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_proof) {
+  if (!p || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  int rc = prove_args_ok(p, "sonic_prover_prove");
+  if (!rc) rc = prove_enqueue(p, transcript);
+  if (!rc) rc = prove_finish(p, out_proof);
+  else if (p->st) (void)hipStreamSynchronize(p->st);      // an enqueue that failed half way: let what was queued drain
+  return rc;
+}
+
+int sonic_prover_submit(sonic_prover_t* p, const uint8_t* transcript) {
+  if (!p || !transcript) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  int rc = prove_args_ok(p, "sonic_prover_submit");
+  if (!rc) rc = prove_enqueue(p, transcript);
+  if (!rc) p->in_flight = true;
+  else if (p->st) (void)hipStreamSynchronize(p->st);
+  return rc;
+}
+
+int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof) {
+  if (!p || !out_proof) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  if (!p->in_flight) { set_error("sonic_prover_collect: nothing was submitted"); return SONIC_ERR_INVALID_ARG; }
+  p->in_flight = false;
+  return prove_finish(p, out_proof);
+}
+
 // Circuit-only precomputation for handles that prove more than once: C_q = Commit(d, P_q), P_q the q-th constraint's
 // weight polynomial.  Afterwards S_j = Commit(d, s(X, y_j)) (Signature.hs:42) is assembled as
 // sum_q y_j^{n+q} C_q + Commit(d, diagonal part): the same group element from an n-term MSM instead of a 3n-term one.
@@ -525,6 +577,7 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   if (!p) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   if (p->prepared) return SONIC_OK;
+  if (p->in_flight) { set_error("sonic_prover_prepare: a submitted proof has not been collected yet"); return SONIC_ERR_INVALID_ARG; }
   if (p->graph) { (void)hipGraphExecDestroy(p->graph); p->graph = nullptr; }     // a captured proof would not know the prepared path
   p->graph_tried = false;
   const long n = p->n, Q = p->Q, d = srs_d(p->srs);

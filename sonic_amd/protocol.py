@@ -154,6 +154,18 @@ class Prover:
         _lib.check(_lib.lib().sonic_prover_prove(self._h, tr.ctypes.data, out))
         return out.raw
 
+    def submit(self, transcript) -> None:
+        """queue one proof on the GPU and return without waiting (sonic_prover_submit); one proof in flight per handle"""
+        tr = fr_array(transcript)
+        assert tr.shape[0] == transcript_len(self.Q)
+        _lib.check(_lib.lib().sonic_prover_submit(self._h, tr.ctypes.data))
+
+    def collect(self) -> bytes:
+        """wait for the submitted proof, finish it on the host, return its bytes (sonic_prover_collect)"""
+        out = C.create_string_buffer(_lib.lib().sonic_proof_size(self.Q))
+        _lib.check(_lib.lib().sonic_prover_collect(self._h, out))
+        return out.raw
+
     def close(self):
         if self._h:
             _lib.lib().sonic_prover_free(self._h)
@@ -164,6 +176,38 @@ class Prover:
             self.close()
         except Exception:
             pass
+
+
+class ProverPipeline:
+    """`mapM prove` over a stream of statements of one circuit, from one host thread: `depth` prover handles used in turn, so that
+    while proof i is being waited for and finished, proof i + 1 is already running (its polynomial building and sorts fill the
+    reduction tail of proof i).  Same bytes as proving one after the other."""
+
+    def __init__(self, srs: SRS, circuit: ArithCircuit, depth: int = 2, prepare: bool = True):
+        self.provers = [Prover(srs, circuit, prepare) for _ in range(max(1, depth))]
+
+    def set_assignment(self, assignment: Assignment):
+        for p in self.provers:
+            p.set_assignment(assignment)
+
+    def prove_all(self, transcripts) -> List[bytes]:
+        k = len(self.provers)
+        out: List[bytes] = []
+        pending = 0
+        for i, tr in enumerate(transcripts):
+            if pending == k:
+                out.append(self.provers[i % k].collect())
+                pending -= 1
+            self.provers[i % k].submit(tr)
+            pending += 1
+        n = len(transcripts)
+        for i in range(n - pending, n):
+            out.append(self.provers[i % k].collect())
+        return out
+
+    def close(self):
+        for p in self.provers:
+            p.close()
 
 
 def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: Optional[list] = None, rng=None):

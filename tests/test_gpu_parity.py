@@ -425,6 +425,34 @@ def test_prover_handle_reuse(sonic, orc, ref, srs_pair):
         assert p.prove_bytes(tr) == want
 
 
+def test_submit_collect_pipeline(sonic, orc, ref, srs_pair):
+    """prove = submit + collect; two handles driven in turn by one host thread give the same bytes as proving one after the
+    other (and as the oracle); the halves refuse to be misused"""
+    d, x, alpha, g, o = srs_pair
+    pyr = random.Random(77)
+    n, Q = 40, 3
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    circuit = sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3])
+    trs = [[pyr.randrange(1, R) for _ in range(8 + 2 * Q)] for _ in range(5)]
+    want = [orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], fr_bytes(t)) for t in trs]
+    pipe = sonic.ProverPipeline(g, circuit, depth=2)
+    pipe.set_assignment(sonic.Assignment(*asg))
+    assert pipe.prove_all(trs) == want
+    assert pipe.prove_all(trs[:1]) == want[:1] and pipe.prove_all([]) == []
+    p = pipe.provers[0]
+    with pytest.raises(sonic.SonicError) as e:
+        p.collect()                                  # nothing submitted
+    assert e.value.code == 7
+    p.submit(trs[2])
+    for misuse in (lambda: p.submit(trs[3]), lambda: p.prove_bytes(trs[3]), lambda: p.set_assignment(sonic.Assignment(*asg))):
+        with pytest.raises(sonic.SonicError) as e:
+            misuse()                                 # one proof in flight per handle
+        assert e.value.code == 7
+    assert p.collect() == want[2]
+    assert p.prove_bytes(trs[4]) == want[4]          # and the handle is as good as new
+    pipe.close()
+
+
 def test_prepared_handle_same_bytes(sonic, orc, ref, srs_pair):
     """sonic_prover_prepare (S_j assembled from the per-constraint commitments) must not change a single byte:
     rndCircuit weights, dense random weights, and a constraint row that is all zero (its commitment is O)"""
