@@ -107,6 +107,26 @@ HD G1XYZZ g1_add_mixed_walk(G1XYZZ acc, const G1Affine& q) {
 #endif
 }
 
+// first + q for two AFFINE points -> XYZZ: the second entry of a bucket walk.  With ZZ = ZZZ = 1 four of the ten products of the
+// mixed addition are trivial; on the device the rest is one generated asm statement (sonic_g1_aadd_asm: 2 squarings, 2 products,
+// 1 two-product call), exceptional lanes (an infinity operand, equal x) redone by the general functions.  `first_only`
+// lanes just get from_affine(first) (a wave whose lanes differ in bucket size calls this for all of them).
+HD G1XYZZ g1_add_affine_walk(const G1Affine& first, const G1Affine& q, bool first_only) {
+#if SONIC_FQ_LAZY && !defined(SONIC_NO_FUSED_MADD)
+  G1XYZZ acc;
+  acc.x = first.x; acc.y = first.y; acc.zz = Fq::one(); acc.zzz = Fq::one();
+  const uint32_t special = (first_only || first.is_inf() || q.is_inf()) ? 1u : 0u;
+  if (sonic_g1_aadd_asm(acc, q.x, q.y, special)) {
+    acc = G1XYZZ::from_affine(first);
+    if (!first_only) acc = g1_add_mixed(acc, q);
+  }
+  return acc;
+#else
+  G1XYZZ acc = G1XYZZ::from_affine(first);
+  return first_only ? acc : g1_add_mixed(acc, q);
+#endif
+}
+
 // p + q, both XYZZ (add-2008-s): 12M + 2S
 HD G1XYZZ g1_add(const G1XYZZ& p, const G1XYZZ& q) {
   if (q.is_inf()) return p;

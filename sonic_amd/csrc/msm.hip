@@ -459,16 +459,20 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
   if (cnt) {
     const uint32_t last = end - 1;
     // The first entry only initialises the accumulator (the fused addition would run all its products with every lane
-    // switched off: one wasted addition per bucket, 4 % of the kernel at 26 entries per bucket, 7 % at 15); the walk starts at
-    // the second entry with the pipeline already primed.
+    // switched off: one wasted addition per bucket, 4 % of the kernel at 26 entries per bucket, 7 % at 15) ...
+    // ... and the second entry meets an affine accumulator (ZZ = ZZZ = 1): four of the ten products are trivial
+    // (g1_add_affine_walk).
     const uint32_t e_first = entries[beg];
-    uint32_t e_cur = entries[beg + 1 <= last ? beg + 1 : last];
-    uint32_t e_nxt = entries[beg + 2 <= last ? beg + 2 : last];
+    const uint32_t e_second = entries[beg + 1 <= last ? beg + 1 : last];
+    uint32_t e_cur = entries[beg + 2 <= last ? beg + 2 : last];
+    uint32_t e_nxt = entries[beg + 3 <= last ? beg + 3 : last];
     G1Affine p_first = pts[entry_point(e_first, stride)];
+    G1Affine p_second = pts[entry_point(e_second, stride)];
     G1Affine p_cur = pts[entry_point(e_cur, stride)];
     if (e_first >> 31) p_first.y = fp_neg(p_first.y);
-    acc = G1XYZZ::from_affine(p_first);
-    for (uint32_t e = beg + 1; e < end; e++) {
+    if (e_second >> 31) p_second.y = fp_neg(p_second.y);
+    acc = g1_add_affine_walk(p_first, p_second, cnt < 2);
+    for (uint32_t e = beg + 2; e < end; e++) {
       const uint32_t e_nn = entries[e + 2 <= last ? e + 2 : last];
       const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
       if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);

@@ -270,9 +270,9 @@ def xyzz_madd(p, X1, Y1, ZZ1, ZZZ1, x2, y2):
     return X3, Y3, mul(ZZ1, PP), mul(ZZZ1, PPP)
 
 
-def run_fused(acc, q, special):
+def run_fused(acc, q, special, affine_acc=False):
     N, p = 12, G.Q
-    L, nv = G.fused_madd_program(p)
+    L, nv = G.fused_madd_program(p, affine_acc)
     cores = {"sonic_mont_mul_fq_core": G.function_text("core", N, p, lazy=True, core=True)[0],
              "sonic_mont_sqr_fq_core": G.function_text("core", N, p, lazy=True, core=True, kind="sqr")[0],
              "sonic_mont_mul2_fq_core": G.function_text("core", N, p, lazy=True, core=True, kind="mul2", cd_base=G.CD_BASE)[0]}
@@ -287,7 +287,7 @@ def run_fused(acc, q, special):
     lane.run(L)
     assert lane.exec is True, "EXEC not restored"
     lane.check_carry_hazard()
-    assert sorted(lane.calls) == ["sonic_mont_mul2_fq_core"] + ["sonic_mont_mul_fq_core"] * 6 + ["sonic_mont_sqr_fq_core"] * 2
+    assert sorted(lane.calls) == ["sonic_mont_mul2_fq_core"] + ["sonic_mont_mul_fq_core"] * (2 if affine_acc else 6) + ["sonic_mont_sqr_fq_core"] * 2
     out = [unlimbs([lane.v[f"%{k * N + j}"] for j in range(N)]) for k in range(4)]
     return out, lane.v[f"%{4 * N}"]
 
@@ -317,6 +317,31 @@ def test_fused_mixed_addition_model():
     acc = [rng.randrange(p) for _ in range(4)]
     q = [rng.randrange(p) for _ in range(2)]
     got, exc = run_fused(acc, q, 1)
+    assert exc == 1 and got == acc
+
+
+def test_fused_affine_plus_affine_model():
+    """the variant for the second entry of a bucket walk: the accumulator comes in affine (ZZ = ZZZ = 1 implied, whatever acc.zz /
+    acc.zzz held is ignored), 2 + 2 + 1 core calls; same results as the general formulas with ZZ1 = ZZZ1 = 1 (Montgomery: R mod q)"""
+    p = G.Q
+    rng = random.Random(4242)
+    one = (1 << 384) % p
+    rep = lambda v: v + p if (rng.random() < 0.5 and v + p < 2 * p) else v
+    for it in range(16):
+        x1, y1, x2, y2 = (rng.randrange(p) for _ in range(4))
+        if it == 0:
+            y1 = 0
+        want = xyzz_madd(p, x1, y1, one, one, x2, y2)
+        got, exc = run_fused([rep(x1), rep(y1), rng.randrange(1 << 384), rng.randrange(1 << 384)], [rep(x2), rep(y2)], 0, affine_acc=True)
+        assert exc == 0 and all(g < 2 * p for g in got)
+        assert [g % p for g in got] == list(want)
+    for bump in (0, p):                                   # equal x (doubling / cancellation), with x2 - x1 represented as 0 or as q
+        x1, y1, y2 = (rng.randrange(p) for _ in range(3))
+        acc = [x1, y1, 7, 9]
+        got, exc = run_fused(acc, [x1 + bump, y2], 0, affine_acc=True)
+        assert exc == 1 and got == acc
+    acc = [rng.randrange(p), rng.randrange(p), 1, 2]
+    got, exc = run_fused(acc, [rng.randrange(p), rng.randrange(p)], 1, affine_acc=True)
     assert exc == 1 and got == acc
 
 

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collects the measurements DESIGN.md section 5 quotes, on one MI355X box:  bash tools/collect_profiles.sh r02
+# Writes gpurun_out/<tag>/...; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh does not touch profiles/).
+# PMC passes are separate runs with one counter group each and no tracing, as MI355X_MICROARCH.md's HBM section prescribes.
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+./tools/microbench > $OUT/microbench.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm_only -o t -- python3 bench.py --msm-only --no-cpu --steps 5 --warmup 1 > $OUT/msm_only.json 2> $OUT/msm_only.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python3 bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o t -- python3 bench.py --msm-only --no-cpu --steps 3 --warmup 1 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_SQ -o t -- python3 bench.py --msm-only --no-cpu --steps 3 --warmup 1 > $OUT/pmc_SQ.json 2> $OUT/pmc_SQ.err
+{
+  echo "# python bench.py --no-cpu --log2n <k> (10 streamed proofs after 2 warm-up, Q = 2, d = 8n): ms per proof streamed / strictly sequential"
+  for lg in 10 13 14 16 17 18 19 20; do
+    python3 bench.py --no-cpu --log2n $lg --msm-log2 12 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=2^$lg  d=2^$((lg+3))  streamed %.2f  sequential %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof']))"
+  done
+  echo "# sensitivity to Q at n = 2^18 (7 + 4Q MSMs per proof)"
+  for q in 1 2 4 8; do
+    python3 bench.py --no-cpu --Q $q --msm-log2 12 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('Q=$q  streamed %.2f  sequential %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof']))"
+  done
+} > $OUT/prove_sizes.txt
+{
+  echo "# python bench.py --no-cpu --msm-only --msm-log2 <k> (SRS d = 2^21: window tables c = 20, 13 windows, 2^19 shared buckets): ms per MSM, scalar-muls/s"
+  for lg in 16 18 20 22; do
+    python3 bench.py --no-cpu --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value']))"
+  done
+} > $OUT/msm_sizes.txt
+find $OUT -name "*.csv" | head -40

@@ -302,14 +302,17 @@ def emit_negate(L, N, out, a, const, Pv, fillers):
 CD_BASE = (99, 87)       # c / d operands of the two-product core: the fused addition's banks R3 and R2
 
 
-def fused_madd_program(p: int):
+def fused_madd_program(p: int, affine_acc: bool = False):
     """acc += q (XYZZ + affine, madd-2008-s) as ONE asm statement around ten calls of the product core.
     What it saves against ten separate product calls from C++ (per addition): the 25 zero-half initialisations of nine products
     (the zero halves and the modulus SGPRs persist across the calls), ~200 of the ~450 marshalling / merge moves (operands are
     routed between the core's fixed registers and four temporary banks by plan: the sub / add blocks write straight into the
     core's A operand or into the accumulator's registers), and every compiler-made copy.
     Lanes in an exceptional position (an infinity operand, or U2 = X1: doubling / cancellation) are switched off with EXEC before
-    anything is written back and reported in `exc`: the caller redoes them with the general C++ addition."""
+    anything is written back and reported in `exc`: the caller redoes them with the general C++ addition.
+    affine_acc: the accumulator comes in as an AFFINE point (x, y in acc.x / acc.y; ZZ = ZZZ = 1 implied, acc.zz / acc.zzz are
+    outputs only) -- the second entry of a bucket walk.  U2 = x2, S2 = y2, ZZ3 = PP and ZZZ3 = PPP need no product:
+    2 squarings + 2 products + 1 two-product call instead of 2 + 6 + 1."""
     N = 12
     A = [f"v{j}" for j in range(N)]
     B = [f"v{N + j}" for j in range(N)]
@@ -351,12 +354,17 @@ def fused_madd_program(p: int):
         L.append(f"v_mov_b32_e32 {r}, 0")
     L.append(f"v_mov_b32_e32 {TPloN}, 0")
     L.append(f"s_mov_b64 {SAVE}, exec")
-    # 1. S2 = q.y * ZZZ1;  R = S2 - Y1
-    mov(A, QY); mov(B, ACCZZZ); call()
-    emit_addsub(L, N, True, R1, T, ACCY, D, Pv, CA, 2 * p)
-    # 2. U2 = q.x * ZZ1;  P = U2 - X1 (into A), exceptional lanes off
-    mov(A, QX); mov(B, ACCZZ); call()
-    emit_addsub(L, N, True, A, T, ACCX, D, Pv, CA, 2 * p)
+    if affine_acc:
+        # 1. R = q.y - Y1;  2. P = q.x - X1 (into A), exceptional lanes off
+        emit_addsub(L, N, True, R1, QY, ACCY, D, Pv, CA, 2 * p)
+        emit_addsub(L, N, True, A, QX, ACCX, D, Pv, CA, 2 * p)
+    else:
+        # 1. S2 = q.y * ZZZ1;  R = S2 - Y1
+        mov(A, QY); mov(B, ACCZZZ); call()
+        emit_addsub(L, N, True, R1, T, ACCY, D, Pv, CA, 2 * p)
+        # 2. U2 = q.x * ZZ1;  P = U2 - X1 (into A), exceptional lanes off
+        mov(A, QX); mov(B, ACCZZ); call()
+        emit_addsub(L, N, True, A, T, ACCX, D, Pv, CA, 2 * p)
     #    P == 0 (as 0 or as p)?  t = OR limbs, u = OR (limb ^ p_j)
     L.append(f"v_or3_b32 {D[0]}, {A[0]}, {A[1]}, {A[2]}")
     for k in range(3, N, 2):
@@ -379,18 +387,23 @@ def fused_madd_program(p: int):
     # 3. PP = P^2  (the squaring core: 78 partial products; clobbers B, keeps A)
     call("sqr")
     mov(B, T)
+    if affine_acc:
+        mov(ACCZZ, T)                       # ZZ3 = PP
     # 4. PPP = P * PP
     call()
     mov(R2, T)
+    if affine_acc:
+        mov(ACCZZZ, T)                      # ZZZ3 = PPP
     # 5. Q = X1 * PP
     mov(A, ACCX); call()
     mov(R3, T)
-    # 6. ZZ3 = ZZ1 * PP
-    mov(A, ACCZZ); call()
-    mov(ACCZZ, T)
-    # 7. ZZZ3 = ZZZ1 * PPP
-    mov(A, ACCZZZ); mov(B, R2); call()
-    mov(ACCZZZ, T)
+    if not affine_acc:
+        # 6. ZZ3 = ZZ1 * PP
+        mov(A, ACCZZ); call()
+        mov(ACCZZ, T)
+        # 7. ZZZ3 = ZZZ1 * PPP
+        mov(A, ACCZZZ); mov(B, R2); call()
+        mov(ACCZZZ, T)
     # 8. X3 = R^2 - PPP - 2 Q  (into the accumulator);  Q - X3 (into A)
     mov(A, R1); call("sqr")
     emit_addsub(L, N, True, R4, T, R2, D, Pv, CA, 2 * p)            # R^2 - PPP       (R4 is free from here on)
@@ -407,20 +420,22 @@ def fused_madd_program(p: int):
     return L, nv
 
 
-def fused_madd_cxx(p: int) -> str:
+def fused_madd_cxx(p: int, affine_acc: bool = False) -> str:
     """The C++ wrapper around fused_madd_program: operands %0..%47 = accumulator (in/out), %48 = exceptional flag (out),
     %49..%72 = the affine point, %73 = "an operand is at infinity" (in)."""
     N = 12
-    L, nv = fused_madd_program(p)
+    L, nv = fused_madd_program(p, affine_acc)
+    fname = "sonic_g1_aadd_asm" if affine_acc else "sonic_g1_madd_asm"
+    ncalls = (2, 2, 1) if affine_acc else (6, 2, 1)
     n_mov = sum(1 for l in L if l.startswith("v_mov_b32"))
     NLs = "\\n\\t"
     outs = [f'"+v"(acc.x.l[{j}])' for j in range(N)] + [f'"+v"(acc.y.l[{j}])' for j in range(N)] + \
            [f'"+v"(acc.zz.l[{j}])' for j in range(N)] + [f'"+v"(acc.zzz.l[{j}])' for j in range(N)] + ['"=&v"(exc)']
     ins = [f'"v"(qx.l[{j}])' for j in range(N)] + [f'"v"(qy.l[{j}])' for j in range(N)] + ['"v"(special)']
     clob = [f'"v{k}"' for k in range(nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 66))] + ['"vcc"', '"scc"']
-    head = [f"// sonic_g1_madd_asm: {len(L)} instructions around 6 calls of sonic_mont_mul_fq_core, 2 of sonic_mont_sqr_fq_core and 1 of "
-            f"sonic_mont_mul2_fq_core ({n_mov} v_mov), VGPRs v0..v{nv - 1}",
-            "template <class XYZZ, class F> __device__ __forceinline__ bool sonic_g1_madd_asm(XYZZ& acc, const F& qx, const F& qy, uint32_t special) {",
+    head = [f"// {fname}: {len(L)} instructions around {ncalls[0]} calls of sonic_mont_mul_fq_core, {ncalls[1]} of sonic_mont_sqr_fq_core and {ncalls[2]} of "
+            f"sonic_mont_mul2_fq_core ({n_mov} v_mov), VGPRs v0..v{nv - 1}" + ("; the accumulator comes in affine (acc.x, acc.y), ZZ = ZZZ = 1 implied" if affine_acc else ""),
+            f"template <class XYZZ, class F> __device__ __forceinline__ bool {fname}(XYZZ& acc, const F& qx, const F& qy, uint32_t special) {{",
             "  uint32_t exc;", "  asm volatile("]
     body = [f'      "{l}{NLs}"' for l in L[:-1]] + [f'      "{L[-1]}"']
     tail = [f"      : {', '.join(outs)}", f"      : {', '.join(ins)}", f"      : {', '.join(clob)});", "  return exc != 0;", "}"]
@@ -551,6 +566,8 @@ def render() -> str:
                                      f"// sonic_mont_mul2_fq_core: a * b + c * d under one reduction (c in v{CD_BASE[0]}.., d in v{CD_BASE[1]}..), same contract as the core above")),
            "",
            fused_madd_cxx(Q),
+           "",
+           fused_madd_cxx(Q, affine_acc=True),
            "",
            addsub_cxx("sonic_fq_sub_asm", "Fp<P>", 12, True),
            addsub_cxx("sonic_fq_add_asm", "Fp<P>", 12, False),

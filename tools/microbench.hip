@@ -195,6 +195,18 @@ __global__ __launch_bounds__(256) void k_check_dbl(const G1Affine* pts, int n, i
   // half of the wave exceptional, half not (EXEC masking inside the statement)
   G1Affine qm = (t & 1) ? p : pts[(t + 3) % n];
   same(g1_add_mixed_walk(G1XYZZ::from_affine(p), qm), g1_add_mixed(G1XYZZ::from_affine(p), qm));
+  // affine + affine (second entry of a walk): general position, P + P, P + (-P), infinity operands, "first only" lanes, mixed waves
+  for (int k = 0; k < 4; k++) {
+    G1Affine q = pts[(t * 3 + 11 * k + 2) % n];
+    if (k & 1) q = g1_neg(q);
+    same(g1_add_affine_walk(p, q, false), g1_add_mixed(G1XYZZ::from_affine(p), q));
+  }
+  same(g1_add_affine_walk(p, p, false), d2);
+  same(g1_add_affine_walk(p, g1_neg(p), false), G1XYZZ::inf());
+  same(g1_add_affine_walk(G1Affine::inf(), p, false), G1XYZZ::from_affine(p));
+  same(g1_add_affine_walk(p, G1Affine::inf(), false), G1XYZZ::from_affine(p));
+  same(g1_add_affine_walk(p, qm, true), G1XYZZ::from_affine(p));
+  same(g1_add_affine_walk(p, qm, (t & 2) != 0), (t & 2) ? G1XYZZ::from_affine(p) : g1_add_mixed(G1XYZZ::from_affine(p), qm));
 }
 
 template <class F> float time_ms(F f, int reps) {
