@@ -40,10 +40,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAD_PEAK_PER_S = 2.79e13       # measured v_mad_u64_u32 issue rate, tools/microbench.hip (profiles/r01_microbench.txt)
-ACCUM_INSTR_PER_ADD = 7139     # static ISA count of one bucket-walk iteration: 899 around 10 x the 624-instruction product core (tools/count_accum_instrs.py; lower bound)
-VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4    # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_msm.json")   # FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc)
+# Integer roof of the bucket accumulation (tools/microbench.hip on one MI355X, profiles/r02_microbench.txt):
+MAD_PEAK_PER_S = 2.8e13        #   v_mad_u64_u32 issue rate, all CUs, independent chains
+MADD_ALU_ONLY_PER_S = 6.51e9   #   the same fused mixed addition in a register-only loop (no memory access): what the instruction mix sustains
+# static ISA count of one bucket-walk iteration (tools/count_accum_instrs.py): 816 instructions around six calls of the 624-instruction
+# product core, two of the 532-instruction squaring core and one of the 924-instruction two-product core
+ACCUM_INSTR_PER_ADD = 6548
+ACCUM_MADS_PER_ADD = 2608
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_msm.json")   # FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc)
 
 
 def log(*a):
@@ -240,30 +244,32 @@ def main():
     try:   # HBM bytes per launch from the separate PMC passes (same command with --msm-only), if taken for this size
         pmc = json.load(open(PMC_FILE))
         if pmc.get("msm_n") == msm_n:
-            traffic, traffic_src = pmc["k_bucket_accum"]["hbm_bytes_per_launch"], "profiles/r01_pmc_msm.json"
+            traffic, traffic_src = pmc["k_bucket_accum"]["hbm_bytes_per_launch"], "profiles/r02_pmc_msm.json"
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": "k_bucket_accum", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "rocprof_summary": "profiles/r01_msm_only_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --msm-only --no-cpu "
-                                   "--steps 5 --warmup 1: the same N = 2^20 launches and nothing else; profiles/r01_bench_kernel_stats.csv is the full "
+                "rocprof_summary": "profiles/r02_msm_only_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --msm-only --no-cpu "
+                                   "--steps 5 --warmup 1: the same N = 2^20 launches and nothing else; profiles/r02_bench_kernel_stats.csv is the full "
                                    "default run, where the kernel also serves the batched groups of prove())",
-                "note": "modular-integer kernel: the binding roof is VALU issue, see int_roofline"}
-    # integer roof: W windows x N mixed additions x 10 Fq products x 288 MADs
+                "note": "modular-integer kernel: the binding roof is integer multiply issue, see int_roofline"}
+    # integer roof of the same kernel.  Additions = entries - buckets (the first entry of a bucket is a copy); every addition is
+    # ACCUM_MADS_PER_ADD v_mad_u64_u32 (the multiplier: ~2.3x the issue cost of a plain 32-bit VALU instruction on this chip) inside
+    # ACCUM_INSTR_PER_ADD instructions.  Two fractions: of the chip's MAD issue rate, and of the rate the whole instruction mix
+    # sustains in a register-only loop (what is left is memory latency and the launch tail).
     pc, pw_, pb = C.c_int(), C.c_int(), C.c_int()
     L.sonic_msm_plan(srs._h, msm_n, C.byref(pc), C.byref(pw_), C.byref(pb))
-    mads = pw_.value * msm_n * 10 * 288
-    int_roofline = {"bound": "v_mad_u64_u32", "achieved": round(mads / (accum_ms * 1e-3) / 1e12, 3) if accum_ms > 0 else 0.0,
-                    "peak": MAD_PEAK_PER_S / 1e12, "unit": "TMAD/s",
-                    "frac": round(mads / (accum_ms * 1e-3) / MAD_PEAK_PER_S, 4) if accum_ms > 0 else 0.0,
-                    "plan": {"window_bits": pc.value, "windows": pw_.value, "bucket_sets": pb.value}}
-    # VALU issue model: one wave per SIMD already issues the routine back to back (1.1 us per dependent product = 680 x 4 cycles),
-    # so the kernel pays for instructions, not latency: additions x static instructions per addition / (time x issue rate)
-    n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value          # the first term of a bucket is a copy
-    int_roofline["valu_issue"] = {"instr_per_mixed_add": ACCUM_INSTR_PER_ADD, "wave_instr_per_s_peak": VALU_WAVE_INSTR_PER_S,
-                                  "pmc": "SQ_INSTS_VALU = 1.468e9 per launch at N = 2^20 (profiles/r01_pmc_SQ_counter_collection.csv) vs 1.461e9 from the static count",
-                                  "frac": round(n_adds * ACCUM_INSTR_PER_ADD / 64 / (accum_ms * 1e-3) / VALU_WAVE_INSTR_PER_S, 4) if accum_ms > 0 else 0.0}
+    n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value
+    adds_per_s = n_adds / (accum_ms * 1e-3) if accum_ms > 0 else 0.0
+    int_roofline = {"bound": "v_mad_u64_u32", "achieved": round(adds_per_s * ACCUM_MADS_PER_ADD / 1e12, 3),
+                    "peak": MAD_PEAK_PER_S / 1e12, "unit": "TMAD/s", "frac": round(adds_per_s * ACCUM_MADS_PER_ADD / MAD_PEAK_PER_S, 4),
+                    "plan": {"window_bits": pc.value, "windows": pw_.value, "bucket_sets": pb.value},
+                    "mixed_additions_per_launch": n_adds, "instr_per_mixed_add": ACCUM_INSTR_PER_ADD, "mads_per_mixed_add": ACCUM_MADS_PER_ADD,
+                    "alu_only": {"adds_per_s_register_loop": MADD_ALU_ONLY_PER_S, "kernel_adds_per_s": round(adds_per_s, 1),
+                                 "frac": round(adds_per_s / MADD_ALU_ONLY_PER_S, 4),
+                                 "source": "tools/microbench g1_add_mixed_walk (profiles/r02_microbench.txt)"},
+                    "pmc": "profiles/r02_pmc_SQ_counter_collection.csv: SQ_INSTS_VALU per launch against n_adds x instr_per_mixed_add / 64"}
 
     cpu_baseline = None
     if not args.no_cpu:

@@ -395,6 +395,31 @@ def test_prove_example_circuits(sonic, ref, srs_pair):
         assert ref.verify_exponent(s, circ, asg, tr, want)
 
 
+def test_reference_bench_shape(sonic, orc, ref):
+    """the reference's criterion benchmark (bench/Main.hs:18-27,37-49): x = 1 (!), alpha = 4, d = 25 n, Example1 and Example2.
+    With x = 1 every element of a basis is the SAME point, so every bucket walk is a chain of P + P / P + (-P): the exceptional
+    lanes of the fused additions (both variants) and of the running sums carry the whole computation.  Prover bytes against
+    both oracles, and the verifier accepts; a larger random circuit on the same degenerate SRS for the sorted-bucket paths."""
+    pyr = random.Random(2024)
+    for circ, asg in (ref.arith_circuit_example1(), ref.arith_circuit_example2(12)):
+        n, Q = len(asg[0]), len(circ[0])
+        d = 25 * n
+        g, s = sonic.SRS.new(d, 1, 4), ref.SRS(d, 1, 4)
+        tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+        circuit = sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3])
+        proof, ro = sonic.prove(g, sonic.Assignment(*asg), circuit, transcript=tr)
+        want, _ = ref.prove(s, asg, circ, tr)
+        assert proof.to_bytes() == ref.proof_to_bytes(want)
+        assert sonic.verify(g, circuit, proof, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    n, Q, d = 300, 3, 7 * 300 + 5
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+    g, o = sonic.SRS.new(d, 1, 4), orc.SRS(d, 1, 4, threads=NCPU)
+    p = sonic.Prover(g, sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3]))
+    p.set_assignment(sonic.Assignment(*asg))
+    assert p.prove_bytes(tr) == orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], fr_bytes(tr))
+
+
 def test_prove_error_contract(sonic, ref, srs_pair):
     d, x, alpha, g, _ = srs_pair
     pyr = random.Random(5)
@@ -567,6 +592,22 @@ def test_reference_verifier_accepts_gpu_proofs(sonic, ref):
         assert pg.verify(vsrs, circ, pr, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
         pr["prB"] = (pr["prB"] + 1) % R
         assert not pg.verify(vsrs, circ, pr, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+
+
+def test_reference_example_program(sonic):
+    """examples/Main.hs of the reference as examples/main.py: fresh x, alpha, z; SRS.new, prove, verify -> Success: True;
+    and a wrong assignment does not verify (the prover refuses it: t(X,y) gets a constant term)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("sonic_example", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "main.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    assert ex.run_example() is True
+    circuit, asg = ex.arith_circuit_example(5)
+    bad = sonic.Assignment(asg.aL, asg.aR, [(asg.aO[0] + 1) % R, asg.aO[1]])
+    with pytest.raises(sonic.SonicError) as e:
+        ex.sonic_protocol(circuit, bad, 12345)
+    assert e.value.code == 2
 
 
 def test_product_verifier(sonic, ref, srs_pair):

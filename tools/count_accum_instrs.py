@@ -36,7 +36,8 @@ def main():
     calls = [sum(1 for x in b[1] if x.startswith("s_swappc")) for b in blocks]
     index = {b[0]: k for k, b in enumerate(blocks)}
     # the hot block is the fused mixed addition: the one that calls the two-product core (else: the block with ten product calls)
-    fused = [k for k, b in enumerate(blocks) if any("sonic_mont_mul2_fq_core@rel32" in x for x in b[1])]
+    # (nine calls: six products, two squarings, one two-product; the affine + affine statement before the loop has five)
+    fused = [k for k, b in enumerate(blocks) if any("sonic_mont_mul2_fq_core@rel32" in x for x in b[1]) and calls[k] == 9]
     hot = fused[0] if fused else calls.index(10)
     # innermost loop around the hot block: smallest [target, source] span of a backward branch that contains it
     span = None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 --pmc passes of `bench.py --msm-only` (FETCH_SIZE, WRITE_SIZE; one counter per pass, as
-MI355X_MICROARCH.md's HBM section prescribes) into profiles/r01_pmc_msm.json: HBM bytes per launch of every MSM kernel.
+MI355X_MICROARCH.md's HBM section prescribes) into profiles/r02_pmc_msm.json: HBM bytes per launch of every MSM kernel.
 
     python tools/pmc_summary.py <FETCH_SIZE_counter_collection.csv> <WRITE_SIZE_counter_collection.csv> <msm_n> <c> <W> <sets> > out.json
 
