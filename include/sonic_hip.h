@@ -150,6 +150,12 @@ int sonic_prover_submit(sonic_prover_t* p, const uint8_t* transcript);
 int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof);
 void sonic_prover_free(sonic_prover_t* p);
 
+/* hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof  (Signature.hs:32-72) on its own, for the s(X,Y) of the handle's
+ * circuit (Constraints.hs:34-53) and any number m of (y_j, z_j) pairs (yzs: m x 64 bytes); u, v are its two `rnd` draws.
+ * out (sonic_hsc_proof_size(m) bytes): [S_j, s_j, W_j]_j, [s'_j, W'_j, Q_j]_j, Q_v, C, u, v -- the HscProof part of a proof. */
+size_t sonic_hsc_proof_size(int64_t m);
+int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out);
+
 /* ---- the verifier side of the API (host CPU; outside the accelerated path) ---- */
 /* pcV :: SRS -> Int -> G1 -> Fr -> (Fr, G1) -> Bool  (CommitmentScheme.hs:51-68); *accepted = 0 / 1 */
 int sonic_pc_v(const sonic_srs_t* srs, int64_t max, const uint8_t commitment[96], const uint8_t z[32], const uint8_t v[32],
@@ -158,6 +164,10 @@ int sonic_pc_v(const sonic_srs_t* srs, int64_t max, const uint8_t commitment[96]
  * hscVerify (Signature.hs:74-90).  yzs = Q pairs y_j || z_j (64 bytes each), i.e. rndOracleYZs. */
 int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                  const uint8_t* cs, const uint8_t* proof, const uint8_t y[32], const uint8_t z[32], const uint8_t* yzs, int* accepted);
+
+/* hscVerify :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> HscProof -> Bool  (Signature.hs:74-90) for the s(X,Y) of a circuit */
+int sonic_hsc_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                     int64_t m, const uint8_t* yzs, const uint8_t* hsc, int* accepted);
 
 /* ---- device memory for callers without a HIP binding ---- */
 int sonic_dev_alloc(size_t bytes, void** out);

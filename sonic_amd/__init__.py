@@ -6,7 +6,7 @@ Python host-side mirror of the reference's Haskell modules over the C ABI of
     Sonic.SRS               -> sonic_amd.srs          (SRS, SRS.new)
     Sonic.CommitmentScheme  -> sonic_amd.commitment   (commit_poly, open_poly, pc_v)
     Sonic.Protocol          -> sonic_amd.protocol     (prove, verify, Proof, RndOracle, Prover)
-    Sonic.Signature         -> sonic_amd.protocol     (HscProof; hscProve runs inside prove)
+    Sonic.Signature         -> sonic_amd.protocol     (HscProof, hsc_prove, hsc_verify; hscProve also runs inside prove)
 
 All compute happens in hand-written HIP kernels on the GPU; this package is ctypes plumbing.
 There is no CPU fallback: without the built extension imports fail, without a GPU calls raise.
@@ -22,7 +22,7 @@ from ._lib import SonicError, LIB_PATH  # noqa: F401,E402
 from .encoding import R_MODULUS, Q_MODULUS, fr_to_bytes, fr_from_bytes, g1_to_bytes, g1_from_bytes  # noqa: F401,E402
 from .srs import SRS  # noqa: F401,E402
 from .commitment import commit_poly, open_poly, pc_v, msm_g1  # noqa: F401,E402
-from .protocol import prove, verify, Proof, HscProof, RndOracle, Prover, ProverPipeline, ArithCircuit, Assignment, GateWeights  # noqa: F401,E402
+from .protocol import prove, verify, hsc_prove, hsc_verify, Proof, HscProof, RndOracle, Prover, ProverPipeline, ArithCircuit, Assignment, GateWeights  # noqa: F401,E402
 
-__all__ = ["SRS", "commit_poly", "open_poly", "pc_v", "msm_g1", "prove", "verify", "Proof", "HscProof", "RndOracle", "Prover", "ProverPipeline",
+__all__ = ["SRS", "commit_poly", "open_poly", "pc_v", "msm_g1", "prove", "verify", "hsc_prove", "hsc_verify", "Proof", "HscProof", "RndOracle", "Prover", "ProverPipeline",
            "ArithCircuit", "Assignment", "GateWeights", "SonicError"]

@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
         "sonic_prover_submit": [vp, vp],
         "sonic_prover_collect": [vp, vp],
         "sonic_prover_prepare": [vp],
+        "sonic_prover_hsc_prove": [vp, i64, vp, cp, cp, vp],
+        "sonic_hsc_verify": [vp, i64, i64, vp, vp, vp, i64, vp, vp, C.POINTER(i32)],
         "sonic_pc_v": [vp, i64, cp, cp, cp, cp, C.POINTER(i32)],
         "sonic_verify": [vp, i64, i64, vp, vp, vp, vp, vp, cp, cp, vp, C.POINTER(i32)],
         "sonic_dev_alloc": [C.c_size_t, C.POINTER(vp)],
@@ -94,6 +96,8 @@ def lib() -> C.CDLL:
     L.sonic_srs_d.restype = i64
     L.sonic_proof_size.argtypes = [i64]
     L.sonic_proof_size.restype = C.c_size_t
+    L.sonic_hsc_proof_size.argtypes = [i64]
+    L.sonic_hsc_proof_size.restype = C.c_size_t
     _lib = L
     return L
 
@@ -104,7 +108,7 @@ EXPORTED = [
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
     "sonic_g1_sum_partials", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
-    "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
+    "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare", "sonic_prover_hsc_prove", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
     "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",
     "sonic_profile_names",
 ]

@@ -620,6 +620,99 @@ int sonic_prover_prepare(sonic_prover_t* p) {
 
 void sonic_prover_free(sonic_prover_t* p) { delete p; }
 
+// hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof (Signature.hs:32-72) on its own, for the s(X,Y) of the handle's
+// circuit (Constraints.hs:34-53) and ANY number m of (y_j, z_j) pairs -- inside prove() m is the number of linear constraints,
+// the reference's own test of the sub-protocol (test/Test/Signature.hs:20-36) draws them freely.  u, v are hscProve's two `rnd`
+// draws (:48, :60).  Not the hot path (prove() runs these MSMs interleaved with the rest of the proof): one group after the
+// other on the handle's main stream, same kernels.  out: [S_j, s_j, W_j]_j, [s'_j, W'_j, Q_j]_j, Q_v, C, u, v.
+size_t sonic_hsc_proof_size(int64_t m) { return (size_t)((2 + 4 * m) * 96 + (2 + 2 * m) * 32); }
+
+int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out) {
+  API_BEGIN
+  if (!p || m < 0 || (m > 0 && !yzs) || !u || !v || !out) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  if (p->in_flight) { set_error("sonic_prover_hsc_prove: a submitted proof has not been collected yet"); return SONIC_ERR_INVALID_ARG; }
+  const long n = p->n, Q = p->Q, d = srs_d(p->srs);
+  for (long k = 0; k < 2 * m; k++)
+    if (bytes_are_zero(yzs + 32 * k, 32)) { set_error("hscProve: y_j / z_j number %ld is zero: Laurent evaluation at 0 divides by zero", k); return SONIC_ERR_INEXACT_DIVISION; }
+  if (bytes_are_zero(u, 32) || bytes_are_zero(v, 32)) { set_error("hscProve: u or v is zero"); return SONIC_ERR_INEXACT_DIVISION; }
+  hipStream_t st = p->st;
+  const sonic_srs* srs = p->srs;
+  const Fr *wL = p->wL.as<Fr>(), *wR = p->wR.as<Fr>(), *wO = p->wO.as<Fr>();
+  const long NS = 2 * m + 2;                                   // scalars: y_1..y_m, z_1..z_m, u, v
+  const long K = 4 * m + 2;                                    // MSMs
+  DevBuf S(sizeof(Fr) * NS), PR(sizeof(Fr) * 2 * NS), slots(sizeof(MsmSlot) * K), frout(sizeof(Fr) * (2 * m + 1)), flags(4);
+  DevBuf pw(sizeof(Fr) * (3 * n + Q + 2)), su(sizeof(Fr) * (2 * n + Q + 1)), sy(sizeof(Fr) * (3 * n + 1));
+  int* fl = flags.as<int>();
+  HIP_OK(hipMemsetAsync(fl, 0, 4, st));
+  {
+    std::vector<uint8_t> h(32 * (size_t)NS);
+    for (long j = 0; j < m; j++) { memcpy(&h[32 * j], yzs + 64 * j, 32); memcpy(&h[32 * (m + j)], yzs + 64 * j + 32, 32); }
+    memcpy(&h[32 * (2 * m)], u, 32); memcpy(&h[32 * (2 * m + 1)], v, 32);
+    HIP_OK(hipMemcpyAsync(S.p, h.data(), h.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+  }
+  fr_to_mont_enqueue(st, S.as<Fr>(), NS, fl);
+  fr_with_inverse_enqueue(st, S.as<Fr>(), (int)NS, PR.as<Fr>());
+  const Fr* P0 = PR.as<Fr>();
+  auto pY = [&](long j) { return P0 + 2 * j; };
+  auto pZ = [&](long j) { return P0 + 2 * (m + j); };
+  const Fr *pU = P0 + 2 * (2 * m), *pV = P0 + 2 * (2 * m + 1);
+  MsmSlot* sl = slots.as<MsmSlot>();
+  Fr* fo = frout.as<Fr>();
+  Lane& lane = p->lanes[0];
+  const long s_lo = -n, s_len = 3 * n + 1, u_lo = -n, u_len = 2 * n + Q + 1;
+  // slots: S_j = 3j, W_j = 3j + 1, W'_j = 3j + 2;  Q_j = 3m + j;  Q_v = 4m;  C = 4m + 1.   frout: s_j = j, s'_j = m + j
+  for (long j = 0; j < m; j++) {                                                       // Signature.hs:40-45, 54
+    poly_scale_powers_enqueue(st, nullptr, pw.as<Fr>(), 2 * n + Q + 1, -n, pY(j), pY(j) + 1);
+    s_of_y_enqueue(st, wL, wR, wO, pw.as<Fr>(), n, Q, sy.as<Fr>());
+    MsmJob jobs[3];
+    jobs[0] = commit_job(st, srs, sy.as<Fr>(), s_lo, s_len, d, &sl[3 * j], fl);
+    jobs[1] = open_job(st, srs, lane.sc[1], sy.as<Fr>(), s_lo, s_len, pZ(j), &fo[j], &sl[3 * j + 1], fl);
+    jobs[2] = open_job(st, srs, lane.sc[2], sy.as<Fr>(), s_lo, s_len, pU, nullptr, &sl[3 * j + 2], fl);
+    run_jobs(st, srs, lane.ws, jobs, 3);
+  }
+  poly_scale_powers_enqueue(st, nullptr, pw.as<Fr>(), 3 * n + 1, -n, pU, pU + 1);      // u^e, e in [-n, 2n]       :51
+  s_of_u_enqueue(st, wL, wR, wO, pw.as<Fr>(), n, Q, su.as<Fr>(), p->tmp);
+  {
+    MsmJob jobs[MSM_MAX_JOBS];
+    int k = 0;
+    auto flush = [&] { run_jobs(st, srs, lane.ws, jobs, k); k = 0; };
+    jobs[k++] = commit_job(st, srs, su.as<Fr>(), u_lo, u_len, d, &sl[4 * m + 1], fl);                               // C    :52
+    for (long j = 0; j < m; j++) {                                                                                    // Q_j  :55
+      if (k == MSM_MAX_JOBS) flush();
+      jobs[k] = open_job(st, srs, lane.sc[k], su.as<Fr>(), u_lo, u_len, pY(j), &fo[m + j], &sl[3 * m + j], fl);
+      k++;
+    }
+    if (k == MSM_MAX_JOBS) flush();
+    jobs[k] = open_job(st, srs, lane.sc[k], su.as<Fr>(), u_lo, u_len, pV, &fo[2 * m], &sl[4 * m], fl);               // Q_v  :63
+    k++;
+    flush();
+  }
+  fr_from_mont_enqueue(st, fo, 2 * m + 1);
+  std::vector<MsmSlot> hs((size_t)K);
+  std::vector<uint8_t> hfr(32 * (size_t)(2 * m + 1));
+  HIP_OK(hipMemcpyAsync(hs.data(), sl, sizeof(MsmSlot) * K, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(hfr.data(), fo, hfr.size(), hipMemcpyDeviceToHost, st));
+  int hflags = read_flags(st, flags);
+  if (hflags) return flags_to_status(hflags, "hscProve");
+  std::vector<uint8_t> pts(96 * (size_t)K);
+  {
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<long>(K, 16);
+    for (int w = 0; w < nt; w++)
+      th.emplace_back([&, w] { for (long i = w; i < K; i += nt) g1_canonical_bytes_host(msm_finish_host(hs[i]), &pts[96 * (size_t)i]); });
+    for (auto& x : th) x.join();
+  }
+  uint8_t* o = out;
+  auto putG = [&](long i) { memcpy(o, &pts[96 * (size_t)i], 96); o += 96; };
+  auto putF = [&](const uint8_t* b) { memcpy(o, b, 32); o += 32; };
+  for (long j = 0; j < m; j++) { putG(3 * j); putF(&hfr[32 * j]); putG(3 * j + 1); }                 // hscS
+  for (long j = 0; j < m; j++) { putF(&hfr[32 * (m + j)]); putG(3 * j + 2); putG(3 * m + j); }       // hscW
+  putG(4 * m); putG(4 * m + 1); putF(u); putF(v);                                                   // Qv, C, u, v
+  API_END
+}
+
 int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                 const uint8_t* cs, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript,
                 uint8_t* out_proof) {

@@ -225,6 +225,46 @@ int pc_v(const sonic_srs* srs, const VerifierKey& vk, int64_t maxm, const G1Affi
   return SONIC_OK;
 }
 
+// hscVerify srs sXY yzs proof (Signature.hs:74-90) for the s(X,Y) of a circuit (Constraints.hs:34-53): s(u,v) on the host,
+// then 3m + 1 pcV checks.  `all` is and-ed with every check.
+int hsc_checks(const sonic_srs* srs, const VerifierKey& vk, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+               int64_t m, const std::vector<Fr>& ys, const std::vector<Fr>& zs, const std::vector<G1Affine>& Sj, const std::vector<Fr>& sj,
+               const std::vector<G1Affine>& Wj, const std::vector<Fr>& spj, const std::vector<G1Affine>& Wpj, const std::vector<G1Affine>& Qj,
+               const G1Affine& Qv, const G1Affine& C, const Fr& u, const Fr& v, bool& all) {
+  // s(u, v): sum_i u^-i U_i(v) + u^i V_i(v) + u^{i+n} W_i(v)   (Signature.hs:81; Constraints.hs:34-53)
+  if (u.is_zero() || v.is_zero()) { set_error("hscVerify: u or v is zero"); return SONIC_ERR_INEXACT_DIVISION; }
+  std::vector<Fr> vq(Q);
+  { Fr x = fr_pow(v, (uint64_t)n); for (int64_t q = 0; q < Q; q++) { x = fp_mul(x, v); vq[q] = x; } }
+  const Fr uinv = fp_inv(u), vinv = fp_inv(v), un = fr_pow(u, (uint64_t)n);
+  Fr up = Fr::one(), um = Fr::one(), vp = Fr::one(), vm = Fr::one(), sv = Fr::zero();
+  for (int64_t i = 1; i <= n; i++) {
+    up = fp_mul(up, u); um = fp_mul(um, uinv); vp = fp_mul(vp, v); vm = fp_mul(vm, vinv);
+    Fr Ui = Fr::zero(), Vi = Fr::zero(), Wi = Fr::zero(), c;
+    for (int64_t q = 0; q < Q; q++) {
+      if (!load_fr(wL + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Ui = fp_add(Ui, fp_mul(c, vq[q]));
+      if (!load_fr(wR + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Vi = fp_add(Vi, fp_mul(c, vq[q]));
+      if (!load_fr(wO + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Wi = fp_add(Wi, fp_mul(c, vq[q]));
+    }
+    Wi = fp_sub(fp_sub(Wi, vp), vm);
+    sv = fp_add(sv, fp_add(fp_add(fp_mul(um, Ui), fp_mul(up, Vi)), fp_mul(fp_mul(up, un), Wi)));
+  }
+  const int64_t d = srs_d(srs);
+  int rc = SONIC_OK;
+  bool ok = false;
+  auto chk = [&](const G1Affine& Fc, const Fr& zz, const Fr& val, const G1Affine& W) {
+    if (rc) return;
+    rc = pc_v(srs, vk, d, Fc, zz, val, W, ok);
+    all = all && ok;
+  };
+  for (int64_t j = 0; j < m; j++) {                                // Signature.hs:82-88
+    chk(Sj[j], zs[j], sj[j], Wj[j]);
+    chk(Sj[j], u, spj[j], Wpj[j]);
+    chk(C, ys[j], spj[j], Qj[j]);
+  }
+  chk(C, v, sv, Qv);                                               // Signature.hs:89
+  return rc;
+}
+
 }  // namespace
 }  // namespace sonic
 
@@ -272,23 +312,6 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
     Fr ky = Fr::zero(), pw = fr_pow(ym, (uint64_t)n);
     for (int64_t q = 0; q < Q; q++) { Fr c; if (!load_fr(cs + 32 * q, c)) return SONIC_ERR_BAD_ENCODING; pw = fp_mul(pw, ym); ky = fp_add(ky, fp_mul(c, pw)); }
     const Fr t = fp_sub(fp_mul(a, fp_add(b, s)), ky);              // Protocol.hs:120
-    // s(u, v): sum_i u^-i U_i(v) + u^i V_i(v) + u^{i+n} W_i(v)   (Signature.hs:81; Constraints.hs:34-53)
-    if (u.is_zero() || v.is_zero()) { set_error("verify: u or v is zero"); return SONIC_ERR_INEXACT_DIVISION; }
-    std::vector<Fr> vq(Q);
-    { Fr x = fr_pow(v, (uint64_t)n); for (int64_t q = 0; q < Q; q++) { x = fp_mul(x, v); vq[q] = x; } }
-    const Fr uinv = fp_inv(u), vinv = fp_inv(v), un = fr_pow(u, (uint64_t)n);
-    Fr up = Fr::one(), um = Fr::one(), vp = Fr::one(), vm = Fr::one(), sv = Fr::zero();
-    for (int64_t i = 1; i <= n; i++) {
-      up = fp_mul(up, u); um = fp_mul(um, uinv); vp = fp_mul(vp, v); vm = fp_mul(vm, vinv);
-      Fr Ui = Fr::zero(), Vi = Fr::zero(), Wi = Fr::zero(), c;
-      for (int64_t q = 0; q < Q; q++) {
-        if (!load_fr(wL + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Ui = fp_add(Ui, fp_mul(c, vq[q]));
-        if (!load_fr(wR + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Vi = fp_add(Vi, fp_mul(c, vq[q]));
-        if (!load_fr(wO + 32 * (q * n + i - 1), c)) return SONIC_ERR_BAD_ENCODING; Wi = fp_add(Wi, fp_mul(c, vq[q]));
-      }
-      Wi = fp_sub(fp_sub(Wi, vp), vm);
-      sv = fp_add(sv, fp_add(fp_add(fp_mul(um, Ui), fp_mul(up, Vi)), fp_mul(fp_mul(up, un), Wi)));
-    }
     VerifierKey vk;
     int rc = fetch_g2(srs, 1, 0, vk.h_alpha);
     if (!rc) rc = fetch_g2(srs, 1, 1, vk.h_alpha_x);
@@ -300,15 +323,42 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
       rc = pc_v(srs, vk, maxm, Fc, zz, val, W, ok);
       all = all && ok;
     };
-    for (int64_t j = 0; j < Q; j++) {                              // hscVerify, Signature.hs:82-88
-      chk(d, Sj[j], zs[j], sj[j], Wj[j]);
-      chk(d, Sj[j], u, spj[j], Wpj[j]);
-      chk(d, C, ys[j], spj[j], Qj[j]);
-    }
-    chk(d, C, v, sv, Qv);                                          // Signature.hs:89
+    rc = hsc_checks(srs, vk, n, Q, wL, wR, wO, Q, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, all);   // hscVerify, Signature.hs:74-90
+    if (rc) return rc;
     chk(n, R, zm, a, Wa);                                          // Protocol.hs:123
     chk(n, R, fp_mul(ym, zm), b, Wb);                              // :124
     chk(d, T, zm, t, Wt);                                          // :125
+    if (rc) return rc;
+    *accepted = all ? 1 : 0;
+    return SONIC_OK;
+  } catch (const HipFail& f) { return f.code; }
+}
+
+// hscVerify :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> HscProof -> Bool (Signature.hs:74-90) for the s(X,Y) of a circuit;
+// hsc = the bytes sonic_prover_hsc_prove wrote (m pairs)
+int sonic_hsc_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                     int64_t m, const uint8_t* yzs, const uint8_t* hsc, int* accepted) {
+  try {
+    if (!srs || n < 1 || Q < 1 || !wL || !wR || !wO || m < 0 || (m > 0 && !yzs) || !hsc || !accepted) return SONIC_ERR_INVALID_ARG;
+    *accepted = 0;
+    const uint8_t* p = hsc;
+    auto G = [&](G1Affine& o) { bool k = load_g1(p, o); p += 96; return k; };
+    auto F = [&](Fr& o) { bool k = load_fr(p, o); p += 32; return k; };
+    std::vector<G1Affine> Sj(m), Wj(m), Wpj(m), Qj(m);
+    std::vector<Fr> sj(m), spj(m), ys(m), zs(m);
+    G1Affine Qv, C; Fr u, v;
+    bool enc = true;
+    for (int64_t j = 0; j < m; j++) enc = enc && G(Sj[j]) && F(sj[j]) && G(Wj[j]);
+    for (int64_t j = 0; j < m; j++) enc = enc && F(spj[j]) && G(Wpj[j]) && G(Qj[j]);
+    enc = enc && G(Qv) && G(C) && F(u) && F(v);
+    for (int64_t j = 0; j < m; j++) enc = enc && load_fr(yzs + 64 * j, ys[j]) && load_fr(yzs + 64 * j + 32, zs[j]);
+    if (!enc) { set_error("hscVerify: non-canonical field element, or point off the curve or outside the order-r subgroup"); return SONIC_ERR_BAD_ENCODING; }
+    VerifierKey vk;
+    int rc = fetch_g2(srs, 1, 0, vk.h_alpha);
+    if (!rc) rc = fetch_g2(srs, 1, 1, vk.h_alpha_x);
+    if (rc) return rc;
+    bool all = true;
+    rc = hsc_checks(srs, vk, n, Q, wL, wR, wO, m, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, all);
     if (rc) return rc;
     *accepted = all ? 1 : 0;
     return SONIC_OK;

@@ -45,6 +45,47 @@ class HscProof:              # Signature.hs:22-29
     hscV: int
 
 
+def _hsc_to_bytes(h: "HscProof") -> bytes:
+    if len(h.hscS) != len(h.hscW):
+        raise ValueError("HscProof: hscS and hscW must have one entry per (y_j, z_j) pair")
+
+    def fr(v):                   # as is: a non-canonical field element must reach the verifier (which rejects it) unreduced
+        return int(v).to_bytes(32, "little")
+    out = []
+    for cm, (sj, wj) in h.hscS:
+        out += [g1_to_bytes(cm), fr(sj), g1_to_bytes(wj)]
+    for sjp, wjp, qj in h.hscW:
+        out += [fr(sjp), g1_to_bytes(wjp), g1_to_bytes(qj)]
+    out += [g1_to_bytes(h.hscQv), g1_to_bytes(h.hscC), fr(h.hscU), fr(h.hscV)]
+    return b"".join(out)
+
+
+def _hsc_from_bytes(b: bytes, m: int) -> "HscProof":
+    if len(b) != (2 + 4 * m) * 96 + (2 + 2 * m) * 32:
+        raise ValueError(f"HscProof for m = {m} is {(2 + 4 * m) * 96 + (2 + 2 * m) * 32} bytes, got {len(b)}")
+    pos = 0
+
+    def g():
+        nonlocal pos
+        v = g1_from_bytes(b[pos:pos + 96]); pos += 96
+        return v
+
+    def f():
+        nonlocal pos
+        v = int.from_bytes(b[pos:pos + 32], "little"); pos += 32
+        return v
+    hscS = []
+    for _ in range(m):
+        cm, sj, wj = g(), f(), g()
+        hscS.append((cm, (sj, wj)))
+    hscW = []
+    for _ in range(m):
+        sjp, wjp, qj = f(), g(), g()
+        hscW.append((sjp, wjp, qj))
+    qv, c, u, v = g(), g(), f(), f()
+    return HscProof(hscS, hscW, qv, c, u, v)
+
+
 @dataclass
 class Proof:                 # Protocol.hs:28-38
     prR: object
@@ -60,49 +101,21 @@ class Proof:                 # Protocol.hs:28-38
     def to_bytes(self) -> bytes:
         """canonical proof bytes (include/sonic_hip.h): the record order of `Proof` then `HscProof`, serialised from the
         fields -- an edited or hand-built Proof is what gets verified, never a cached copy of the prover's output"""
-        h = self.prHscProof
-        if len(h.hscS) != len(h.hscW):
-            raise ValueError("HscProof: hscS and hscW must have one entry per linear constraint")
-
-        def fr_to_bytes(v):          # as is: a non-canonical field element must reach the verifier (which rejects it) unreduced
+        def fr(v):               # as is: a non-canonical field element must reach the verifier (which rejects it) unreduced
             return int(v).to_bytes(32, "little")
-        out = [g1_to_bytes(self.prR), g1_to_bytes(self.prT), fr_to_bytes(self.prA), g1_to_bytes(self.prWa), fr_to_bytes(self.prB),
-               g1_to_bytes(self.prWb), g1_to_bytes(self.prWt), fr_to_bytes(self.prS)]
-        for cm, (sj, wj) in h.hscS:
-            out += [g1_to_bytes(cm), fr_to_bytes(sj), g1_to_bytes(wj)]
-        for sjp, wjp, qj in h.hscW:
-            out += [fr_to_bytes(sjp), g1_to_bytes(wjp), g1_to_bytes(qj)]
-        out += [g1_to_bytes(h.hscQv), g1_to_bytes(h.hscC), fr_to_bytes(h.hscU), fr_to_bytes(h.hscV)]
-        return b"".join(out)
+        head = [g1_to_bytes(self.prR), g1_to_bytes(self.prT), fr(self.prA), g1_to_bytes(self.prWa), fr(self.prB),
+                g1_to_bytes(self.prWb), g1_to_bytes(self.prWt), fr(self.prS)]
+        return b"".join(head) + _hsc_to_bytes(self.prHscProof)
 
     @classmethod
     def from_bytes(cls, b: bytes, Q: int) -> "Proof":
         b = bytes(b)
         if len(b) != (7 + 4 * Q) * 96 + (5 + 2 * Q) * 32:
             raise ValueError(f"proof for Q = {Q} is {(7 + 4 * Q) * 96 + (5 + 2 * Q) * 32} bytes, got {len(b)}")
-        pos = 0
-
-        def g():
-            nonlocal pos
-            v = g1_from_bytes(b[pos:pos + 96]); pos += 96
-            return v
-
-        def f():
-            nonlocal pos
-            v = int.from_bytes(b[pos:pos + 32], "little"); pos += 32
-            return v
-
-        prR, prT, prA, prWa, prB, prWb, prWt, prS = g(), g(), f(), g(), f(), g(), g(), f()
-        hscS = []
-        for _ in range(Q):
-            cm, sj, wj = g(), f(), g()
-            hscS.append((cm, (sj, wj)))
-        hscW = []
-        for _ in range(Q):
-            sjp, wjp, qj = f(), g(), g()
-            hscW.append((sjp, wjp, qj))
-        qv, c, u, v = g(), g(), f(), f()
-        return cls(prR, prT, prA, prWa, prB, prWb, prWt, prS, HscProof(hscS, hscW, qv, c, u, v))
+        g = lambda o: g1_from_bytes(b[o:o + 96])                  # noqa: E731
+        f = lambda o: int.from_bytes(b[o:o + 32], "little")       # noqa: E731
+        # R T a Wa b Wb Wt s
+        return cls(g(0), g(96), f(192), g(224), f(320), g(352), g(448), f(544), _hsc_from_bytes(b[576:], Q))
 
 
 @dataclass
@@ -166,6 +179,14 @@ class Prover:
         _lib.check(_lib.lib().sonic_prover_collect(self._h, out))
         return out.raw
 
+    def hsc_prove(self, yzs, u: int, v: int) -> HscProof:
+        """hscProve srs sXY yzs (Signature.hs:32-72) for the s(X,Y) of this handle's circuit; u, v: its two `rnd` draws"""
+        yzs = list(yzs)
+        flat = fr_array([x for pair in yzs for x in pair])
+        out = C.create_string_buffer(_lib.lib().sonic_hsc_proof_size(len(yzs)))
+        _lib.check(_lib.lib().sonic_prover_hsc_prove(self._h, len(yzs), flat.ctypes.data, fr_to_bytes(u), fr_to_bytes(v), out))
+        return _hsc_from_bytes(out.raw, len(yzs))
+
     def close(self):
         if self._h:
             _lib.lib().sonic_prover_free(self._h)
@@ -193,16 +214,21 @@ class ProverPipeline:
     def prove_all(self, transcripts) -> List[bytes]:
         k = len(self.provers)
         out: List[bytes] = []
-        pending = 0
-        for i, tr in enumerate(transcripts):
-            if pending == k:
-                out.append(self.provers[i % k].collect())
-                pending -= 1
-            self.provers[i % k].submit(tr)
-            pending += 1
-        n = len(transcripts)
-        for i in range(n - pending, n):
-            out.append(self.provers[i % k].collect())
+        inflight: List[int] = []          # indices of the submitted, not yet collected proofs, oldest first
+        try:
+            for i, tr in enumerate(transcripts):
+                if len(inflight) == k:
+                    out.append(self.provers[inflight.pop(0) % k].collect())
+                self.provers[i % k].submit(tr)
+                inflight.append(i)
+            while inflight:
+                out.append(self.provers[inflight.pop(0) % k].collect())
+        finally:
+            for i in inflight:            # an error on the way: leave no handle with a proof in flight
+                try:
+                    self.provers[i % k].collect()
+                except Exception:
+                    pass
         return out
 
     def close(self):
@@ -228,6 +254,37 @@ def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: O
     t = [int(v) % R_MODULUS for v in transcript]
     oracle = RndOracle(t[4], t[5], list(zip(t[6:6 + Q], t[6 + Q:6 + 2 * Q])))
     return Proof.from_bytes(raw, Q), oracle
+
+
+def hsc_prove(srs: SRS, circuit: ArithCircuit, yzs, u: Optional[int] = None, v: Optional[int] = None, rng=None) -> HscProof:
+    """hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof (Signature.hs:32-72), with sXY = sPoly of `circuit`'s weights
+    (Constraints.hs:34-53); u, v default to fresh draws"""
+    draw = (lambda: rng.randrange(1, R_MODULUS)) if rng is not None else (lambda: secrets.randbelow(R_MODULUS - 1) + 1)
+    p = Prover(srs, circuit, prepare=False)
+    try:
+        return p.hsc_prove(yzs, draw() if u is None else u, draw() if v is None else v)
+    finally:
+        p.close()
+
+
+def hsc_verify(srs: SRS, circuit: ArithCircuit, yzs, proof: HscProof) -> bool:
+    """hscVerify :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> HscProof -> Bool (Signature.hs:74-90); host CPU pairings"""
+    w = circuit.weights
+    wL, wR, wO = fr_matrix(w.wL), fr_matrix(w.wR), fr_matrix(w.wO)
+    Q = fr_array(circuit.cs).shape[0]
+    if Q < 1 or wL.shape[0] % Q or wL.shape[0] == 0 or wR.shape != wL.shape or wO.shape != wL.shape:
+        raise ValueError("hsc_verify: need Q >= 1 weight rows of equal length n >= 1 in wL, wR, wO")
+    n = wL.shape[0] // Q
+    yzs = list(yzs)
+    if any(len(pair) != 2 for pair in yzs):
+        raise ValueError("hsc_verify: yzs must hold (y_j, z_j) pairs")
+    if len(proof.hscS) != len(yzs) or len(proof.hscW) != len(yzs):
+        return False
+    flat = fr_array([x for pair in yzs for x in pair])
+    ok = C.c_int(0)
+    _lib.check(_lib.lib().sonic_hsc_verify(srs._h, n, Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data, len(yzs), flat.ctypes.data,
+                                           _hsc_to_bytes(proof), C.byref(ok)))
+    return bool(ok.value)
 
 
 def verify(srs: SRS, circuit: ArithCircuit, proof: Proof, y: int, z: int, yzs) -> bool:

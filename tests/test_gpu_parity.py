@@ -610,6 +610,40 @@ def test_reference_example_program(sonic):
     assert e.value.code == 2
 
 
+def test_hsc_prove_and_verify_standalone(sonic, ref):
+    """Sonic.Signature on its own (test/Test/Signature.hs:20-36): hscProve for the s(X,Y) of a random circuit with m (y_j, z_j)
+    pairs, m independent of the number of constraints; every element against the literal restatement, hscVerify accepts it
+    (host pairings, and the oracle's python pairing on the GPU's points), rejects a tampered one and other evaluation points"""
+    from oracle import pairing as pg
+    pyr = random.Random(55)
+    for n, Q, m in ((3, 2, 3), (5, 4, 1), (2, 1, 0)):
+        circ, asg = ref.rnd_circuit(pyr, n, Q)
+        d = 7 * n + 3
+        x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+        g, s = sonic.SRS.new(d, x, alpha), ref.SRS(d, x, alpha)
+        circuit = sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3])
+        yzs = [(pyr.randrange(1, R), pyr.randrange(1, R)) for _ in range(m)]
+        u, v = pyr.randrange(1, R), pyr.randrange(1, R)
+        got = sonic.hsc_prove(g, circuit, yzs, u, v)
+        want = ref.hsc_prove(s, ref.s_poly(*circ[:3]), yzs, u, v)
+        assert (got.hscS, got.hscW, got.hscQv, got.hscC, got.hscU, got.hscV) == \
+            (want["hscS"], want["hscW"], want["hscQv"], want["hscC"], want["hscU"], want["hscV"])
+        assert sonic.hsc_verify(g, circuit, yzs, got)
+        if m:
+            import dataclasses
+            assert pg.hsc_verify(pg.SRS(d, x, alpha), ref.s_poly(*circ[:3]), yzs, want)
+            sjp, wjp, qj = got.hscW[0]
+            bad = dataclasses.replace(got, hscW=[((sjp + 1) % R, wjp, qj)] + got.hscW[1:])
+            assert not sonic.hsc_verify(g, circuit, yzs, bad)
+            assert not sonic.hsc_verify(g, circuit, [((yzs[0][0] + 1) % R, yzs[0][1])] + yzs[1:], got)
+            assert not sonic.hsc_verify(g, circuit, yzs[:-1], got)
+    fresh = sonic.hsc_prove(g, circuit, [(3, 5)])                      # u, v drawn inside, as the reference's `rnd`
+    assert sonic.hsc_verify(g, circuit, [(3, 5)], fresh) and 0 < fresh.hscU < R and 0 < fresh.hscV < R
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.hsc_prove(g, circuit, [(0, 5)], 1, 2)
+    assert e.value.code == 4
+
+
 def test_product_verifier(sonic, ref, srs_pair):
     """verify . prove inside the product (test/Test/Protocol.hs:14-23): sonic_verify / sonic_pc_v (host pairings over the
     GPU-generated G2 elements) accept GPU proofs, reject tampered ones, and agree with the oracle's verifier"""

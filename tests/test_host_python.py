@@ -26,6 +26,21 @@ def test_proof_bytes_round_trip():
         assert p.to_bytes() == raw
 
 
+def test_hsc_proof_bytes_round_trip():
+    """the HscProof part of a proof is what sonic_prover_hsc_prove writes and sonic_hsc_verify reads (Signature.hs:22-29)"""
+    from sonic_amd.protocol import _hsc_from_bytes, _hsc_to_bytes
+    import sonic_amd
+    c = json.load(open(os.path.join(GOLD, "prove_small.json")))["cases"][0]
+    raw, Q = bytes.fromhex(c["proof"]), c["Q"]
+    tail = raw[576:]
+    h = _hsc_from_bytes(tail, Q)
+    assert _hsc_to_bytes(h) == tail and h == sonic_amd.Proof.from_bytes(raw, Q).prHscProof
+    assert len(tail) == (2 + 4 * Q) * 96 + (2 + 2 * Q) * 32
+    import pytest
+    with pytest.raises(ValueError):
+        _hsc_from_bytes(tail[:-1], Q)
+
+
 def test_transcript_draws():
     import random
     from sonic_amd.protocol import draw_transcript, transcript_len
