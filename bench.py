@@ -250,6 +250,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_bucket_accum", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_by_design_per_launch": None,   # filled below: the window-table method reads one 96-B table point per (term, window)
                 "rocprof_summary": "profiles/r02_msm_only_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --msm-only --no-cpu "
                                    "--steps 5 --warmup 1: the same N = 2^20 launches and nothing else; profiles/r02_bench_kernel_stats.csv is the full "
                                    "default run, where the kernel also serves the batched groups of prove())",
@@ -260,6 +261,7 @@ def main():
     # sustains in a register-only loop (what is left is memory latency and the launch tail).
     pc, pw_, pb = C.c_int(), C.c_int(), C.c_int()
     L.sonic_msm_plan(srs._h, msm_n, C.byref(pc), C.byref(pw_), C.byref(pb))
+    roofline["bytes_by_design_per_launch"] = float((4 + 96) * pw_.value * msm_n) if pb.value == 1 else None   # 4-B sorted entry + 96-B table point per (term, window)
     n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value
     adds_per_s = n_adds / (accum_ms * 1e-3) if accum_ms > 0 else 0.0
     int_roofline = {"bound": "v_mad_u64_u32", "achieved": round(adds_per_s * ACCUM_MADS_PER_ADD / 1e12, 3),
