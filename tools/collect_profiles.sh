@@ -30,4 +30,9 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAI
     python3 bench.py --no-cpu --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value']))"
   done
 } > $OUT/msm_sizes.txt
+python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1
+python3 tools/throughput_mode.py --log2n 18 --proofs 16 >> $OUT/throughput_mode.txt 2>&1
+# timeline of one solo proof (no streaming): where the time of prove() goes
+rocprofv3 --kernel-trace --output-format csv -d $OUT/solo -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pipeline --msm-log2 10 > $OUT/solo.json 2> $OUT/solo.err
+python3 tools/timeline.py $OUT/solo/t_kernel_trace.csv 250 > $OUT/timeline_solo.txt 2>&1
 find $OUT -name "*.csv" | head -40

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of the last prove() in a rocprofv3 --kernel-trace CSV: device span, union busy time, concurrency histogram
+"""Timeline of one prove() (the last but one) in a rocprofv3 --kernel-trace CSV: device span, union busy time, concurrency histogram
 and the long kernels in start order.  usage: python tools/timeline.py gpurun_out/trace/*/*kernel_trace.csv [min_us]"""
 import collections
 import csv
@@ -12,10 +12,12 @@ def main():
     ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("sonic::", "")[:28],
                  r.get("Queue_Id", "?")) for r in rows)
     starts = [s for s, e, n, q in ks if "k_build_r1" in n]
-    s0 = starts[-1]
+    # the last-but-one proof: everything from its first kernel to the first kernel of the next proof (run the bench with
+    # --no-pipeline so that consecutive proofs do not overlap); with a single proof: until the device pauses for 2 ms
+    s0, s1 = (starts[-2], starts[-1]) if len(starts) >= 2 else (starts[-1], None)
     sel, last_end = [], s0
     for s, e, n, q in (k for k in ks if k[0] >= s0):
-        if sel and s - last_end > 2_000_000:
+        if (s1 is not None and s >= s1) or (s1 is None and sel and s - last_end > 2_000_000):
             break
         sel.append((s, e, n, q))
         last_end = max(last_end, e)
