@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel HIP-event totals to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pipelined-throughput leg (timelines of one solo proof)")
+    ap.add_argument("--msm-lanes", type=int, default=3, help="lanes the standalone MSMs are streamed over")
     ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
     args = ap.parse_args()
 
@@ -201,6 +202,8 @@ def main():
         parts = sd.allgather_partials(part, world, device=coll_dev if use_nccl else None)       # RCCL all-gather of 192 B
         msm_result[0] = sd.sum_partials(parts, world)                                            # k-1 curve additions
 
+    # (1) one MSM after the other, every launch bracketed by HIP events: the dominant kernel's duration for the roofline
+    #     (alone on the chip, as in the rocprofv3 summary of --msm-only) and the latency of one MSM
     for _ in range(W):
         msm_step()
     barrier()
@@ -210,13 +213,42 @@ def main():
     for _ in range(K):
         msm_step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_seq = time.perf_counter() - t0
     L.sonic_profile_enable(0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    seq_result = msm_result[0]
+    # (2) the same K MSMs streamed over two lanes (sonic_msm_submit / sonic_msm_collect): MSM i + 1 is queued before MSM i is
+    #     collected, so the sort and the latency-bound reduction of one run under the accumulation of the other; each MSM's
+    #     partial still goes through the all-gather and the curve additions.  `msm.value` is this throughput.
+    NL = max(1, args.msm_lanes)
+    lanes = [sonic_amd.MsmLane() for _ in range(NL)]
+
+    def msm_stream(count):
+        res = b""
+        if count <= 0:
+            return res
+        for j in range(min(NL - 1, count)):
+            lanes[j % NL].submit(srs, basis, e0, dsc, msm_n)
+        for i in range(count):
+            if i + NL - 1 < count:
+                lanes[(i + NL - 1) % NL].submit(srs, basis, e0, dsc, msm_n)
+            mine = np.frombuffer(lanes[i % NL].collect(partial=True), np.uint8)
+            parts = sd.allgather_partials(mine, world, device=coll_dev if use_nccl else None)
+            res = sd.sum_partials(parts, world)
+        return res
+
+    msm_stream(max(W, NL))
+    barrier()
+    t0 = time.perf_counter()
+    stream_result = msm_stream(K)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt, dt_seq], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_msm = float(tmax.item())
+    dt_msm, dt_msm_seq = float(tmax[0].item()), float(tmax[1].item())
     msm_per_s = world * msm_n * K / dt_msm
+    for ln in lanes:
+        ln.close()
     ms, cnt = C.c_double(), C.c_int64()
     L.sonic_profile_get(b"k_bucket_accum", C.byref(ms), C.byref(cnt))
     accum_ms = ms.value / max(1, cnt.value)
@@ -334,7 +366,10 @@ def main():
                    "streaming": "K proofs streamed by one host thread through 2 prover handles per GPU (submit / collect); "
                                 "the strictly sequential rate is in `sequential`"},
         "msm": {"metric": "G1 MSM scalar-muls/sec", "value": round(msm_per_s, 1), "unit": "scalar-muls/s", "N_per_gpu": msm_n,
-                "ms_per_msm": round(1e3 * dt_msm / K, 3), "kernel_ms_per_msm": round(kern_total / K, 3)},
+                "ms_per_msm": round(1e3 * dt_msm / K, 3),
+                "streaming": f"K MSMs streamed over {NL} lanes per GPU (submit / collect); one at a time in `sequential`",
+                "sequential": {"scalar_muls_per_s": round(world * msm_n * K / dt_msm_seq, 1), "ms_per_msm": round(1e3 * dt_msm_seq / K, 3),
+                               "kernel_ms_per_msm": round(kern_total / K, 3), "same_result_as_streamed": seq_result == stream_result}},
         "roofline": roofline,
         "int_roofline": int_roofline,
         "cpu_baseline": cpu_baseline,

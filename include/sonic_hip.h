@@ -114,6 +114,15 @@ int sonic_msm_g1_srs_dev(const sonic_srs_t* srs, int basis, int64_t e0, const vo
 /* one rank's share of a range-sharded MSM: the un-normalised partial sum */
 int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars,
                                  int64_t n, uint8_t out_partial[192]);
+/* the same MSM in two halves on a lane of its own (stream, bucket workspace, pinned result): submit queues it and returns,
+ * collect waits and finishes it (out_g1: 96 canonical bytes, out_partial: 192-byte un-normalised sum; either may be NULL).
+ * One MSM in flight per lane; two lanes used in turn stream MSMs with the sort and the reduction of one under the
+ * accumulation of the other.  d_scalars: canonical 32-byte Fr resident in HBM, untouched until collect. */
+typedef struct sonic_msm_lane sonic_msm_lane_t;
+int sonic_msm_lane_new(sonic_msm_lane_t** out);
+void sonic_msm_lane_free(sonic_msm_lane_t* lane);
+int sonic_msm_submit(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n);
+int sonic_msm_collect(sonic_msm_lane_t* lane, uint8_t* out_g1, uint8_t* out_partial);
 /* curve addition of k partials (RCCL has no such reduction op) + normalisation */
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]);
 /* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n) */

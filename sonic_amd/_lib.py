@@ -57,6 +57,9 @@ def lib() -> C.CDLL:
         "sonic_msm_g1_srs_dev": [vp, i32, i64, vp, i64, vp],
         "sonic_msm_g1_srs_partial_dev": [vp, i32, i64, vp, i64, vp],
         "sonic_g1_sum_partials": [vp, i32, vp],
+        "sonic_msm_lane_new": [C.POINTER(vp)],
+        "sonic_msm_submit": [vp, vp, i32, i64, vp, i64],
+        "sonic_msm_collect": [vp, vp, vp],
         "sonic_ntt_fr": [vp, i32, i32],
         "sonic_poly_mul_fr": [vp, i64, vp, i64, vp],
         "sonic_msm_set_window": [i32],
@@ -92,6 +95,8 @@ def lib() -> C.CDLL:
     L.sonic_srs_free.restype = None
     L.sonic_prover_free.argtypes = [vp]
     L.sonic_prover_free.restype = None
+    L.sonic_msm_lane_free.argtypes = [vp]
+    L.sonic_msm_lane_free.restype = None
     L.sonic_srs_d.argtypes = [vp]
     L.sonic_srs_d.restype = i64
     L.sonic_proof_size.argtypes = [i64]
@@ -106,7 +111,7 @@ EXPORTED = [
     "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_srs_new", "sonic_srs_from_points",
     "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
-    "sonic_g1_sum_partials", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window", "sonic_msm_plan",
+    "sonic_g1_sum_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
     "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare", "sonic_prover_hsc_prove", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
     "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",

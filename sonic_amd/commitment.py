@@ -60,3 +60,37 @@ def msm_g1_srs(srs: SRS, basis: int, e0: int, scalars) -> bytes:
     out = C.create_string_buffer(96)
     _lib.check(_lib.lib().sonic_msm_g1_srs(srs._h, basis, e0, sc.ctypes.data, sc.shape[0], out))
     return out.raw
+
+
+class MsmLane:
+    """One MSM at a time over an SRS slice with device-resident scalars, in two halves (sonic_msm_submit / sonic_msm_collect).
+    Two lanes used in turn stream MSMs: the sort and the reduction of one run under the accumulation of the other."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().sonic_msm_lane_new(C.byref(self._h)))
+
+    def submit(self, srs: SRS, basis: int, e0: int, d_scalars, n: int) -> None:
+        """d_scalars: device pointer (int / c_void_p) to n canonical 32-byte Fr; must stay untouched until collect()"""
+        _lib.check(_lib.lib().sonic_msm_submit(self._h, srs._h, basis, e0, d_scalars, n))
+
+    def collect(self, partial: bool = False) -> bytes:
+        """the 96 canonical bytes of the sum, or (partial=True) the 192-byte un-normalised partial for a cross-rank sum"""
+        if partial:
+            out = C.create_string_buffer(192)
+            _lib.check(_lib.lib().sonic_msm_collect(self._h, None, out))
+        else:
+            out = C.create_string_buffer(96)
+            _lib.check(_lib.lib().sonic_msm_collect(self._h, out, None))
+        return out.raw
+
+    def close(self):
+        if self._h:
+            _lib.lib().sonic_msm_lane_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

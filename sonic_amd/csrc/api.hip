@@ -2,6 +2,7 @@
 // the SRS handle and the standalone MSM / NTT entry points.  prove lives in prove.hip.
 #include <stdarg.h>
 #include <string.h>
+#include <memory>
 #include "internal.hpp"
 #include "g2.hpp"
 
@@ -439,28 +440,93 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
   API_END
 }
 
+// ---- the same MSM in two halves, on a lane of its own (stream + bucket workspace + pinned result slot): submit queues scalar
+// check, sort, accumulation and reduction and returns; collect waits, finishes on the host.  Two lanes used in turn keep the
+// chip busy across consecutive MSMs: the sort and the (latency-bound) reduction of one run under the accumulation of the other.
+struct sonic_msm_lane {
+  hipStream_t st = nullptr;
+  MsmWorkspace ws;
+  DevBuf slot, err;
+  MsmSlot* h_slot = nullptr;
+  int* h_err = nullptr;
+  int Wb = 0;
+  bool in_flight = false;
+  std::mutex mu;
+  ~sonic_msm_lane() {
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (h_slot) (void)hipHostFree(h_slot);
+    if (h_err) (void)hipHostFree(h_err);
+  }
+};
+
+int sonic_msm_lane_new(sonic_msm_lane_t** out) {
+  API_BEGIN
+  if (!out) return SONIC_ERR_INVALID_ARG;
+  std::unique_ptr<sonic_msm_lane> l(new sonic_msm_lane());
+  HIP_OK(hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking));
+  l->slot.alloc(sizeof(MsmSlot));
+  l->err.alloc(4);
+  HIP_OK(hipHostMalloc((void**)&l->h_slot, sizeof(MsmSlot), hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&l->h_err, 4, hipHostMallocDefault));
+  *out = l.release();
+  API_END
+}
+void sonic_msm_lane_free(sonic_msm_lane_t* l) { delete l; }
+
+int sonic_msm_submit(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n) {
+  API_BEGIN
+  if (!l || !srs || n < 0 || (n > 0 && !d_scalars) || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
+  if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
+  std::lock_guard<std::mutex> g(l->mu);
+  if (l->in_flight) { set_error("sonic_msm_submit: the lane's previous MSM has not been collected"); return SONIC_ERR_INVALID_ARG; }
+  hipStream_t st = l->st;
+  const Fr* dsc = static_cast<const Fr*>(d_scalars);
+  HIP_OK(hipMemsetAsync(l->err.p, 0, 4, st));
+  fr_check_enqueue(st, dsc, n, l->err.as<int>());
+  const MsmPlan pl = srs_msm_plan(srs, n);
+  msm_enqueue(st, l->ws, pl, srs->basis(basis) + (e0 + srs->d), dsc, n, false, l->slot.as<MsmSlot>());
+  l->Wb = pl.Wb;
+  HIP_OK(hipMemcpyAsync(l->h_slot, l->slot.p, sizeof(int) * 4 + sizeof(G1XYZZ) * pl.Wb, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(l->h_err, l->err.p, 4, hipMemcpyDeviceToHost, st));
+  l->in_flight = true;
+  API_END
+}
+
+int sonic_msm_collect(sonic_msm_lane_t* l, uint8_t* out_g1, uint8_t* out_partial) {
+  API_BEGIN
+  if (!l) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(l->mu);
+  if (!l->in_flight) { set_error("sonic_msm_collect: nothing was submitted"); return SONIC_ERR_INVALID_ARG; }
+  l->in_flight = false;
+  HIP_OK(hipStreamSynchronize(l->st));
+  if (*l->h_err) { set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
+  G1XYZZ sum = msm_finish_host(*l->h_slot);
+  if (out_g1) g1_canonical_bytes_host(sum, out_g1);
+  if (out_partial) memcpy(out_partial, &sum, sizeof sum);
+  API_END
+}
+
+// the blocking entry points run on one shared lane (pinned result slot, one host synchronisation per call)
 static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, const uint8_t* h_scalars,
                           int64_t n, uint8_t* out96, uint8_t* out192) {
-  API_BEGIN
+  try { require_device(); } catch (const HipFail& f) { return f.code; }
   if (!srs || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
-  if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
   std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
-  DevBuf sc, err(4);
-  const Fr* dsc = static_cast<const Fr*>(d_scalars);
-  HIP_OK(hipMemsetAsync(err.p, 0, 4, st));
-  if (h_scalars && n > 0) {
-    sc.alloc(32 * n);
-    HIP_OK(hipMemcpyAsync(sc.p, h_scalars, 32 * n, hipMemcpyHostToDevice, st));
-    dsc = sc.as<Fr>();
-  }
-  fr_check_enqueue(st, dsc, n, err.as<int>());
-  int herr = 0;
-  HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipStreamSynchronize(st));
-  if (herr) { set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
-  msm_blocking(st, shared_msm_ws(), srs_msm_plan(srs, n), srs->basis(basis) + (e0 + srs->d), dsc, n, false, out96, out192);
-  API_END
+  static sonic_msm_lane_t* lane = nullptr;
+  if (!lane) { int rc = sonic_msm_lane_new(&lane); if (rc) return rc; }
+  DevBuf sc;
+  const void* dsc = d_scalars;
+  try {
+    if (h_scalars && n > 0) {
+      sc.alloc(32 * n);
+      HIP_OK(hipMemcpyAsync(sc.p, h_scalars, 32 * n, hipMemcpyHostToDevice, lane->st));
+      dsc = sc.p;
+    }
+  } catch (const HipFail& f) { return f.code; }
+  if (n > 0 && !dsc) return SONIC_ERR_INVALID_ARG;
+  int rc = sonic_msm_submit(lane, srs, basis, e0, dsc, n);
+  if (rc) return rc;
+  return sonic_msm_collect(lane, out96, out192);       // waits for the stream: `sc` may go out of scope afterwards
 }
 
 int sonic_msm_g1_srs(const sonic_srs_t* srs, int basis, int64_t e0, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]) {

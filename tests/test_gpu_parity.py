@@ -737,6 +737,61 @@ def test_open_poly_at_zero(sonic, ref, srs_pair):
     assert (fz, W) == ref.open_poly(s, 0, {0: 1, d + 1: 5})
 
 
+def test_msm_lanes_stream(sonic, orc, srs_pair):
+    """sonic_msm_submit / sonic_msm_collect: MSMs streamed over two lanes equal the blocking entry point and the oracle; a lane
+    holds one MSM at a time; non-canonical scalars surface at collect"""
+    from sonic_amd import _lib
+    from sonic_amd.commitment import msm_g1_srs
+    d, _, _, g, o = srs_pair
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    jobs = [(0, -700, 1400), (1, 1, 900), (0, -d, 2 * d + 1), (1, -50, 50), (0, 3, 1), (0, 0, 0)]
+    bufs = []
+    for basis, e0, n in jobs:
+        sc = rand_fr_array(rng, max(n, 1))[:n]
+        dp = C.c_void_p()
+        _lib.check(L.sonic_dev_alloc(32 * max(n, 1), C.byref(dp)))
+        if n:
+            _lib.check(L.sonic_dev_upload(dp, sc.ctypes.data, 32 * n))
+        bufs.append((sc, dp))
+    lanes = [sonic.MsmLane(), sonic.MsmLane()]
+    got = []
+    lanes[0].submit(g, *jobs[0][:2], bufs[0][1], jobs[0][2])
+    for i in range(len(jobs)):
+        if i + 1 < len(jobs):
+            lanes[(i + 1) & 1].submit(g, *jobs[i + 1][:2], bufs[i + 1][1], jobs[i + 1][2])
+        got.append(lanes[i & 1].collect())
+    for (basis, e0, n), (sc, dp), out in zip(jobs, bufs, got):
+        want = orc.msm_srs(o, basis, e0, sc, 1, NCPU) if n else bytes(96)
+        assert out == want == msm_g1_srs(g, basis, e0, sc)
+    # partial + sum_partials == the normalised result
+    lanes[0].submit(g, 0, -700, bufs[0][1], 1400)
+    part = np.frombuffer(lanes[0].collect(partial=True), np.uint8)
+    from sonic_amd import distributed as sd
+    assert sd.sum_partials(part, 1) == got[0]
+    with pytest.raises(sonic.SonicError) as e:
+        lanes[0].collect()
+    assert e.value.code == 7
+    lanes[0].submit(g, 0, -700, bufs[0][1], 1400)
+    with pytest.raises(sonic.SonicError) as e:
+        lanes[0].submit(g, 0, -700, bufs[0][1], 1400)
+    assert e.value.code == 7
+    assert lanes[0].collect() == got[0]
+    with pytest.raises(sonic.SonicError) as e:
+        lanes[0].submit(g, 0, d, bufs[0][1], 2)               # runs past gPositiveX
+    assert e.value.code == 2
+    bad = np.full((4, 32), 0xFF, np.uint8)
+    _lib.check(L.sonic_dev_upload(bufs[0][1], bad.ctypes.data, 128))
+    lanes[1].submit(g, 0, -700, bufs[0][1], 4)
+    with pytest.raises(sonic.SonicError) as e:
+        lanes[1].collect()
+    assert e.value.code == 3
+    for ln in lanes:
+        ln.close()
+    for _, dp in bufs:
+        L.sonic_dev_free(dp)
+
+
 def test_msm_zero_and_identity_scalars(sonic, orc, srs_pair):
     from sonic_amd.commitment import msm_g1_srs
     d, _, _, g, o = srs_pair

@@ -25,9 +25,9 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAI
   done
 } > $OUT/prove_sizes.txt
 {
-  echo "# python bench.py --no-cpu --msm-only --msm-log2 <k> (SRS d = 2^21: window tables c = 20, 13 windows, 2^19 shared buckets): ms per MSM, scalar-muls/s"
+  echo "# python bench.py --no-cpu --msm-only --msm-log2 <k> (SRS d = 2^21: window tables c = 20, 13 windows, 2^19 shared buckets): ms per MSM and scalar-muls/s, streamed over two lanes / one at a time"
   for lg in 16 18 20 22; do
-    python3 bench.py --no-cpu --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value']))"
+    python3 bench.py --no-cpu --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  streamed %.2f ms  %.3g /s   one at a time %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value'], d['msm']['sequential']['ms_per_msm'], d['msm']['sequential']['scalar_muls_per_s']))"
   done
 } > $OUT/msm_sizes.txt
 python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1
