@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel HIP-event totals to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pipelined-throughput leg (timelines of one solo proof)")
-    ap.add_argument("--msm-lanes", type=int, default=3, help="lanes the standalone MSMs are streamed over")
+    ap.add_argument("--msm-lanes", type=int, default=3, help="lanes the standalone MSMs are streamed over (0: skip the streamed leg, e.g. for rocprofv3 / PMC passes over the solo kernels)")
     ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
     args = ap.parse_args()
 
@@ -219,7 +219,7 @@ def main():
     # (2) the same K MSMs streamed over two lanes (sonic_msm_submit / sonic_msm_collect): MSM i + 1 is queued before MSM i is
     #     collected, so the sort and the latency-bound reduction of one run under the accumulation of the other; each MSM's
     #     partial still goes through the all-gather and the curve additions.  `msm.value` is this throughput.
-    NL = max(1, args.msm_lanes)
+    NL = max(0, args.msm_lanes)
     lanes = [sonic_amd.MsmLane() for _ in range(NL)]
 
     def msm_stream(count):
@@ -236,12 +236,15 @@ def main():
             res = sd.sum_partials(parts, world)
         return res
 
-    msm_stream(max(W, NL))
-    barrier()
-    t0 = time.perf_counter()
-    stream_result = msm_stream(K)
-    barrier()
-    dt = time.perf_counter() - t0
+    if NL > 0:
+        msm_stream(max(W, NL))
+        barrier()
+        t0 = time.perf_counter()
+        stream_result = msm_stream(K)
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        stream_result, dt = seq_result, dt_seq
     tmax = torch.tensor([dt, dt_seq], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -283,7 +286,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_by_design_per_launch": None,   # filled below: the window-table method reads one 96-B table point per (term, window)
-                "rocprof_summary": "profiles/r02_msm_only_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --msm-only --no-cpu "
+                "rocprof_summary": "profiles/r02_msm_only_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu "
                                    "--steps 5 --warmup 1: the same N = 2^20 launches and nothing else; profiles/r02_bench_kernel_stats.csv is the full "
                                    "default run, where the kernel also serves the batched groups of prove())",
                 "note": "modular-integer kernel: the binding roof is integer multiply issue, see int_roofline"}
@@ -367,7 +370,7 @@ def main():
                                 "the strictly sequential rate is in `sequential`"},
         "msm": {"metric": "G1 MSM scalar-muls/sec", "value": round(msm_per_s, 1), "unit": "scalar-muls/s", "N_per_gpu": msm_n,
                 "ms_per_msm": round(1e3 * dt_msm / K, 3),
-                "streaming": f"K MSMs streamed over {NL} lanes per GPU (submit / collect); one at a time in `sequential`",
+                "streaming": (f"K MSMs streamed over {NL} lanes per GPU (submit / collect); one at a time in `sequential`" if NL > 0 else "none (--msm-lanes 0): one MSM at a time"),
                 "sequential": {"scalar_muls_per_s": round(world * msm_n * K / dt_msm_seq, 1), "ms_per_msm": round(1e3 * dt_msm_seq / K, 3),
                                "kernel_ms_per_msm": round(kern_total / K, 3), "same_result_as_streamed": seq_result == stream_result}},
         "roofline": roofline,

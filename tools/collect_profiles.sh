@@ -8,12 +8,12 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/microbench > $OUT/microbench.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm_only -o t -- python3 bench.py --msm-only --no-cpu --steps 5 --warmup 1 > $OUT/msm_only.json 2> $OUT/msm_only.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm_only -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 5 --warmup 1 > $OUT/msm_only.json 2> $OUT/msm_only.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python3 bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o t -- python3 bench.py --msm-only --no-cpu --steps 3 --warmup 1 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_SQ -o t -- python3 bench.py --msm-only --no-cpu --steps 3 --warmup 1 > $OUT/pmc_SQ.json 2> $OUT/pmc_SQ.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_SQ -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1 > $OUT/pmc_SQ.json 2> $OUT/pmc_SQ.err
 {
   echo "# python bench.py --no-cpu --log2n <k> (10 streamed proofs after 2 warm-up, Q = 2, d = 8n): ms per proof streamed / strictly sequential"
   for lg in 10 13 14 16 17 18 19 20; do
@@ -25,7 +25,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAI
   done
 } > $OUT/prove_sizes.txt
 {
-  echo "# python bench.py --no-cpu --msm-only --msm-log2 <k> (SRS d = 2^21: window tables c = 20, 13 windows, 2^19 shared buckets): ms per MSM and scalar-muls/s, streamed over two lanes / one at a time"
+  echo "# python bench.py --no-cpu --msm-only --msm-log2 <k> (SRS d = 2^21: window tables c = 20, 13 windows, 2^19 shared buckets): ms per MSM and scalar-muls/s, streamed over three lanes / one at a time"
   for lg in 16 18 20 22; do
     python3 bench.py --no-cpu --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  streamed %.2f ms  %.3g /s   one at a time %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value'], d['msm']['sequential']['ms_per_msm'], d['msm']['sequential']['scalar_muls_per_s']))"
   done

@@ -25,7 +25,7 @@ def per_kernel(path, counter):
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     msm_n, c, W, sets = (int(x) for x in sys.argv[3:7])
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE) --output-format csv -- python3 bench.py --msm-only --no-cpu --steps 3 "
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE) --output-format csv -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 "
                       "--warmup 1  (one counter per pass; values = mean over the launches of the 3 timed MSMs)",
            "msm_n": msm_n, "plan": {"window_bits": c, "windows": W, "bucket_sets": sets},
            "method": "MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 128-B requests "
