@@ -346,7 +346,20 @@ def main():
         orc.msm_srs(osrs, 0, -(cmsm_n // 2) if 8 * cn >= cmsm_n // 2 else -8 * cn, csc[: min(cmsm_n, 16 * cn)], 1, cores)
         cmsm_dt = time.perf_counter() - t0
         cmsm_terms = min(cmsm_n, 16 * cn)
+        # the reference-shaped cost ("cpu-literal"): per-term double-and-add fold for the MSMs
+        # (CommitmentScheme.hs:26-29) and the schoolbook product for tPoly, one thread as the reference never forks; small n only
+        orc.set_mode(0, 1)
+        lit_n = 256
+        lsrs = orc.SRS(8 * lit_n, cx, ca, threads=cores)
+        lc = big_circuit(1, lit_n, Q, None)
+        t0 = time.perf_counter()
+        orc.prove(lsrs, lit_n, Q, lc["wL"], lc["wR"], lc["wO"], lc["cs"], lc["aL"], lc["aR"], lc["aO"], ctr, False)
+        lit_dt = time.perf_counter() - t0
+        orc.set_mode(1, cores)
         cpu_baseline = {"value": round(1.0 / cdt, 4), "unit": "proofs/s", "cores": cores, "kind": "port",
+                        "literal": {"n": lit_n, "s_per_proof": round(lit_dt, 2), "cores": 1,
+                                    "note": "the oracle with the reference's algorithms (fold of per-term double-and-add, schoolbook tPoly): "
+                                            "cost grows like n^2 in tPoly and 380 group operations per term in the MSMs"},
                         "sample": f"oracle/sonic_oracle.c (Pippenger + NTT, {cores} threads) prove() at n=2^{cpu_lg}, Q={Q}, d=8n; "
                                   f"{cdt:.2f}s per proof; cost is ~linear in n, so n=2^{args.log2n} would be ~{cdt * (n / cn):.0f}s per proof",
                         "msm_scalar_muls_per_s": round(cmsm_terms / cmsm_dt, 1), "msm_sample": f"N={cmsm_terms} Pippenger, {cores} threads"}
