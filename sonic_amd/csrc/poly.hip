@@ -18,13 +18,21 @@
 
 namespace sonic {
 
+// Elements per thread of k_scale_powers.  A thread pays ~45 products for its starting power x^(e0 + i) and x^256 and then 2 per
+// element, i.e. (45 + 2 PER) / PER products per element: 7.6 at PER = 8, 3.4 at 32.  These kernels touch ~77 n elements per proof
+// (two passes per opening), so at 8 they were ~5 % of a proof's instruction count -- which is what streamed proofs pay for.
+#ifndef SONIC_SCALE_PER
+#define SONIC_SCALE_PER 32
+#endif
+constexpr int SCALE_PER = SONIC_SCALE_PER;
+
 // out[i] = v(i) * x^(e0 + i); v(i) depends on mode:
 //   0: in[i]                     1: 1 (pure power table)
 //   2: quotient numerator: j = lo_q + i >= 0 ? F - P[i] : -P[i], with F = in[nF-1] (the last prefix)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_scale_powers(const Fr* __restrict__ in, Fr* __restrict__ out, long n, long e0,
                                                       const Fr* __restrict__ px, const Fr* __restrict__ pxinv, long lo_q, long nF) {
-  constexpr int PER = 8;                       // elements per thread, strided by the block size
+  constexpr int PER = SCALE_PER;                // elements per thread, strided by the block size
   const long base = (long)blockIdx.x * (256 * PER) + threadIdx.x;
   if (base >= n) return;
   const Fr x = *px, xinv = *pxinv;
@@ -48,15 +56,15 @@ __global__ __launch_bounds__(256) void k_scale_powers(const Fr* __restrict__ in,
 
 void poly_scale_powers_enqueue(hipStream_t st, const Fr* in, Fr* out, long n, long e0, const Fr* d_x, const Fr* d_xinv) {
   if (n <= 0) return;
-  if (in) LAUNCH(k_scale_powers<0>, ceil_div(n, 2048), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
-  else LAUNCH(k_scale_powers<1>, ceil_div(n, 2048), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
+  if (in) LAUNCH(k_scale_powers<0>, ceil_div(n, 256 * SCALE_PER), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
+  else LAUNCH(k_scale_powers<1>, ceil_div(n, 256 * SCALE_PER), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
 }
 
 // q[i] (exponent lo + i, i < n - 1) from the prefix sums P (n entries, exponents lo .. lo + n - 1)
 void poly_quotient_enqueue(hipStream_t st, const Fr* prefix, Fr* q, long n, long lo, const Fr* d_z, const Fr* d_zinv) {
   if (n <= 1) return;
   // z^{-1-j} = (z^-1)^{1+j}: base z^-1 (inverse base z), first exponent 1 + lo
-  LAUNCH(k_scale_powers<2>, ceil_div(n - 1, 2048), 256, 0, st, prefix, q, n - 1, 1 + lo, d_zinv, d_z, lo, n);
+  LAUNCH(k_scale_powers<2>, ceil_div(n - 1, 256 * SCALE_PER), 256, 0, st, prefix, q, n - 1, 1 + lo, d_zinv, d_z, lo, n);
 }
 
 // ---- inclusive prefix sums in Fr (tile = 1024) -----------------------------------------------
