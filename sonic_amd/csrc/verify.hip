@@ -10,6 +10,8 @@
 // |x| = 0xd201000000010000 on the curve untwisted into Fq12 = Fq[w]/(w^12 - 2 w^6 + 2), one shared final
 // exponentiation (q^12 - 1)/r per check.  Plain and slow (~0.5 s per pcV) on purpose: it is a checker.
 #include <string.h>
+#include <algorithm>
+#include <thread>
 #include <vector>
 #include "internal.hpp"
 #include "g2.hpp"
@@ -209,28 +211,67 @@ int fetch_g2(const sonic_srs* srs, int basis, int64_t e, G2Affine& out) {
   return SONIC_OK;
 }
 
-// pcV srs max F z (v, W)  (CommitmentScheme.hs:51-68)
-int pc_v(const sonic_srs* srs, const VerifierKey& vk, int64_t maxm, const G1Affine& F, const Fr& z_m, const Fr& v_m, const G1Affine& W, bool& ok) {
+// pcV srs max F z (v, W)  (CommitmentScheme.hs:51-68), in two steps: the G2 element h^{x^{-d+max}} comes from the SRS handle
+// (device memory, the library's call mutex), the pairing equation itself is pure host arithmetic -- so a verifier's checks
+// fetch their elements first and then run side by side on host threads (a proof with Q constraints has 4 + 3Q of them at
+// ~0.17 s each).
+int pc_v_element(const sonic_srs* srs, int64_t maxm, G2Affine& hxi) {
   const int64_t d = srs_d(srs);
   const int64_t difference = -d + maxm;                              // h^{x^{-d+max}}: hPositiveX / hNegativeX
   if (difference > d || difference < -d) { set_error("pcV: hPositiveX / hNegativeX is not long enough: %ld", (long)difference); return SONIC_ERR_SRS_INDEX; }
-  G2Affine hxi;
-  int rc = fetch_g2(srs, 0, difference, hxi);
-  if (rc) return rc;
+  return fetch_g2(srs, 0, difference, hxi);
+}
+bool pc_v_equation(const VerifierKey& vk, const G2Affine& hxi, const G1Affine& F, const Fr& z_m, const Fr& v_m, const G1Affine& W) {
   const Fr v = fp_from_mont(v_m), negz = fp_from_mont(fp_neg(z_m));
   G1Affine left = g1_to_affine(g1_add(g1_mul_fr(g1_gen_host(), v), g1_mul_fr(W, negz)));   // g^v W^{-z}
   G1Affine negF = g1_neg(F);
   F12 f = f12_mul(f12_mul(miller_loop(W, vk.h_alpha_x), miller_loop(left, vk.h_alpha)), miller_loop(negF, hxi));
-  ok = f12_eq(final_exp(f), f12_one());                              // eA <> eB == eC
+  return f12_eq(final_exp(f), f12_one());                            // eA <> eB == eC
+}
+int pc_v(const sonic_srs* srs, const VerifierKey& vk, int64_t maxm, const G1Affine& F, const Fr& z_m, const Fr& v_m, const G1Affine& W, bool& ok) {
+  G2Affine hxi;
+  int rc = pc_v_element(srs, maxm, hxi);
+  if (rc) return rc;
+  ok = pc_v_equation(vk, hxi, F, z_m, v_m, W);
+  return SONIC_OK;
+}
+
+struct PcvCheck { int64_t maxm; G1Affine F; Fr z, val; G1Affine W; };
+// all checks of a verifier: elements first (one per distinct max), equations on up to 16 host threads
+int run_checks(const sonic_srs* srs, const VerifierKey& vk, const std::vector<PcvCheck>& checks, bool& all) {
+  std::vector<int64_t> maxs;
+  std::vector<G2Affine> elems;
+  std::vector<int> which(checks.size());
+  for (size_t i = 0; i < checks.size(); i++) {
+    size_t k = 0;
+    while (k < maxs.size() && maxs[k] != checks[i].maxm) k++;
+    if (k == maxs.size()) {
+      G2Affine h;
+      int rc = pc_v_element(srs, checks[i].maxm, h);
+      if (rc) return rc;
+      maxs.push_back(checks[i].maxm); elems.push_back(h);
+    }
+    which[i] = (int)k;
+  }
+  std::vector<char> ok(checks.size(), 0);
+  const int nt = (int)std::min<size_t>(checks.size(), 16);
+  std::vector<std::thread> th;
+  for (int w = 0; w < nt; w++)
+    th.emplace_back([&, w] {
+      for (size_t i = w; i < checks.size(); i += nt)
+        ok[i] = pc_v_equation(vk, elems[which[i]], checks[i].F, checks[i].z, checks[i].val, checks[i].W) ? 1 : 0;
+    });
+  for (auto& t : th) t.join();
+  for (char c : ok) all = all && c;
   return SONIC_OK;
 }
 
 // hscVerify srs sXY yzs proof (Signature.hs:74-90) for the s(X,Y) of a circuit (Constraints.hs:34-53): s(u,v) on the host,
-// then 3m + 1 pcV checks.  `all` is and-ed with every check.
+// then its 3m + 1 pcV checks are appended to `checks` (run_checks evaluates them).
 int hsc_checks(const sonic_srs* srs, const VerifierKey& vk, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                int64_t m, const std::vector<Fr>& ys, const std::vector<Fr>& zs, const std::vector<G1Affine>& Sj, const std::vector<Fr>& sj,
                const std::vector<G1Affine>& Wj, const std::vector<Fr>& spj, const std::vector<G1Affine>& Wpj, const std::vector<G1Affine>& Qj,
-               const G1Affine& Qv, const G1Affine& C, const Fr& u, const Fr& v, bool& all) {
+               const G1Affine& Qv, const G1Affine& C, const Fr& u, const Fr& v, std::vector<PcvCheck>& checks) {
   // s(u, v): sum_i u^-i U_i(v) + u^i V_i(v) + u^{i+n} W_i(v)   (Signature.hs:81; Constraints.hs:34-53)
   if (u.is_zero() || v.is_zero()) { set_error("hscVerify: u or v is zero"); return SONIC_ERR_INEXACT_DIVISION; }
   std::vector<Fr> vq(Q);
@@ -249,20 +290,13 @@ int hsc_checks(const sonic_srs* srs, const VerifierKey& vk, int64_t n, int64_t Q
     sv = fp_add(sv, fp_add(fp_add(fp_mul(um, Ui), fp_mul(up, Vi)), fp_mul(fp_mul(up, un), Wi)));
   }
   const int64_t d = srs_d(srs);
-  int rc = SONIC_OK;
-  bool ok = false;
-  auto chk = [&](const G1Affine& Fc, const Fr& zz, const Fr& val, const G1Affine& W) {
-    if (rc) return;
-    rc = pc_v(srs, vk, d, Fc, zz, val, W, ok);
-    all = all && ok;
-  };
   for (int64_t j = 0; j < m; j++) {                                // Signature.hs:82-88
-    chk(Sj[j], zs[j], sj[j], Wj[j]);
-    chk(Sj[j], u, spj[j], Wpj[j]);
-    chk(C, ys[j], spj[j], Qj[j]);
+    checks.push_back(PcvCheck{d, Sj[j], zs[j], sj[j], Wj[j]});
+    checks.push_back(PcvCheck{d, Sj[j], u, spj[j], Wpj[j]});
+    checks.push_back(PcvCheck{d, C, ys[j], spj[j], Qj[j]});
   }
-  chk(C, v, sv, Qv);                                               // Signature.hs:89
-  return rc;
+  checks.push_back(PcvCheck{d, C, v, sv, Qv});                     // Signature.hs:89
+  return SONIC_OK;
 }
 
 }  // namespace
@@ -317,17 +351,14 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
     if (!rc) rc = fetch_g2(srs, 1, 1, vk.h_alpha_x);
     if (rc) return rc;
     const int64_t d = srs_d(srs);
-    bool all = true, ok = false;
-    auto chk = [&](int64_t maxm, const G1Affine& Fc, const Fr& zz, const Fr& val, const G1Affine& W) {
-      if (rc) return;
-      rc = pc_v(srs, vk, maxm, Fc, zz, val, W, ok);
-      all = all && ok;
-    };
-    rc = hsc_checks(srs, vk, n, Q, wL, wR, wO, Q, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, all);   // hscVerify, Signature.hs:74-90
+    std::vector<PcvCheck> checks;
+    rc = hsc_checks(srs, vk, n, Q, wL, wR, wO, Q, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, checks);   // hscVerify, Signature.hs:74-90
     if (rc) return rc;
-    chk(n, R, zm, a, Wa);                                          // Protocol.hs:123
-    chk(n, R, fp_mul(ym, zm), b, Wb);                              // :124
-    chk(d, T, zm, t, Wt);                                          // :125
+    checks.push_back(PcvCheck{n, R, zm, a, Wa});                   // Protocol.hs:123
+    checks.push_back(PcvCheck{n, R, fp_mul(ym, zm), b, Wb});       // :124
+    checks.push_back(PcvCheck{d, T, zm, t, Wt});                   // :125
+    bool all = true;
+    rc = run_checks(srs, vk, checks, all);
     if (rc) return rc;
     *accepted = all ? 1 : 0;
     return SONIC_OK;
@@ -358,7 +389,9 @@ int sonic_hsc_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
     if (!rc) rc = fetch_g2(srs, 1, 1, vk.h_alpha_x);
     if (rc) return rc;
     bool all = true;
-    rc = hsc_checks(srs, vk, n, Q, wL, wR, wO, m, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, all);
+    std::vector<PcvCheck> checks;
+    rc = hsc_checks(srs, vk, n, Q, wL, wR, wO, m, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, checks);
+    if (!rc) rc = run_checks(srs, vk, checks, all);
     if (rc) return rc;
     *accepted = all ? 1 : 0;
     return SONIC_OK;
