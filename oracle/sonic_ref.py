@@ -17,6 +17,8 @@ stack.yaml:5-14).  What pins this restatement instead:
     (test/Test/Protocol.hs:21), so every commitment F has a known discrete log and
     pcV's pairing equation e(W,h^{ax}) e(g^v W^{-z},h^a) = e(F,h^{x^{-d+max}})
     (src/Sonic/CommitmentScheme.hs:58-68) is equivalent to an identity in Fr.
+  * two public third-party known answers that need no hashing, EIP-2537's doubles of the G1 and G2
+    generators (tests/golden/eip2537_kat.json): generators and group laws are the public ones.
 
 Each function cites the reference lines it follows.  Polynomials are kept in the reference's own
 shape: a sparse Laurent polynomial is a dict {exponent: coeff != 0} (poly's normalised VLaurent),

@@ -28,6 +28,24 @@ def test_srs_new_matches_oracle(srs_pair):
     assert g.points(1, 0, 1).tobytes() == bytes(96)
 
 
+def test_public_known_answer_vectors_on_gpu(sonic):
+    """EIP-2537's 2 G1 and 2 G2 (tests/golden/eip2537_kat.json, public, independent of repository and reference) from the HIP
+    path: SRS.new with x = 2 puts them at gPositiveX[1] / hPositiveX[1]; the MSM entry point gives 2 G1 as 2 * G and G + G"""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eip2537_kat.json")))
+    g = (int(k["g1_generator"]["x"], 16), int(k["g1_generator"]["y"], 16))
+    g2x = (int(k["g1_generator_doubled"]["x"], 16), int(k["g1_generator_doubled"]["y"], 16))
+    h2 = k["g2_generator_doubled"]
+    h2x = ((int(h2["x_c0"], 16), int(h2["x_c1"], 16)), (int(h2["y_c0"], 16), int(h2["y_c1"], 16)))
+    s = sonic.SRS.new(8, 2, 3)
+    assert s.gPositiveX(0) == g and s.gPositiveX(1) == g2x
+    assert s.hPositiveX(1) == h2x
+    pts = np.frombuffer(sonic.g1_to_bytes(g) * 2, np.uint8).reshape(2, 96)
+    assert sonic.g1_from_bytes(sonic.msm_g1(pts[:1], [2])) == g2x
+    assert sonic.g1_from_bytes(sonic.msm_g1(pts, [1, 1])) == g2x
+
+
 def test_srs_index_maps(srs_pair, ref):
     """the four reference vectors as views (SRS.hs:33-39), against the literal python restatement"""
     d, x, alpha, g, _ = srs_pair

@@ -90,6 +90,21 @@ def test_c_oracle_matches_python_on_fresh_cases(orc, ref):
         assert got == ref.proof_to_bytes(proof)
 
 
+def test_public_known_answer_vectors(orc, ref):
+    """EIP-2537's doubles of the standard generators (tests/golden/eip2537_kat.json: public vectors, independent of this
+    repository and of the reference, which holds none): both oracles and the pairing oracle's G2 reproduce them"""
+    from oracle import pairing as pg
+    k = json.load(open(os.path.join(GOLD, "eip2537_kat.json")))
+    g = (int(k["g1_generator"]["x"], 16), int(k["g1_generator"]["y"], 16))
+    g2x = (int(k["g1_generator_doubled"]["x"], 16), int(k["g1_generator_doubled"]["y"], 16))
+    assert ref.G1_GEN == g and ref.g1_add(g, g) == g2x and ref.g1_mul(g, 2) == g2x
+    enc = lambda p: p[0].to_bytes(48, "little") + p[1].to_bytes(48, "little")
+    assert orc.g1_mul(enc(g), 2) == enc(g2x)
+    h2 = k["g2_generator_doubled"]
+    want = ((int(h2["x_c0"], 16), int(h2["x_c1"], 16)), (int(h2["y_c0"], 16), int(h2["y_c1"], 16)))
+    assert pg.g2_add(pg.G2_GEN, pg.G2_GEN) == want and pg.g2_mul(pg.G2_GEN, 2) == want
+
+
 # ---- the reference's properties, restated ----------------------------------------------------
 def test_prop_linear_constraints(ref):
     """test/Test/Constraints.hs:19-27"""
