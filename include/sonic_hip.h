@@ -114,7 +114,8 @@ int sonic_msm_g1_srs_dev(const sonic_srs_t* srs, int basis, int64_t e0, const vo
 /* one rank's share of a range-sharded MSM: the un-normalised partial sum */
 int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars,
                                  int64_t n, uint8_t out_partial[192]);
-/* the same MSM in two halves on a lane of its own (stream, bucket workspace, pinned result): submit queues it and returns,
+/* the same fold (CommitmentScheme.hs:26-29, 45-48 over an SRS slice, as sonic_msm_g1_srs_dev) in two halves on a lane of its
+ * own (stream, bucket workspace, pinned result): submit queues it and returns,
  * collect waits and finishes it (out_g1: 96 canonical bytes, out_partial: 192-byte un-normalised sum; either may be NULL).
  * One MSM in flight per lane; two lanes used in turn stream MSMs with the sort and the reduction of one under the
  * accumulation of the other.  d_scalars: canonical 32-byte Fr resident in HBM, untouched until collect. */
@@ -150,7 +151,7 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
  * S_j = commitPoly(s(X, y_j)) (Signature.hs:42) costs an n-term MSM instead of a 3n-term one.  Same proof bytes. */
 int sonic_prover_prepare(sonic_prover_t* p);
 int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_proof);
-/* the same in two halves: submit queues the whole proof on the handle's streams and returns without waiting for the GPU;
+/* prove (Protocol.hs:47-109) in two halves: submit queues the whole proof on the handle's streams and returns without waiting for the GPU;
  * collect waits for it, finishes it on the host and writes the bytes (prove = submit + collect).  One proof in flight per
  * handle.  A host thread that alternates between two handles -- submit(A, t0), submit(B, t1), collect(A), submit(A, t2),
  * collect(B), ... -- streams proofs with the next proof's start-up under the previous proof's tail (the reference's
