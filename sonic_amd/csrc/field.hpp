@@ -199,6 +199,52 @@ HD_NOINLINE Fp<P> fp_mul_generic(const Fp<P> a, const Fp<P> b) {
   return r;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// The same product for the host (the verifier's pairings, the tails of the MSMs): CIOS over N/2 64-bit limbs with 128-bit
+// intermediates, ~6x the speed of the 32-bit loop on a CPU.  Same representation (little-endian limbs), same R, result below p.
+template <class P>
+inline Fp<P> fp_mul_host64(const Fp<P>& a, const Fp<P>& b) {
+  constexpr int N = P::N, M = N / 2;
+  static_assert(N % 2 == 0, "even limb count");
+  typedef unsigned __int128 u128;
+  constexpr uint64_t p0 = (uint64_t)P::p(0) | ((uint64_t)P::p(1) << 32);
+  constexpr uint64_t x32 = (uint64_t)(uint32_t)(0u - P::INV);                 // p^-1 mod 2^32
+  constexpr uint64_t inv = 0 - x32 * (2 - p0 * x32);                          // -p^-1 mod 2^64 (one Newton step)
+  uint64_t A[M], B[M], Pm[M], t[M + 2];
+  for (int i = 0; i < M; i++) {
+    A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+    B[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+    Pm[i] = (uint64_t)P::p(2 * i) | ((uint64_t)P::p(2 * i + 1) << 32);
+  }
+  for (int i = 0; i < M + 2; i++) t[i] = 0;
+  for (int i = 0; i < M; i++) {
+    u128 c = 0;
+    for (int j = 0; j < M; j++) {
+      c += (u128)A[j] * B[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[M];
+    t[M] = (uint64_t)c;
+    t[M + 1] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * inv;
+    c = ((u128)m * Pm[0] + t[0]) >> 64;
+    for (int j = 1; j < M; j++) {
+      c += (u128)m * Pm[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[M];
+    t[M - 1] = (uint64_t)c;
+    t[M] = t[M + 1] + (uint64_t)(c >> 64);
+  }
+  Fp<P> r;
+  for (int i = 0; i < M; i++) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+  fp_reduce_once(r);
+  return r;
+}
+#endif
+
 }  // namespace sonic
 #include "mont_asm.hpp"   // device only: hand-scheduled gfx950 routines (tools/gen_mont_asm.py)
 namespace sonic {
@@ -210,8 +256,10 @@ HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SONIC_NO_ASM_MUL)
   if constexpr (P::N == FQ_LIMBS) return sonic_mont_mul_fq_call(a, b);
   else return sonic_mont_mul_fr_call(a, b);
-#else
+#elif defined(__HIP_DEVICE_COMPILE__)
   return fp_mul_generic(a, b);
+#else
+  return fp_mul_host64(a, b);
 #endif
 }
 
