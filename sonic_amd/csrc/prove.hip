@@ -29,6 +29,9 @@ enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
 // work-optimal end; the group that finishes last has nothing left to hide under and takes a short chain.  Measured
 // (ms per proof, batched / last): n = 2^18 (2^19 buckets): 16/8 45.9, 32/8 44.3, 64/8 43.2, 64/16 42.6, 64/32 43.7, 128/16 44.6;
 // n = 2^16 (2^16 buckets): 4/4 15.7, 8/4 15.1, 16/4 14.95, 16/8 15.1; n = 2^14: 4/4 7.2, 8/4 6.7, 16/4 6.6.
+// window tables of the per-circuit commitments C_q (sonic_prover_prepare): 29 windows of 9 / 8 bits over 256 shared buckets
+constexpr int CQ_TAB_W = 29, CQ_TAB_C = 9;
+constexpr long CQ_TAB_MAX_Q = 1L << 16;
 static int PROVE_SEGMENT = getenv("SONIC_PROVE_SEGMENT") ? atoi(getenv("SONIC_PROVE_SEGMENT")) : 0;
 static int PROVE_SEGMENT_LAST = getenv("SONIC_PROVE_SEGMENT_LAST") ? atoi(getenv("SONIC_PROVE_SEGMENT_LAST")) : 0;
 static int prove_segment(const MsmPlan& pl, int k, bool last) {
@@ -179,6 +182,9 @@ struct sonic_prover {
   std::chrono::steady_clock::time_point t_begin, t_enq;
   bool prepared = false;
   DevBuf cq;
+  // window tables of the C_q (CQ_TAB_W x Q points, table w = 2^shift(w) C_q): their Q-term MSM then shares one bucket set and
+  // leaves ONE window sum like every other MSM of a proof, instead of 64 that the host folds with 255 doublings (126 us each)
+  DevBuf cq_tab;
   std::vector<DevBuf> diag, yq;
   hipEvent_t ev_r1 = nullptr, ev_sy0 = nullptr, ev_t = nullptr, ev_su = nullptr;
   std::vector<hipEvent_t> ev_syj;
@@ -454,7 +460,8 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     open(syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                          // W'_j          :54
     flush_group();
     if (p->prepared)                                                                  // sum_q y_j^{n+q} C_q, Q-term MSM
-      msm_enqueue(cur->st, cur->ws, msm_plan(Q), p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
+      msm_enqueue(cur->st, cur->ws, p->cq_tab.p ? msm_plan_tables(Q, CQ_TAB_C, CQ_TAB_W, Q) : msm_plan(Q),
+                  p->cq_tab.p ? p->cq_tab.as<G1Affine>() : p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
   }
   begin_group(p->ev_su);
   commit(su, u_lo, u_len, d, 6 + 4 * Q);                                             // C             :52
@@ -504,20 +511,27 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
   if (hflags) return flags_to_status(hflags, "prove");
   std::vector<uint8_t> pts(96 * (size_t)K);
   {
-    // host tails (Horner over <= 64 window sums + one inversion each), one task per MSM
+    // host tails: with window tables a slot holds ONE window sum and there is nothing to fold; without them the Horner walks
+    // over <= 64 window sums (255 doublings each) run on threads.  One shared inversion normalises all results.
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> th;
-    const int nt = K < 16 ? K : 16;
-    for (int w = 0; w < nt; w++)
-      th.emplace_back([&, w] {
-        for (int i = w; i < K; i += nt) {
-          G1XYZZ s = msm_finish_host(hs[i]);
-          const int j = (i - 5) / 2;
-          if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) s = g1_add(s, msm_finish_host(hs[K + j]));
-          g1_canonical_bytes_host(s, &pts[96 * (size_t)i]);
-        }
-      });
-    for (auto& x : th) x.join();
+    std::vector<G1XYZZ> sums((size_t)K);
+    auto tail = [&](int i) {
+      G1XYZZ s = msm_finish_host(hs[i]);
+      const int j = (i - 5) / 2;
+      if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) s = g1_add(s, msm_finish_host(hs[K + j]));
+      sums[i] = s;
+    };
+    bool folded = true;
+    for (int i = 0; i < K; i++) folded = folded && hs[i].W == 1;
+    if (folded) {
+      for (int i = 0; i < K; i++) tail(i);
+    } else {
+      std::vector<std::thread> th;
+      const int nt = K < 16 ? K : 16;
+      for (int w = 0; w < nt; w++) th.emplace_back([&, w] { for (int i = w; i < K; i += nt) tail(i); });
+      for (auto& x : th) x.join();
+    }
+    g1_canonical_bytes_host_batch(sums.data(), K, pts.data());
     if (timing) fprintf(stderr, "[sonic] host tails of %d MSMs: %.3f ms\n", K, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   auto G = [&](long i) { return &pts[96 * (size_t)i]; };
@@ -610,6 +624,28 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   }
   p->cq.alloc(sizeof(G1Affine) * Q);
   HIP_OK(hipMemcpy(p->cq.p, cq.data(), sizeof(G1Affine) * Q, hipMemcpyHostToDevice));
+  if (Q <= CQ_TAB_MAX_Q) {
+    // tab[w * Q + q] = 2^shift(w) C_q: 255 doublings per C_q, once per circuit, on the host
+    std::vector<G1XYZZ> tx((size_t)CQ_TAB_W * Q);
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<long>(Q, 16);
+    for (int t = 0; t < nt; t++)
+      th.emplace_back([&, t] {
+        for (long q = t; q < Q; q += nt) {
+          G1XYZZ a = G1XYZZ::from_affine(cq[q]);
+          tx[q] = a;
+          for (int w = 1; w < CQ_TAB_W; w++) {
+            for (int k = 0; k < msm_even_width(CQ_TAB_W, w - 1); k++) a = g1_dbl(a);
+            tx[(size_t)w * Q + q] = a;
+          }
+        }
+      });
+    for (auto& x : th) x.join();
+    std::vector<G1Affine> tab(tx.size());
+    g1_batch_affine_host(tx.data(), (long)tx.size(), tab.data());
+    p->cq_tab.alloc(sizeof(G1Affine) * tab.size());
+    HIP_OK(hipMemcpy(p->cq_tab.p, tab.data(), sizeof(G1Affine) * tab.size(), hipMemcpyHostToDevice));
+  }
   p->diag.resize(Q); p->yq.resize(Q);
   for (auto& b : p->diag) b.alloc(sizeof(Fr) * n);
   for (auto& b : p->yq) b.alloc(sizeof(Fr) * Q);
@@ -698,11 +734,18 @@ int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, con
   if (hflags) return flags_to_status(hflags, "hscProve");
   std::vector<uint8_t> pts(96 * (size_t)K);
   {
-    std::vector<std::thread> th;
-    const int nt = (int)std::min<long>(K, 16);
-    for (int w = 0; w < nt; w++)
-      th.emplace_back([&, w] { for (long i = w; i < K; i += nt) g1_canonical_bytes_host(msm_finish_host(hs[i]), &pts[96 * (size_t)i]); });
-    for (auto& x : th) x.join();
+    std::vector<G1XYZZ> sums((size_t)K);
+    bool folded = true;
+    for (long i = 0; i < K; i++) folded = folded && hs[i].W == 1;
+    if (folded) {
+      for (long i = 0; i < K; i++) sums[i] = msm_finish_host(hs[i]);
+    } else {
+      std::vector<std::thread> th;
+      const int nt = (int)std::min<long>(K, 16);
+      for (int w = 0; w < nt; w++) th.emplace_back([&, w] { for (long i = w; i < K; i += nt) sums[i] = msm_finish_host(hs[i]); });
+      for (auto& x : th) x.join();
+    }
+    g1_canonical_bytes_host_batch(sums.data(), (int)K, pts.data());
   }
   uint8_t* o = out;
   auto putG = [&](long i) { memcpy(o, &pts[96 * (size_t)i], 96); o += 96; };
