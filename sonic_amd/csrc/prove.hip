@@ -126,13 +126,6 @@ static MsmJob open_job_at_zero(hipStream_t st, const sonic_srs* srs, const Fr* p
   return MsmJob{srs_basis(srs, 0) + d, poly + 1, i1, slot};
 }
 
-// IN = [y, z, y*z, u, v, y_1..y_Q, z_1..z_Q] from the transcript S = [c1..c4, y, z, ys, zs, u, v]
-__global__ void k_prep_scalars(const Fr* __restrict__ S, long Q, Fr* __restrict__ IN) {
-  long t = threadIdx.x + (long)blockIdx.x * blockDim.x;
-  if (t == 0) { IN[0] = S[4]; IN[1] = S[5]; IN[2] = fp_mul(S[4], S[5]); IN[3] = S[6 + 2 * Q]; IN[4] = S[7 + 2 * Q]; }
-  if (t < 2 * Q) IN[5 + t] = S[6 + t];
-}
-
 static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
 }  // namespace sonic
@@ -163,11 +156,12 @@ struct sonic_prover {
   Lane lanes[N_LANES];
   int next_lane = 0;
   NttTables ntt;
-  DevBuf S, IN, PAIRS, r1, sy0, su, pw, kpow, fa, fb, slots, frout, flags, tmp;
+  DevBuf S, PAIRS, r1, sy0, su, pw, kpow, fa, fb, slots, frout, flags, tmp;
   std::vector<DevBuf> syj;
   // sonic_prover_prepare: Commit(P_q) per constraint row (affine, Montgomery) and per-j scalar buffers
   // pinned host staging (fixed addresses: the whole enqueue of a proof can be captured once and replayed as a hipGraph)
   uint8_t* h_tr = nullptr;
+  Fr* h_pairs = nullptr;         // {v, v^-1} of the evaluation points, computed on the host (prove_enqueue)
   MsmSlot* h_slots = nullptr;
   uint8_t* h_fr = nullptr;
   int* h_flags = nullptr;
@@ -211,7 +205,7 @@ struct sonic_prover {
     if (st) (void)hipStreamDestroy(st);
     if (ts) (void)hipStreamDestroy(ts);
     if (graph) (void)hipGraphExecDestroy(graph);
-    for (void* h : {(void*)h_tr, (void*)h_slots, (void*)h_fr, (void*)h_flags}) if (h) (void)hipHostFree(h);
+    for (void* h : {(void*)h_tr, (void*)h_pairs, (void*)h_slots, (void*)h_fr, (void*)h_flags}) if (h) (void)hipHostFree(h);
   }
 };
 
@@ -298,10 +292,11 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   p->su.alloc(sizeof(Fr) * (2 * n + Q + 1));
   p->pw.alloc(sizeof(Fr) * (3 * n + Q + 2));
   p->kpow.alloc(sizeof(Fr) * Q);
-  p->S.alloc(sizeof(Fr) * (8 + 2 * Q)); p->IN.alloc(sizeof(Fr) * (5 + 2 * Q)); p->PAIRS.alloc(sizeof(Fr) * 2 * (5 + 2 * Q));
+  p->S.alloc(sizeof(Fr) * (8 + 2 * Q)); p->PAIRS.alloc(sizeof(Fr) * 2 * (5 + 2 * Q));
   p->slots.alloc(sizeof(MsmSlot) * (7 + 5 * Q));
   p->use_graph = getenv("SONIC_PROVE_GRAPH") && atoi(getenv("SONIC_PROVE_GRAPH")) != 0;
   HIP_OK(hipHostMalloc((void**)&p->h_tr, 32 * (8 + 2 * Q), hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&p->h_pairs, sizeof(Fr) * 2 * (5 + 2 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_slots, sizeof(MsmSlot) * (7 + 5 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_fr, 32 * (3 + 2 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_flags, 4, hipHostMallocDefault));
@@ -354,6 +349,25 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     if (bytes_are_zero(transcript + 32 * k, 32)) { set_error("prove: transcript element %ld is zero: Laurent evaluation at 0 divides by zero", k); return SONIC_ERR_INEXACT_DIVISION; }
   int* flags = p->flags.as<int>();
   memcpy(p->h_tr, transcript, 32 * (8 + 2 * Q));
+  {
+    // {v, v^-1} for v = y, z, yz, u, v, y_1..y_Q, z_1..z_Q (Montgomery form), on the host with one shared inversion: the same
+    // values cost a proof 0.35 ms of single-thread Fermat inversions on the device before its first polynomial could be built.
+    // A non-canonical element is flagged by the device's conversion of the transcript below; its pair here is then irrelevant.
+    const long np = 5 + 2 * Q;
+    std::vector<Fr> v((size_t)np), pre((size_t)np);
+    auto tr = [&](long k) { Fr a; memcpy(a.l, transcript + 32 * k, 32); return fp_to_mont(a); };
+    v[0] = tr(4); v[1] = tr(5); v[2] = fp_mul(v[0], v[1]); v[3] = tr(6 + 2 * Q); v[4] = tr(7 + 2 * Q);
+    for (long t = 0; t < 2 * Q; t++) v[5 + t] = tr(6 + t);
+    Fr acc = Fr::one();
+    for (long i = 0; i < np; i++) { pre[i] = acc; acc = fp_mul(acc, v[i].is_zero() ? Fr::one() : v[i]); }
+    Fr inv = fp_inv(acc);
+    for (long i = np - 1; i >= 0; i--) {
+      p->h_pairs[2 * i] = v[i];
+      if (v[i].is_zero()) { p->h_pairs[2 * i + 1] = v[i]; continue; }
+      p->h_pairs[2 * i + 1] = fp_mul(inv, pre[i]);
+      inv = fp_mul(inv, v[i]);
+    }
+  }
   const int K = (int)(7 + 4 * Q);
   const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
@@ -371,10 +385,8 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   Fr* S = p->S.as<Fr>();
   HIP_OK(hipMemcpyAsync(S, p->h_tr, 32 * (8 + 2 * Q), hipMemcpyHostToDevice, st));
   fr_to_mont_enqueue(st, S, 8 + 2 * Q, flags);
-  Fr* IN = p->IN.as<Fr>();
   Fr* PR = p->PAIRS.as<Fr>();
-  LAUNCH(k_prep_scalars, ceil_div(2 * Q + 1, 64), 64, 0, st, (const Fr*)S, Q, IN);
-  fr_with_inverse_enqueue(st, IN, (int)(5 + 2 * Q), PR);
+  HIP_OK(hipMemcpyAsync(PR, p->h_pairs, sizeof(Fr) * 2 * (5 + 2 * Q), hipMemcpyHostToDevice, st));
   const Fr *pY = PR + 0, *pZ = PR + 2, *pYZ = PR + 4, *pU = PR + 6, *pV = PR + 8;
   auto pYj = [&](long j) { return PR + 2 * (5 + j); };
   auto pZj = [&](long j) { return PR + 2 * (5 + Q + j); };
