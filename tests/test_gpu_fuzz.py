@@ -73,3 +73,44 @@ def test_prove_fuzz(sonic, orc, ref, seed):
         p.set_assignment(sonic.Assignment(*asg))
         assert p.prove_bytes(tr) == want, (seed, n, Q, d)
         assert p.prove_bytes(tr) == want          # deterministic on repeat
+
+
+@pytest.mark.parametrize("seed", range(2 * FUZZ_ROUNDS))
+def test_verify_fuzz(sonic, ref, seed):
+    """verify . prove == True on random circuits (test/Test/Protocol.hs:14-23), and every single element of the proof matters:
+    each of its 7 + 4Q points replaced by another point of the proof (a valid element of the subgroup) and each of its 5 + 2Q
+    scalars moved by one is rejected -- the 4 + 3Q pairing checks and the scalar identities of verify / hscVerify
+    (Protocol.hs:111-130, Signature.hs:74-90) through the tower-field pairing of csrc/pairing.hpp"""
+    pyr = random.Random(5000 + seed)
+    n = pyr.randint(1, 24)
+    Q = pyr.randint(1, min(n, 3))
+    d = {1: 12, 2: 16}.get(n, 7 * n) + pyr.randint(0, n)
+    circ, asg = ref.rnd_circuit(pyr, n, Q)
+    g = sonic.SRS.new(d, pyr.randrange(1, R), pyr.randrange(1, R))
+    circuit = sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3])
+    proof, ro = sonic.prove(g, sonic.Assignment(*asg), circuit, rng=pyr)
+    args = (ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs)
+    assert sonic.verify(g, circuit, proof, *args)
+    raw = proof.to_bytes()
+    kinds = list("GGFGFGGF") + list("GFG") * Q + list("FGG") * Q + list("GGFF")
+    offs, o = [], 0
+    for k in kinds:
+        offs.append(o)
+        o += 96 if k == "G" else 32
+    assert o == len(raw)
+    gslots = [i for i, k in enumerate(kinds) if k == "G"]
+    for i, k in enumerate(kinds):
+        b = bytearray(raw)
+        if k == "G":
+            j = gslots[(gslots.index(i) + 1) % len(gslots)]
+            if raw[offs[j]:offs[j] + 96] == raw[offs[i]:offs[i] + 96]:
+                continue
+            b[offs[i]:offs[i] + 96] = raw[offs[j]:offs[j] + 96]
+        else:
+            v = (int.from_bytes(raw[offs[i]:offs[i] + 32], "little") + 1) % R
+            b[offs[i]:offs[i] + 32] = v.to_bytes(32, "little")
+        try:
+            ok = sonic.verify(g, circuit, sonic.Proof.from_bytes(bytes(b), Q), *args)
+        except sonic.SonicError:
+            ok = False                                  # e.g. u or v moved onto 0
+        assert not ok, (seed, n, Q, i, k)
