@@ -2,6 +2,7 @@
 #pragma once
 #include "common.hpp"
 #include "g1.hpp"
+#include "g1_host.hpp"
 
 namespace sonic {
 
@@ -64,12 +65,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
 
 // Host tail: Horner over the slot's window sums -> un-normalised XYZZ sum.
 G1XYZZ msm_finish_host(const MsmSlot& s);
-// canonical 96-byte encoding (one Fq inversion), on the host
-void g1_canonical_bytes_host(const G1XYZZ& p, uint8_t* out96);
-void g1_batch_affine_host(const G1XYZZ* p, long n, G1Affine* out);
-// n points -> n x 96 bytes with one shared inversion
-void g1_canonical_bytes_host_batch(const G1XYZZ* p, int n, uint8_t* out);
-
+// canonical 96-byte encodings on the host: g1_host.hpp
 int msm_window_override();
 void msm_set_window_override(int c);
 

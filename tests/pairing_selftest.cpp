@@ -1,5 +1,6 @@
 // Host self-test of the verifier's pairing (sonic_amd/csrc/pairing.hpp), built with g++ by tests/test_pairing_host.py:
 //   * the host's 64-bit-limb Montgomery product (field.hpp, fp_mul_host64) against the portable 32-bit loop, Fq and Fr;
+//   * the host inversion and the shared-inversion normalisations of G1 results (g1_host.hpp) against the one-at-a-time ones;
 //   * the tower arithmetic against itself (inverse, squaring vs product, sparse line product vs full product, Frobenius^12 = id,
 //     Frobenius = q-th power on a random element);
 //   * value: final_exponentiation(miller_loop(P, Q)) == plain pairing(P, Q)^3 for random multiples P = a G1, Q = b G2
@@ -12,6 +13,7 @@
 #include <stdlib.h>
 #include <chrono>
 #include "pairing.hpp"
+#include "g1_host.hpp"
 #include "pairing_plain.hpp"
 
 using namespace sonic;
@@ -90,6 +92,35 @@ int main() {
       const Fr c = rnd_fr(), d = rnd_fr();
       CHECK(fp_mul_host64(c, d) == fp_mul_generic(c, d), "Fr: 64-bit-limb product == 32-bit-limb product");
     }
+  }
+  // ---- host inversion (binary Euclid, field.hpp) and the shared-inversion normalisations of g1_host.hpp ----
+  {
+    for (int it = 0; it < 200; it++) {
+      const Fq a = rnd_fq();
+      CHECK(fp_mul(a, fp_inv(a)) == Fq::one(), "Fq: a * a^-1 == 1");
+      Fr b; for (int i = 0; i < 8; i++) b.l[i] = (uint32_t)rnd64(); b.l[7] &= 0x3fffffffu; b = fp_to_mont(b);
+      CHECK(b.is_zero() || fp_mul(b, fp_inv(b)) == Fr::one(), "Fr: a * a^-1 == 1");
+    }
+    CHECK(fp_inv(Fq::zero()).is_zero() && fp_inv(Fq::one()) == Fq::one(), "0^-1 := 0, 1^-1 == 1");
+    std::vector<G1XYZZ> pts;
+    G1XYZZ a = g1_dbl_affine(g1_gen());
+    for (int i = 0; i < 19; i++) {
+      a = g1_add_mixed(g1_dbl(a), g1_gen());
+      pts.push_back(i % 7 == 3 ? G1XYZZ::inf() : a);
+    }
+    pts.push_back(G1XYZZ::from_affine(g1_gen()));
+    std::vector<uint8_t> one(96 * pts.size()), all(96 * pts.size());
+    std::vector<G1Affine> aff(pts.size());
+    for (size_t i = 0; i < pts.size(); i++) g1_canonical_bytes_host(pts[i], &one[96 * i]);
+    g1_canonical_bytes_host_batch(pts.data(), (int)pts.size(), all.data());
+    CHECK(one == all, "canonical bytes: shared inversion == one inversion per point (with points at infinity)");
+    g1_batch_affine_host(pts.data(), (long)pts.size(), aff.data());
+    for (size_t i = 0; i < pts.size(); i++) {
+      const G1Affine w = g1_to_affine(pts[i]);
+      CHECK(aff[i].x == w.x && aff[i].y == w.y, "batch affine == g1_to_affine");
+    }
+    std::vector<uint8_t> none(1);
+    g1_canonical_bytes_host_batch(pts.data(), 0, none.data());       // empty batch: nothing written, no inversion of an empty product gone wrong
   }
   // ---- tower arithmetic ----
   for (int it = 0; it < 4; it++) {
