@@ -114,3 +114,55 @@ def test_verify_fuzz(sonic, ref, seed):
         except sonic.SonicError:
             ok = False                                  # e.g. u or v moved onto 0
         assert not ok, (seed, n, Q, i, k)
+
+
+def _random_d(pyr, n):
+    """randomD (test/Test/Reference.hs:101-104)"""
+    return pyr.randint(12, 100) if n == 1 else pyr.randint(16, 200) if n == 2 else pyr.randint(7 * n, 100 * n)
+
+
+@pytest.mark.parametrize("seed", range(5 * FUZZ_ROUNDS))
+def test_commitment_scheme_properties(sonic, ref, seed):
+    """The three properties of test/Test/CommitmentScheme.hs on the reference's own generators (rndCircuit n <= 20, randomD,
+    randomParams), with commitPoly / openPoly on the GPU and pcV through the product's pairing:
+      :25-53  pcV srs d (commitPoly srs d t(X,y)) z (openPoly srs z t(X,y))
+      :58-71  pcV srs n (commitPoly srs n r(X,1)) z (openPoly srs z r(X,1))
+      :76-96  the same for the blinded r(X,1) + sum c_{n+i} X^{-2n-i}, opened at yz
+    each also rejected for a moved evaluation.  (5 x SONIC_FUZZ_ROUNDS cases; the reference runs 25 / 50 / 50.)"""
+    pyr = random.Random(9000 + seed)
+    n = pyr.randint(1, 20)
+    Q = pyr.randint(1, n)
+    d = _random_d(pyr, n)
+    x, y, z, alpha = (pyr.randrange(1, R) for _ in range(4))
+    circ, asg = ref.rnd_circuit(pyr, n, Q)
+    g = sonic.SRS.new(d, x, alpha)
+    rXY = ref.r_poly(*asg)
+    tXy = ref.eval_y(y, ref.t_poly(rXY, ref.s_poly(*circ[:3]), ref.k_poly(circ[3], n)))
+    rX1 = ref.eval_y(1, rXY)
+    blinded = ref.lp_add(rX1, {-2 * n - i: pyr.randrange(1, R) for i in range(1, 5)})
+    for maxm, poly, pt in ((d, tXy, z), (n, rX1, z), (n, blinded, y * z % R)):
+        F = sonic.commit_poly(g, maxm, poly)
+        op = sonic.open_poly(g, pt, poly)
+        assert op[0] == ref.lp_eval(poly, pt)
+        assert sonic.pc_v(g, maxm, F, pt, op), (seed, n, Q, d, maxm)
+        assert not sonic.pc_v(g, maxm, F, pt, ((op[0] + 1) % R, op[1]))
+        assert not sonic.pc_v(g, maxm, F, (pt + 1) % R, op)
+
+
+@pytest.mark.parametrize("seed", range(4 * FUZZ_ROUNDS))
+def test_reference_acceptance_properties(sonic, ref, seed):
+    """test/Test/Signature.hs:20-36 (hscVerify . hscProve, 20 cases in the reference) and test/Test/Protocol.hs:14-23
+    (verify . prove, 50 cases) on the reference's generators -- rndCircuit (n <= 20, m <= n), randomD, randomParams -- with the
+    prover on the GPU and the verifier's pairings on the host.  4 x SONIC_FUZZ_ROUNDS cases of each."""
+    pyr = random.Random(12000 + seed)
+    n = pyr.randint(1, 20)
+    m = pyr.randint(1, n)
+    d = _random_d(pyr, n)
+    circ, asg = ref.rnd_circuit(pyr, n, m)
+    g = sonic.SRS.new(d, pyr.randrange(1, R), pyr.randrange(1, R))
+    circuit = sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3])
+    yzs = [(pyr.randrange(1, R), pyr.randrange(1, R)) for _ in range(m)]
+    hp = sonic.hsc_prove(g, circuit, yzs, rng=pyr)
+    assert sonic.hsc_verify(g, circuit, yzs, hp), (seed, n, m, d)
+    proof, ro = sonic.prove(g, sonic.Assignment(*asg), circuit, rng=pyr)
+    assert sonic.verify(g, circuit, proof, ro.rndOracleY, ro.rndOracleZ, ro.rndOracleYZs), (seed, n, m, d)
