@@ -15,17 +15,23 @@ Workload (BASELINE.json configs[2], "n=2^18, d=2^20"): the reference rejects d <
 (src/Sonic/Protocol.hs:54-55), so prove() runs at the stated n = 2^18 with d = 8n = 2^21 and the
 standalone MSM runs at exactly N = d = 2^20 terms (run A).  Q = 2.
 
-N > 1: one process per GPU.  prove() shards by proof (each rank proves its own proofs on a replicated
-SRS: no data-path collective); the standalone MSM is range-sharded (each rank one 2^20-term slice of
-an N*2^20-term MSM) and the 192-byte partial sums are all-gathered over RCCL, then added on every rank.
-Weak scaling in both cases.
+N > 1: one process per GPU, SRS replicated.
+  * prove() shards by proof (each rank proves its own proofs: no data-path collective)            -> `value`, weak scaling
+  * `msm`: each rank one 2^20-term slice of an N*2^20-term MSM, 192-byte partials all-gathered    -> weak scaling
+  * `msm_strong`: ONE fixed 2^22-term MSM (BASELINE.json configs[3]) split over the N ranks: term ranges for the
+    accumulation, then an all-to-all of bucket ranges so that each rank reduces 1/N of the buckets, then the 192-byte
+    gather                                                                                          -> strong scaling
+All collectives run over RCCL on device tensors (sonic_amd/distributed.py); a process group of ONE rank (launched under
+torch.distributed.run with N = 1) still executes them.
 
+Every number of the roofline objects can be recomputed from the files they name under profiles/.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -37,21 +43,48 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per pro
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Integer roof of the bucket accumulation (tools/microbench.hip on one MI355X, profiles/r02_microbench.txt):
-MAD_PEAK_PER_S = 2.8e13        #   v_mad_u64_u32 issue rate, all CUs, independent chains
-MADD_ALU_ONLY_PER_S = 6.51e9   #   the same fused mixed addition in a register-only loop (no memory access): what the instruction mix sustains
-# static ISA count of one bucket-walk iteration (tools/count_accum_instrs.py): 816 instructions around six calls of the 624-instruction
-# product core, two of the 532-instruction squaring core and one of the 924-instruction two-product core
-ACCUM_INSTR_PER_ADD = 6548
-ACCUM_MADS_PER_ADD = 2608
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_msm.json")   # FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc)
+ROUND = "r03"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def load_profile_json(name):
+    """the newest profiles/rNN_<name> (this round's if it has been collected, else the previous round's), with its path"""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{name}")))
+    if not cands:
+        return None, None
+    try:
+        return json.load(open(cands[-1])), os.path.relpath(cands[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def rocprof_avg_ms(kernel):
+    """average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --msm-only --msm-lanes 0`"""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_msm_only_kernel_stats.csv")))
+    if not cands:
+        return None, None
+    import csv
+    for r in csv.DictReader(open(cands[-1])):
+        if kernel in r.get("Name", ""):
+            return float(r["AverageNs"]) / 1e6, os.path.relpath(cands[-1], ROOT)
+    return None, os.path.relpath(cands[-1], ROOT)
+
+
+def effective_cores():
+    """host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def main():
@@ -62,11 +95,15 @@ def main():
     ap.add_argument("--log2n", type=int, default=18, help="mult. gates n = 2^log2n (default: BASELINE configs[2])")
     ap.add_argument("--Q", type=int, default=2)
     ap.add_argument("--msm-log2", type=int, default=20)
-    ap.add_argument("--cpu-log2n", type=int, default=0, help="n of the bounded CPU-baseline sample (0: sized from a probe at n=2^11 "
-                                                              "so that one CPU proof takes <= ~5 s, at most n=2^15)")
+    ap.add_argument("--msm-strong-log2", type=int, default=22, help="terms of the ONE MSM that is split over all ranks (BASELINE configs[3]); capped by the SRS")
+    ap.add_argument("--msm-strong", action="store_true", help="only the strong-scaling MSM leg")
+    ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) time one rank's share of the strong-scaling MSM as if there were this many "
+                                                                "ranks: 1/E of the terms, a device copy in place of the all-to-all, 1/E of the buckets")
+    ap.add_argument("--cpu-log2n", type=int, default=0, help="n of the CPU-baseline proof (0: the bench's own n if a probe says it fits --cpu-budget-s, else the largest that does)")
+    ap.add_argument("--cpu-budget-s", type=float, default=75.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel HIP-event totals to stderr")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pipelined-throughput leg (timelines of one solo proof)")
     ap.add_argument("--msm-lanes", type=int, default=3, help="lanes the standalone MSMs are streamed over (0: skip the streamed leg, e.g. for rocprofv3 / PMC passes over the solo kernels)")
     ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
@@ -75,6 +112,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # under torch.distributed.run: a process group even for N = 1
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
 
@@ -83,30 +121,40 @@ def main():
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_nccl = args.backend == "nccl"
-    if world > 1:
+    if launched:
         if use_nccl:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=args.backend)
-    coll_dev = torch.device("cuda", dev_index) if use_nccl else torch.device("cpu")
+    pg = launched
+    coll_dev = device if use_nccl else torch.device("cpu")
 
     import sonic_amd
-    from sonic_amd import _lib
-    from util import big_circuit, rand_fr_array, R
+    from sonic_amd import _lib, distributed as sd
+    from sonic_amd.workload import big_circuit, rand_fr_array
     L = _lib.lib()
     _lib.check(L.sonic_init(dev_index))
 
     n, Q = 1 << args.log2n, args.Q
     d = 8 * n
     msm_n = min(1 << args.msm_log2, 2 * d)          # the standalone MSM reads its points from this SRS (2d+1 per basis)
+    strong_n = min(1 << args.msm_strong_log2, 2 * d)
     K, W = args.steps, args.warmup
+    only_strong = args.msm_strong
 
     def barrier():
-        if world > 1:
+        if pg:
             dist.barrier()
         torch.cuda.synchronize()
         L.sonic_device_sync()
+
+    def max_over_ranks(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=coll_dev)
+        if pg:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
 
     # ---------------- setup (untimed): SRS on the GPU, circuit resident in HBM ----------------
     t0 = time.time()
@@ -115,11 +163,14 @@ def main():
     alpha = int.from_bytes(rand_fr_array(seed_rng, 1)[0].tobytes(), "little") | 1
     srs = sonic_amd.SRS.new(d, x, alpha)
     t_srs = time.time() - t0
-    prover = None
-    if not args.msm_only:       # --msm-only launches nothing but the stand-alone MSMs (so that a rocprofv3 summary of it is about them)
-        circ = big_circuit(1000 + rank, n, Q, None)
-        prover = sonic_amd.Prover(srs, sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
-        prover.set_assignment(sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"]))
+    pipe = circ = None
+    do_prove = not (args.msm_only or only_strong)
+    depth = 1 if (args.kernel_table or args.no_pipeline) else 2
+    if do_prove:       # --msm-only launches nothing but the stand-alone MSMs (so that a rocprofv3 summary of it is about them)
+        circ = big_circuit(1000 + rank, n, Q)
+        circuit = sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"])
+        pipe = sonic_amd.ProverPipeline(srs, circuit, depth=depth)
+        pipe.set_assignment(sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"]))
     tr_rng = np.random.default_rng(77 + rank)
     transcripts = [rand_fr_array(tr_rng, 8 + 2 * Q) for _ in range(K + W)]
     for t in transcripts:
@@ -132,35 +183,21 @@ def main():
     # that proof i + 1 is already running while proof i is waited for and finished on the host -- nothing is synchronised between
     # steps, everything is complete at the closing barrier.  The strictly sequential number (every prove() call finished before
     # the next begins: the latency of one proof) is measured right after and reported beside it as "sequential".
-    if args.msm_only:
-        K_prove, W_prove = 0, 0
-    else:
-        K_prove, W_prove = K, W
     proof = b""
-    dt_prove, proofs_per_s, sequential, pipe = 1.0, 0.0, None, None
-    if prover is not None:
-        depth = 1 if (args.kernel_table or args.no_pipeline) else 2
-        pipe = sonic_amd.ProverPipeline.__new__(sonic_amd.ProverPipeline)
-        pipe.provers = [prover]
-        for _ in range(depth - 1):
-            px = sonic_amd.Prover(srs, sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
-            px.set_assignment(sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"]))
-            pipe.provers.append(px)
-        pipe.prove_all(transcripts[:max(W_prove, depth)])           # warm-up (also grows every handle's workspaces)
+    dt_prove, proofs_per_s, sequential = 1.0, 0.0, None
+    if do_prove:
+        pipe.prove_all(transcripts[:max(W, depth)])           # warm-up (also grows every handle's workspaces)
         barrier()
         L.sonic_profile_reset()
         L.sonic_profile_enable(1 if args.kernel_table else 0)
         t0 = time.perf_counter()
-        outs = pipe.prove_all(transcripts[W:W + K_prove])
+        outs = pipe.prove_all(transcripts[W:W + K])
         barrier()
         dt = time.perf_counter() - t0
         L.sonic_profile_enable(0)
         proof = outs[-1] if outs else b""
-        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_prove = float(tmax.item())
-        proofs_per_s = world * K_prove / dt_prove
+        dt_prove = max_over_ranks([dt])[0]
+        proofs_per_s = world * K / dt_prove
         if args.kernel_table and rank == 0:
             names = C.create_string_buffer(8192)
             L.sonic_profile_names(names, 8192)
@@ -174,195 +211,313 @@ def main():
                 log(f"  {nm:28s} {ms:10.2f} ms {cnt:7d} launches {100 * ms / tot:5.1f}%")
             log(f"  kernels total {tot:.1f} ms of {dt * 1e3:.1f} ms wall ({K} proofs)")
         # strictly sequential (rank 0): the same K proofs, one finished prove() call after the other, on one handle
-        if rank == 0 and K_prove >= 1 and depth > 1:
+        if rank == 0 and K >= 1 and depth > 1:
             L.sonic_device_sync()
             t0 = time.perf_counter()
-            for i in range(K_prove):
-                seq_proof = prover.prove_bytes(transcripts[W + i])
+            for i in range(K):
+                seq_proof = pipe.provers[0].prove_bytes(transcripts[W + i])
             L.sonic_device_sync()
             dts = time.perf_counter() - t0
-            sequential = {"proofs_per_s_per_gpu": round(K_prove / dts, 4), "ms_per_proof": round(1e3 * dts / K_prove, 2),
+            sequential = {"proofs_per_s_per_gpu": round(K / dts, 4), "ms_per_proof": round(1e3 * dts / K, 2),
                           "same_bytes_as_streamed": seq_proof == proof}
         for px in pipe.provers[1:]:
             px.close()
     barrier()
 
+    # ---------------- NTT product alone on the chip (rank 0; roofline_ntt) ----------------
+    ntt = None
+    if do_prove and rank == 0:
+        na, nb = 3 * n + 5, 4 * n + 5                       # r(X,1) and r(X,y) + s(X,y): the shapes of tPoly's product (7n + 9 coefficients)
+        lgM = (na + nb - 2).bit_length()
+        M = 1 << lgM
+        pa, pb = rand_fr_array(np.random.default_rng(5), na), rand_fr_array(np.random.default_rng(6), nb)
+        da, db, do = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        for ptr, sz in ((da, 32 * na), (db, 32 * nb), (do, 32 * (na + nb - 1))):
+            _lib.check(L.sonic_dev_alloc(sz, C.byref(ptr)))
+        _lib.check(L.sonic_dev_upload(da, pa.ctypes.data, 32 * na))
+        _lib.check(L.sonic_dev_upload(db, pb.ctypes.data, 32 * nb))
+        for _ in range(2):
+            _lib.check(L.sonic_poly_mul_fr_dev(da, na, db, nb, do))
+        L.sonic_profile_reset()
+        L.sonic_profile_enable(1)
+        reps = 5
+        for _ in range(reps):
+            _lib.check(L.sonic_poly_mul_fr_dev(da, na, db, nb, do))
+        L.sonic_profile_enable(0)
+        per = {}
+        for nm in ("k_ntt_stage2", "k_ntt_stage", "k_ntt_local", "k_fr_pointwise_mul"):
+            ms, cnt = C.c_double(), C.c_int64()
+            L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
+            per[nm] = {"ms_per_product": round(ms.value / reps, 4), "launches_per_product": cnt.value // reps}
+        t_ms = sum(v["ms_per_product"] for v in per.values())
+        passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_stage2", "k_ntt_stage", "k_ntt_local")) // 3
+        alg = 288.0 * M
+        ntt = {"bound": "hbm", "kernel": "three radix-2 transforms of size M + the pointwise product (k_ntt_stage2 / k_ntt_stage / k_ntt_local / k_fr_pointwise_mul)",
+               "M": M, "achieved": round(alg / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_product": round(t_ms, 4),
+               "algorithmic_bytes": alg, "algorithmic_bytes_rule": "288 M: each transform reads and writes M x 32 B once (3 x 64 M) + 96 M for the pointwise product (SURVEY 8d lower bound)",
+               "hbm_passes_per_transform": passes, "bytes_by_design": float((3 * passes * 64 + 96) * M),
+               "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products"}
+        for ptr in (da, db, do):
+            L.sonic_dev_free(ptr)
+
     # ---------------- timed: standalone G1 MSM, N = 2^20 per GPU, scalars resident in HBM ----------------
-    sc = rand_fr_array(np.random.default_rng(500 + rank), msm_n)
+    sc = rand_fr_array(np.random.default_rng(500), max(msm_n, strong_n))       # the same scalars on every rank (the strong leg splits them)
     dsc = C.c_void_p()
-    _lib.check(L.sonic_dev_alloc(32 * msm_n, C.byref(dsc)))
-    _lib.check(L.sonic_dev_upload(dsc, sc.ctypes.data, 32 * msm_n))
-    from sonic_amd import distributed as sd
-    basis, e0 = sd.msm_shard(rank, world, d, msm_n)
-    part = np.zeros(sd.PARTIAL_BYTES, np.uint8)
-    msm_result = [b""]
+    _lib.check(L.sonic_dev_alloc(32 * sc.shape[0], C.byref(dsc)))
+    _lib.check(L.sonic_dev_upload(dsc, sc.ctypes.data, 32 * sc.shape[0]))
+    msm = roofline = int_roofline = None
+    accum_ms, kern_total = 0.0, 0.0
+    if not only_strong:
+        basis, e0 = sd.msm_shard(rank, world, d, msm_n)
+        # (1) one MSM after the other, every launch bracketed by HIP events: the dominant kernel's duration for the roofline
+        #     (alone on the chip, as in the rocprofv3 summary of --msm-only) and the latency of one MSM.  The partial stays on
+        #     the device, the all-gather runs over RCCL on the lane's stream, one device-to-host copy brings the gathered partials.
+        one = sd.ShardedMsm(srs, rank, world, device)
+        for _ in range(W):
+            one.run_terms(basis, e0, dsc, msm_n)
+        barrier()
+        L.sonic_profile_reset()
+        L.sonic_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            seq_result = one.run_terms(basis, e0, dsc, msm_n)
+        barrier()
+        dt_seq = time.perf_counter() - t0
+        L.sonic_profile_enable(0)
+        one.close()
+        # (2) the same K MSMs streamed over NL lanes: MSM i + 1 is queued before MSM i is collected, so the sort and the
+        #     latency-bound reduction of one run under the accumulation of the other; each MSM's partial still goes through the
+        #     all-gather and the curve additions.  `msm.value` is this throughput.
+        NL = max(0, args.msm_lanes)
+        lanes = [sonic_amd.MsmLane() for _ in range(NL)]
 
-    def msm_step():
-        _lib.check(L.sonic_msm_g1_srs_partial_dev(srs._h, basis, e0, dsc, msm_n, part.ctypes.data))
-        parts = sd.allgather_partials(part, world, device=coll_dev if use_nccl else None)       # RCCL all-gather of 192 B
-        msm_result[0] = sd.sum_partials(parts, world)                                            # k-1 curve additions
-
-    # (1) one MSM after the other, every launch bracketed by HIP events: the dominant kernel's duration for the roofline
-    #     (alone on the chip, as in the rocprofv3 summary of --msm-only) and the latency of one MSM
-    for _ in range(W):
-        msm_step()
-    barrier()
-    L.sonic_profile_reset()
-    L.sonic_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(K):
-        msm_step()
-    barrier()
-    dt_seq = time.perf_counter() - t0
-    L.sonic_profile_enable(0)
-    seq_result = msm_result[0]
-    # (2) the same K MSMs streamed over two lanes (sonic_msm_submit / sonic_msm_collect): MSM i + 1 is queued before MSM i is
-    #     collected, so the sort and the latency-bound reduction of one run under the accumulation of the other; each MSM's
-    #     partial still goes through the all-gather and the curve additions.  `msm.value` is this throughput.
-    NL = max(0, args.msm_lanes)
-    lanes = [sonic_amd.MsmLane() for _ in range(NL)]
-
-    def msm_stream(count):
-        res = b""
-        if count <= 0:
+        def msm_stream(count):
+            res = b""
+            if count <= 0:
+                return res
+            for j in range(min(NL - 1, count)):
+                lanes[j % NL].submit(srs, basis, e0, dsc, msm_n)
+            for i in range(count):
+                if i + NL - 1 < count:
+                    lanes[(i + NL - 1) % NL].submit(srs, basis, e0, dsc, msm_n)
+                mine = np.frombuffer(lanes[i % NL].collect(partial=True), np.uint8)
+                parts = sd.allgather_partials(mine, world, device=coll_dev if use_nccl else None)
+                res = sd.sum_partials(parts, world)
             return res
-        for j in range(min(NL - 1, count)):
-            lanes[j % NL].submit(srs, basis, e0, dsc, msm_n)
-        for i in range(count):
-            if i + NL - 1 < count:
-                lanes[(i + NL - 1) % NL].submit(srs, basis, e0, dsc, msm_n)
-            mine = np.frombuffer(lanes[i % NL].collect(partial=True), np.uint8)
-            parts = sd.allgather_partials(mine, world, device=coll_dev if use_nccl else None)
-            res = sd.sum_partials(parts, world)
-        return res
 
-    if NL > 0:
-        msm_stream(max(W, NL))
+        if NL > 0:
+            msm_stream(max(W, NL))
+            barrier()
+            t0 = time.perf_counter()
+            stream_result = msm_stream(K)
+            barrier()
+            dt = time.perf_counter() - t0
+        else:
+            stream_result, dt = seq_result, dt_seq
+        dt_msm, dt_msm_seq = max_over_ranks([dt, dt_seq])
+        msm_per_s = world * msm_n * K / dt_msm
+        for ln in lanes:
+            ln.close()
+        ms, cnt = C.c_double(), C.c_int64()
+        L.sonic_profile_get(b"k_bucket_accum", C.byref(ms), C.byref(cnt))
+        accum_ms = ms.value / max(1, cnt.value)
+        names = C.create_string_buffer(8192)
+        L.sonic_profile_names(names, 8192)
+        per_kernel = {}
+        for nm in names.value.decode().split():
+            m2, c2 = C.c_double(), C.c_int64()
+            L.sonic_profile_get(nm.encode(), C.byref(m2), C.byref(c2))
+            kern_total += m2.value
+            per_kernel[nm] = round(m2.value / max(1, K), 4)
+            if args.kernel_table and rank == 0:
+                log(f"  [msm] {nm:24s} {m2.value / max(1, c2.value):9.3f} ms/launch x{c2.value}")
+        msm = {"metric": "G1 MSM scalar-muls/sec", "value": round(msm_per_s, 1), "unit": "scalar-muls/s", "N_per_gpu": msm_n, "scaling": "weak",
+               "ms_per_msm": round(1e3 * dt_msm / K, 3),
+               "streaming": (f"K MSMs streamed over {NL} lanes per GPU (submit / collect); one at a time in `sequential`" if NL > 0 else "none (--msm-lanes 0): one MSM at a time"),
+               "sequential": {"scalar_muls_per_s": round(world * msm_n * K / dt_msm_seq, 1), "ms_per_msm": round(1e3 * dt_msm_seq / K, 3),
+                              "kernel_ms_per_msm": round(kern_total / K, 3), "kernel_ms": per_kernel, "same_result_as_streamed": seq_result == stream_result}}
+
+    # ---------------- timed: ONE 2^22-term MSM split over all ranks (strong scaling; BASELINE configs[3]) ----------------
+    msm_strong = None
+    if not args.msm_only:
+        sh = sd.ShardedMsm(srs, rank, world, device)
+        lo, hi = sd.split_range(strong_n, world, rank)
+        dmine = C.c_void_p(dsc.value + 32 * lo)
+        e_lo = -d + lo
+        try:
+            sd.exchange_layout(srs, world)
+            exchange = world > 1
+        except _lib.SonicError:            # an SRS without window tables (SONIC_MSM_TABLES=0, or d too large for them): term ranges only
+            exchange = False
+        if exchange:
+            run = lambda: sh.run_buckets(0, e_lo, dmine, hi - lo)             # noqa: E731
+        elif world > 1:
+            run = lambda: sh.run_terms(0, e_lo, dmine, hi - lo)               # noqa: E731
+        else:
+            run = lambda: sh.run_terms(0, -d, dsc, strong_n)                  # noqa: E731  (one rank: the plain MSM is the baseline of the curve)
+        for _ in range(max(1, W)):
+            res_strong = run()
+        check = sh.run_terms(0, e_lo, dmine, hi - lo)                          # the same sum by term-range partials (every rank its slice)
         barrier()
         t0 = time.perf_counter()
-        stream_result = msm_stream(K)
+        for _ in range(K):
+            res_strong = run()
         barrier()
-        dt = time.perf_counter() - t0
-    else:
-        stream_result, dt = seq_result, dt_seq
-    tmax = torch.tensor([dt, dt_seq], dtype=torch.float64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_msm, dt_msm_seq = float(tmax[0].item()), float(tmax[1].item())
-    msm_per_s = world * msm_n * K / dt_msm
-    for ln in lanes:
-        ln.close()
-    ms, cnt = C.c_double(), C.c_int64()
-    L.sonic_profile_get(b"k_bucket_accum", C.byref(ms), C.byref(cnt))
-    accum_ms = ms.value / max(1, cnt.value)
-    kern_total = 0.0
-    names = C.create_string_buffer(8192)
-    L.sonic_profile_names(names, 8192)
-    for nm in names.value.decode().split():
-        m2, c2 = C.c_double(), C.c_int64()
-        L.sonic_profile_get(nm.encode(), C.byref(m2), C.byref(c2))
-        kern_total += m2.value
-        if args.kernel_table and rank == 0:
-            log(f"  [msm] {nm:24s} {m2.value / max(1, c2.value):9.3f} ms/launch x{c2.value}")
+        dt_strong = max_over_ranks([time.perf_counter() - t0])[0]
+        msm_strong = {"metric": "one G1 MSM split over all ranks", "N_total": strong_n, "scaling": "strong", "n_gpus": world,
+                      "ms_per_msm": round(1e3 * dt_strong / K, 3), "value": round(strong_n * K / dt_strong, 1), "unit": "scalar-muls/s",
+                      "method": ("term ranges accumulated per rank, all-to-all of bucket ranges (RCCL), 1/N of the buckets reduced per rank, 192-B all-gather"
+                                 if exchange else ("term ranges, 192-B all-gather (no window tables on this SRS)" if world > 1 else
+                                                   "single rank: the plain MSM (baseline of the strong-scaling curve)")),
+                      "same_result_as_term_range_sharding": res_strong == check}
+        if args.emulate_world > 1 and world == 1:
+            E = args.emulate_world
+            lo_e, hi_e = sd.split_range(strong_n, E, 0)
+            for _ in range(max(1, W)):
+                sh.run_buckets_emulated(0, -d, dsc, hi_e - lo_e, E)
+            L.sonic_device_sync()
+            L.sonic_profile_reset()
+            L.sonic_profile_enable(1)
+            t0 = time.perf_counter()
+            for _ in range(K):
+                sh.run_buckets_emulated(0, -d, dsc, hi_e - lo_e, E)
+            L.sonic_device_sync()
+            dte = time.perf_counter() - t0
+            L.sonic_profile_enable(0)
+            names = C.create_string_buffer(8192)
+            L.sonic_profile_names(names, 8192)
+            perk = {}
+            for nm in names.value.decode().split():
+                m2, c2 = C.c_double(), C.c_int64()
+                L.sonic_profile_get(nm.encode(), C.byref(m2), C.byref(c2))
+                perk[nm] = round(m2.value / K, 4)
+            msm_strong["emulated_share"] = {"world": E, "terms": hi_e - lo_e, "ms_per_share": round(1e3 * dte / K, 3), "kernel_ms": perk,
+                                            "speedup_vs_single": round((dt_strong / K) / (dte / K), 2),
+                                            "note": "UNMEASURED ON MULTI-GPU HARDWARE: one GPU doing one rank's work, device copy instead of the xGMI all-to-all"}
+        sh.close()
     L.sonic_dev_free(dsc)
 
     if rank != 0:
-        if world > 1:
+        if pg:
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel (k_bucket_accum of the N = 2^20 MSM): algorithmic bytes = 128 B per
-    # scalar-mul (96 B affine point + 32 B scalar) x the terms one launch covers
-    alg_bytes = 128.0 * msm_n
-    achieved = alg_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
-    traffic, traffic_src = None, None
-    try:   # HBM bytes per launch from the separate PMC passes (same command with --msm-only), if taken for this size
-        pmc = json.load(open(PMC_FILE))
-        if pmc.get("msm_n") == msm_n:
-            traffic, traffic_src = pmc["k_bucket_accum"]["hbm_bytes_per_launch"], "profiles/r02_pmc_msm.json"
-    except Exception:
-        pass
-    roofline = {"bound": "hbm", "kernel": "k_bucket_accum", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_by_design_per_launch": None,   # filled below: the window-table method reads one 96-B table point per (term, window)
-                "rocprof_summary": "profiles/r02_msm_only_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu "
-                                   "--steps 5 --warmup 1: the same N = 2^20 launches and nothing else; profiles/r02_bench_kernel_stats.csv is the full "
-                                   "default run, where the kernel also serves the batched groups of prove())",
-                "note": "modular-integer kernel: the binding roof is integer multiply issue, see int_roofline"}
-    # integer roof of the same kernel.  Additions = entries - buckets (the first entry of a bucket is a copy); every addition is
-    # ACCUM_MADS_PER_ADD v_mad_u64_u32 (the multiplier: ~2.3x the issue cost of a plain 32-bit VALU instruction on this chip) inside
-    # ACCUM_INSTR_PER_ADD instructions.  Two fractions: of the chip's MAD issue rate, and of the rate the whole instruction mix
-    # sustains in a register-only loop (what is left is memory latency and the launch tail).
-    pc, pw_, pb = C.c_int(), C.c_int(), C.c_int()
-    L.sonic_msm_plan(srs._h, msm_n, C.byref(pc), C.byref(pw_), C.byref(pb))
-    roofline["bytes_by_design_per_launch"] = float((4 + 96) * pw_.value * msm_n) if pb.value == 1 else None   # 4-B sorted entry + 96-B table point per (term, window)
-    n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value
-    adds_per_s = n_adds / (accum_ms * 1e-3) if accum_ms > 0 else 0.0
-    int_roofline = {"bound": "v_mad_u64_u32", "achieved": round(adds_per_s * ACCUM_MADS_PER_ADD / 1e12, 3),
-                    "peak": MAD_PEAK_PER_S / 1e12, "unit": "TMAD/s", "frac": round(adds_per_s * ACCUM_MADS_PER_ADD / MAD_PEAK_PER_S, 4),
-                    "plan": {"window_bits": pc.value, "windows": pw_.value, "bucket_sets": pb.value},
-                    "mixed_additions_per_launch": n_adds, "instr_per_mixed_add": ACCUM_INSTR_PER_ADD, "mads_per_mixed_add": ACCUM_MADS_PER_ADD,
-                    "alu_only": {"adds_per_s_register_loop": MADD_ALU_ONLY_PER_S, "kernel_adds_per_s": round(adds_per_s, 1),
-                                 "frac": round(adds_per_s / MADD_ALU_ONLY_PER_S, 4),
-                                 "source": "tools/microbench g1_add_mixed_walk (profiles/r02_microbench.txt)"},
-                    "pmc": "profiles/r02_pmc_SQ_counter_collection.csv: SQ_INSTS_VALU per launch against n_adds x instr_per_mixed_add / 64"}
+    if msm is not None:
+        # roofline of the dominant kernel (k_bucket_accum of the N = 2^20 MSM): algorithmic bytes = 128 B per
+        # scalar-mul (96 B affine point + 32 B scalar) x the terms one launch covers
+        alg_bytes = 128.0 * msm_n
+        achieved = alg_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+        pmc, pmc_src = load_profile_json("pmc_msm.json")
+        traffic = pmc["k_bucket_accum"]["hbm_bytes_per_launch"] if pmc and pmc.get("msm_n") == msm_n and "k_bucket_accum" in pmc else None
+        rp_ms, rp_src = rocprof_avg_ms("k_bucket_accum")
+        roofline = {"bound": "hbm", "kernel": "k_bucket_accum", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_uses": "avg_launch_ms (live HIP events of THIS run)",
+                    "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
+                    "avg_launch_ms": round(accum_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                    "rocprof": {"avg_launch_ms": None if rp_ms is None else round(rp_ms, 4), "summary": rp_src,
+                                "frac": None if not rp_ms else round(alg_bytes / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                "note": "rocprofv3 --kernel-trace --stats of `bench.py --msm-only --msm-lanes 0 --no-cpu --steps 5 --warmup 1` on another box of the pool "
+                                        "(same launches, nothing else); run-to-run and box-to-box spread of this kernel is a few per cent"},
+                    "note": "modular-integer kernel: the binding roof is integer multiply issue, see int_roofline"}
+        # integer roof of the same kernel: additions x MADs per addition against the chip's v_mad_u64_u32 issue rate; counts and
+        # rates are read from profiles/rNN_kernel_model.json (tools/kernel_model.py: static ISA count of the compiled kernel +
+        # the on-hardware microbenchmarks), not constants in this file.
+        pc, pw_, pb = C.c_int(), C.c_int(), C.c_int()
+        L.sonic_msm_plan(srs._h, msm_n, C.byref(pc), C.byref(pw_), C.byref(pb))
+        roofline["bytes_by_design_per_launch"] = float((4 + 96) * pw_.value * msm_n) if pb.value == 1 else None   # 4-B sorted entry + 96-B table point per (term, window)
+        model, model_src = load_profile_json("kernel_model.json")
+        n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value
+        adds_per_s = n_adds / (accum_ms * 1e-3) if accum_ms > 0 else 0.0
+        if model:
+            mads, instr = model["mads_per_addition"], model["instr_per_addition"]
+            int_roofline = {"bound": "v_mad_u64_u32", "achieved": round(adds_per_s * mads / 1e12, 3), "peak": model["mad_peak_per_s"] / 1e12, "unit": "TMAD/s",
+                            "frac": round(adds_per_s * mads / model["mad_peak_per_s"], 4),
+                            "plan": {"window_bits": pc.value, "windows": pw_.value, "bucket_sets": pb.value},
+                            "additions_per_launch": n_adds, "instr_per_addition": instr, "mads_per_addition": mads,
+                            "alu_only": {"adds_per_s_register_loop": model.get("addition_register_loop_per_s"), "kernel_adds_per_s": round(adds_per_s, 1),
+                                         "frac": round(adds_per_s / model["addition_register_loop_per_s"], 4) if model.get("addition_register_loop_per_s") else None},
+                            "model": model_src}
+        else:
+            int_roofline = {"note": "profiles/rNN_kernel_model.json missing (tools/kernel_model.py)", "additions_per_launch": n_adds, "kernel_adds_per_s": round(adds_per_s, 1)}
+
+    # whole prove(): SURVEY 8d's algorithmic bytes against the time of one streamed proof
+    roofline_prove = None
+    if do_prove:
+        lgM = (7 * n + 8).bit_length()
+        scalar_muls = 27 * n + 28 + 2 * Q + Q * (11 * n + Q)
+        alg_p = 128.0 * scalar_muls + 288.0 * (1 << lgM)
+        roofline_prove = {"bound": "hbm", "algorithmic_bytes_per_proof": alg_p, "scalar_muls_per_proof": scalar_muls, "ntt_size": 1 << lgM,
+                          "rule": "128 B x (27n + 28 + 2Q + Q(11n + Q)) + 288 M (SURVEY 8d)", "achieved": round(alg_p * proofs_per_s / world / 1e9, 2),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_p * proofs_per_s / world / 1e9 / HBM_PEAK_GBS, 5),
+                          "scalar_muls_per_s_inside_prove": round(scalar_muls * proofs_per_s, 1)}
 
     cpu_baseline = None
-    if not args.no_cpu:
+    if not args.no_cpu and do_prove:
         from oracle import orc    # the CPU oracle is only ever the baseline leg here, never part of the GPU path
-        cores = os.cpu_count() or 1
+        cores = effective_cores()
         cr = np.random.default_rng(3)
-        cx = int.from_bytes(rand_fr_array(cr, 1)[0].tobytes(), "little") | 1
-        ca = int.from_bytes(rand_fr_array(cr, 1)[0].tobytes(), "little") | 1
-        ctr = rand_fr_array(cr, 8 + 2 * Q)
-        ctr[:, 0] |= 1
         orc.set_mode(1, cores)
 
-        def cpu_prove_time(lg, budget_s, max_reps):
+        def cpu_prove_time(lg, osrs_, cc, tr_):
             m = 1 << lg
-            osrs_ = orc.SRS(8 * m, cx, ca, threads=cores)
-            cc = big_circuit(1, m, Q, None)
             t0_ = time.perf_counter()
-            reps_ = 0
-            while True:
-                orc.prove(osrs_, m, Q, cc["wL"], cc["wR"], cc["wO"], cc["cs"], cc["aL"], cc["aR"], cc["aO"], ctr, True)
-                reps_ += 1
-                if time.perf_counter() - t0_ > budget_s or reps_ >= max_reps:
-                    break
-            return (time.perf_counter() - t0_) / reps_, osrs_
+            pb_ = orc.prove(osrs_, m, Q, cc["wL"], cc["wR"], cc["wO"], cc["cs"], cc["aL"], cc["aR"], cc["aO"], tr_, True)
+            return time.perf_counter() - t0_, pb_
 
-        cpu_lg = args.cpu_log2n
-        if cpu_lg <= 0:     # bounded sample whatever the host: probe at 2^11, then the largest n <= 2^15 whose proof stays under ~5 s
-            probe, _ = cpu_prove_time(11, 0.0, 1)
-            cpu_lg = 11
-            while cpu_lg < 15 and probe * (1 << (cpu_lg + 1 - 11)) <= 5.0:
-                cpu_lg += 1
-        cn = 1 << cpu_lg
-        cdt, osrs = cpu_prove_time(cpu_lg, 12.0, 4)
-        cmsm_n = 1 << 16
-        csc = rand_fr_array(cr, cmsm_n)
+        # probe at n = 2^12 on an oracle-made SRS (cost is ~linear in n), then ONE proof at the largest n <= the bench's n that
+        # fits the budget -- on the bench's own SRS, circuit and transcript when that is the bench's n, so that the CPU proof
+        # can be compared with the GPU's byte for byte.  No extrapolation: what is printed was timed.
+        plg = min(12, args.log2n)
+        pcirc = big_circuit(1, 1 << plg, Q)
+        ptr = rand_fr_array(cr, 8 + 2 * Q)
+        ptr[:, 0] |= 1
+        psrs = orc.SRS(8 << plg, x, alpha, threads=cores)
+        probe, _ = cpu_prove_time(plg, psrs, pcirc, ptr)
+        cpu_lg = args.cpu_log2n if args.cpu_log2n > 0 else args.log2n
+        if args.cpu_log2n <= 0:
+            while cpu_lg > plg and probe * (1 << (cpu_lg - plg)) > args.cpu_budget_s:
+                cpu_lg -= 1
+        same = None
+        if cpu_lg == args.log2n:
+            # the SRS is set-up, not part of prove(): the oracle takes the GPU-made points (orc_srs_from_points) instead of
+            # spending minutes of fixed-base multiplications on the host
+            t0 = time.perf_counter()
+            osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1))
+            t_osrs = time.perf_counter() - t0
+            cdt, cproof = cpu_prove_time(cpu_lg, osrs, circ, transcripts[W + K - 1])
+            same = cproof == proof
+            srs_note = f"SRS points taken from the GPU-made SRS ({t_osrs:.1f}s copy, untimed)"
+        else:
+            cn_ = 1 << cpu_lg
+            t0 = time.perf_counter()
+            osrs = orc.SRS(8 * cn_, x, alpha, threads=cores)
+            t_osrs = time.perf_counter() - t0
+            ccirc = big_circuit(1, cn_, Q)
+            cdt, _ = cpu_prove_time(cpu_lg, osrs, ccirc, ptr)
+            srs_note = f"oracle-made SRS ({t_osrs:.1f}s, untimed)"
+        cmsm_n = min(msm_n, 2 * (8 << cpu_lg))
         t0 = time.perf_counter()
-        orc.msm_srs(osrs, 0, -(cmsm_n // 2) if 8 * cn >= cmsm_n // 2 else -8 * cn, csc[: min(cmsm_n, 16 * cn)], 1, cores)
+        orc.msm_srs(osrs, 0, -(8 << cpu_lg), sc[:cmsm_n], 1, cores)
         cmsm_dt = time.perf_counter() - t0
-        cmsm_terms = min(cmsm_n, 16 * cn)
         # the reference-shaped cost ("cpu-literal"): per-term double-and-add fold for the MSMs
         # (CommitmentScheme.hs:26-29) and the schoolbook product for tPoly, one thread as the reference never forks; small n only
         orc.set_mode(0, 1)
         lit_n = 256
-        lsrs = orc.SRS(8 * lit_n, cx, ca, threads=cores)
-        lc = big_circuit(1, lit_n, Q, None)
+        lc = big_circuit(1, lit_n, Q)
+        lsrs = orc.SRS(8 * lit_n, x, alpha, threads=cores)
         t0 = time.perf_counter()
-        orc.prove(lsrs, lit_n, Q, lc["wL"], lc["wR"], lc["wO"], lc["cs"], lc["aL"], lc["aR"], lc["aO"], ctr, False)
+        orc.prove(lsrs, lit_n, Q, lc["wL"], lc["wR"], lc["wO"], lc["cs"], lc["aL"], lc["aR"], lc["aO"], ptr, False)
         lit_dt = time.perf_counter() - t0
         orc.set_mode(1, cores)
-        cpu_baseline = {"value": round(1.0 / cdt, 4), "unit": "proofs/s", "cores": cores, "kind": "port",
+        cpu_baseline = {"value": round(1.0 / cdt, 5), "unit": "proofs/s", "cores": cores, "kind": "port",
+                        "n": 1 << cpu_lg, "at_bench_size": cpu_lg == args.log2n, "s_per_proof": round(cdt, 2), "same_bytes_as_gpu_proof": same,
+                        "sample": f"oracle/sonic_oracle.c (Pippenger + NTT, {cores} threads = usable host cores of {os.cpu_count()} visible) ONE prove() at n=2^{cpu_lg}, Q={Q}, d=8n: "
+                                  f"{cdt:.2f}s; {srs_note}; sized by a {probe:.2f}s probe at n=2^{plg} against a {args.cpu_budget_s:.0f}s budget",
+                        "msm_scalar_muls_per_s": round(cmsm_n / cmsm_dt, 1), "msm_sample": f"ONE N={cmsm_n} Pippenger MSM, {cores} threads, {cmsm_dt:.2f}s",
                         "literal": {"n": lit_n, "s_per_proof": round(lit_dt, 2), "cores": 1,
                                     "note": "the oracle with the reference's algorithms (fold of per-term double-and-add, schoolbook tPoly): "
-                                            "cost grows like n^2 in tPoly and 380 group operations per term in the MSMs"},
-                        "sample": f"oracle/sonic_oracle.c (Pippenger + NTT, {cores} threads) prove() at n=2^{cpu_lg}, Q={Q}, d=8n; "
-                                  f"{cdt:.2f}s per proof; cost is ~linear in n, so n=2^{args.log2n} would be ~{cdt * (n / cn):.0f}s per proof",
-                        "msm_scalar_muls_per_s": round(cmsm_terms / cmsm_dt, 1), "msm_sample": f"N={cmsm_terms} Pippenger, {cores} threads"}
+                                            "cost grows like n^2 in tPoly and 380 group operations per term in the MSMs"}}
 
     line = {
         "metric": "prove() proofs/sec",
@@ -378,22 +533,23 @@ def main():
         "dtype": "u32 limbs (Fq 12x32, Fr 8x32 Montgomery)",
         "data": "synthetic",
         "config": {"workload": f"prove(): rndCircuit n=2^{args.log2n}, Q={Q}, SRS d=2^{args.log2n + 3} (d=8n >= 7n, Protocol.hs:54); "
-                               f"G1 MSM N=2^{args.msm_log2} per GPU", "n": n, "Q": Q, "d": d, "sharding": "proof-per-rank; MSM range-sharded",
+                               f"G1 MSM N=2^{args.msm_log2} per GPU; one G1 MSM N=2^{strong_n.bit_length() - 1} over all GPUs", "n": n, "Q": Q, "d": d,
+                   "sharding": "proof-per-rank (value); MSM term-range-sharded (msm, weak); one MSM bucket-range-sharded (msm_strong, strong)",
                    "streaming": "K proofs streamed by one host thread through 2 prover handles per GPU (submit / collect); "
-                                "the strictly sequential rate is in `sequential`"},
-        "msm": {"metric": "G1 MSM scalar-muls/sec", "value": round(msm_per_s, 1), "unit": "scalar-muls/s", "N_per_gpu": msm_n,
-                "ms_per_msm": round(1e3 * dt_msm / K, 3),
-                "streaming": (f"K MSMs streamed over {NL} lanes per GPU (submit / collect); one at a time in `sequential`" if NL > 0 else "none (--msm-lanes 0): one MSM at a time"),
-                "sequential": {"scalar_muls_per_s": round(world * msm_n * K / dt_msm_seq, 1), "ms_per_msm": round(1e3 * dt_msm_seq / K, 3),
-                               "kernel_ms_per_msm": round(kern_total / K, 3), "same_result_as_streamed": seq_result == stream_result}},
+                                "the strictly sequential rate is in `sequential`",
+                   "process_group": (f"{args.backend}, {world} rank(s)" if pg else "none (plain single-process run)")},
+        "msm": msm,
+        "msm_strong": msm_strong,
         "roofline": roofline,
         "int_roofline": int_roofline,
+        "roofline_ntt": ntt,
+        "roofline_prove": roofline_prove,
         "cpu_baseline": cpu_baseline,
         "proof_bytes": len(proof),
         "sequential": sequential,
     }
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg:
         dist.destroy_process_group()
 
 

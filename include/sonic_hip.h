@@ -89,8 +89,13 @@ int sonic_srs_set_g2_points(sonic_srs_t* srs, const uint8_t* basis0, const uint8
 /* on-disk SRS (the reference has no persistence): "SONICSRS", u32 version = 2, u32 flags (bit 0: G2 half present), i64 d,
  * the two G1 bases as (2d+1) x 96 canonical bytes each, then -- with_g2 != 0 -- the two G2 bases as (2d+1) x 192 bytes
  * each.  Loading validates every point like sonic_srs_from_points / sonic_srs_set_g2_points; version-1 files (G1 only)
- * still load.  A file never holds x or alpha. */
+ * still load.  A file never holds x or alpha.  with_g2: 0 = G1 only, 1 = with the G2 half (SONIC_ERR_INVALID_ARG if the handle
+ * has none), 2 = with the G2 half if the handle has it (sonic_srs_has_g2).  (ABI note: the with_g2 argument was added in
+ * round 2; callers built against the two-argument prototype must be recompiled.)  Infinity is rejected in every SRS input
+ * (from_points except the omitted g^alpha slot, set_g2_points, load): no power of a generator is the identity. */
 int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2);
+/* 1 if the handle holds the G2 half or can still generate it (made by sonic_srs_new and not yet used), else 0 */
+int sonic_srs_has_g2(const sonic_srs_t* srs);
 int sonic_srs_load(const char* path, sonic_srs_t** out);
 
 /* ---- Sonic.CommitmentScheme ---- */
@@ -124,12 +129,35 @@ int sonic_msm_lane_new(sonic_msm_lane_t** out);
 void sonic_msm_lane_free(sonic_msm_lane_t* lane);
 int sonic_msm_submit(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n);
 int sonic_msm_collect(sonic_msm_lane_t* lane, uint8_t* out_g1, uint8_t* out_partial);
+/* a lane on a stream the caller owns (e.g. the stream its RCCL collectives are ordered on); the stream must outlive the lane */
+int sonic_msm_lane_new_on_stream(void* hip_stream, sonic_msm_lane_t** out);
+/* sonic_msm_submit that also leaves the un-normalised 192-byte sum in device memory, queued on the lane's stream: the operand
+ * of a cross-rank all-gather that never visits the host.  Needs a plan with one window sum (window tables). */
+int sonic_msm_submit_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
+                         void* d_partial_out);
+/* ONE MSM strong-scaled over `world` GPUs by sharding its BUCKETS (the fold of CommitmentScheme.hs:25-29 / 45-48 split twice: by term
+ * range for the accumulation, by bucket range for the reduction):
+ *   layout      n_buckets of the shared bucket set and the slice length S (a multiple of 16384, world * S >= n_buckets)
+ *   accumulate  sort + bucket accumulation of this rank's terms into d_buckets (capacity >= world * S entries of 192 B; the
+ *               padding is cleared), queued on the lane's stream
+ *   -- the caller exchanges slices: all-to-all, rank r receives entries [r S, (r+1) S) of every rank, laid out [world][S] --
+ *   reduce      element-wise curve addition of the k slices, then sum_i (bucket_base + i + 1) * slice[i]: 192-byte partial in
+ *               device memory (gathered and added like the term-range partials), queued on the lane's stream
+ *   sync        waits for the lane, reports a non-canonical scalar */
+int sonic_msm_exchange_layout(const sonic_srs_t* srs, int world, int64_t* n_buckets, int64_t* slice_len);
+int sonic_msm_accumulate_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
+                             void* d_buckets, int64_t capacity);
+int sonic_msm_reduce_slices_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, const void* d_slices, int k, int64_t slice_len,
+                                int64_t bucket_base, void* d_partial_out);
+int sonic_msm_lane_sync(sonic_msm_lane_t* lane);
 /* curve addition of k partials (RCCL has no such reduction op) + normalisation */
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]);
 /* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n) */
 int sonic_ntt_fr(uint8_t* data, int log2n, int inverse);
 /* dense product of two coefficient arrays (the `*` at Constraints.hs:61): out has na+nb-1 Fr */
 int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out);
+/* the same with operands and result resident in HBM (device pointers to canonical Fr; d_out: na + nb - 1 elements) */
+int sonic_poly_mul_fr_dev(const void* d_a, int64_t na, const void* d_b, int64_t nb, void* d_out);
 /* MSM tuning knob for tests: window bits (0 = automatic) */
 int sonic_msm_set_window(int c);
 /* what an n-term MSM over this SRS will run as: window bits, number of windows, and bucket sets
@@ -160,11 +188,36 @@ int sonic_prover_submit(sonic_prover_t* p, const uint8_t* transcript);
 int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof);
 void sonic_prover_free(sonic_prover_t* p);
 
+/* ---- opt-in Fiat-Shamir transcript ----
+ * The reference draws its challenges with `rnd` (Protocol.hs:58,66,76,84-85; Signature.hs:48,60) and hands y, z, (y_j, z_j) to the
+ * verifier as RndOracle.  In this mode each draw is instead SHA-256 of everything that precedes it, in that order (exact
+ * definition: sonic_amd/csrc/fs.hpp): the proof carries its own challenges.  It serialises the
+ * proof (R -> y -> T -> z -> ...: six waits for the GPU instead of one), so the explicit transcript above stays the default.
+ *   circuit_digest  SHA-256 of (n, Q, wL, wR, wO, cs): computed once per circuit
+ *   prove_fs        blinder_seed: the prover's secret randomness (32 bytes) the four blinders are derived from;
+ *                   out_transcript (may be NULL): the 8 + 2Q values the proof was made with, in sonic_prove's transcript order --
+ *                   sonic_prover_prove on them reproduces the proof byte for byte
+ *   fs_challenges   what a proof determines: y, z, y_1..y_Q, z_1..z_Q, u, v (32 bytes each)
+ *   verify_fs       recomputes them, requires the proof's own u, v to match, then verify (Protocol.hs:111-130) */
+int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO, const uint8_t* cs, uint8_t out[32]);
+int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], const uint8_t blinder_seed[32], uint8_t* out_proof,
+                          uint8_t* out_transcript);
+int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t* proof, uint8_t* out);
+int sonic_verify_fs(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                    const uint8_t* cs, const uint8_t* proof, int* accepted);
+
 /* hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof  (Signature.hs:32-72) on its own, for the s(X,Y) of the handle's
  * circuit (Constraints.hs:34-53) and any number m of (y_j, z_j) pairs (yzs: m x 64 bytes); u, v are its two `rnd` draws.
  * out (sonic_hsc_proof_size(m) bytes): [S_j, s_j, W_j]_j, [s'_j, W'_j, Q_j]_j, Q_v, C, u, v -- the HscProof part of a proof. */
 size_t sonic_hsc_proof_size(int64_t m);
 int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out);
+
+/* hscProve with the reference's own signature (Signature.hs:32-37): ANY sparse bivariate Laurent polynomial
+ * s(X,Y) = sum_i coeffs[i] X^{x_exps[i]} Y^{y_exps[i]} (terms in any order, repeated exponent pairs are summed), m pairs (y_j, z_j),
+ * the two `rnd` draws u, v.  Same output layout as sonic_prover_hsc_prove.  An evaluation point may be zero only if the
+ * polynomial has no negative power of that variable (`pow 0 e`, e < 0, divides by zero in the reference). */
+int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t* x_exps, const int64_t* y_exps, const uint8_t* coeffs,
+                         int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out);
 
 /* ---- the verifier side of the API (host CPU; outside the accelerated path) ---- */
 /* pcV :: SRS -> Int -> G1 -> Fr -> (Fr, G1) -> Bool  (CommitmentScheme.hs:51-68); *accepted = 0 / 1 */
@@ -178,6 +231,10 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
 /* hscVerify :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> HscProof -> Bool  (Signature.hs:74-90) for the s(X,Y) of a circuit */
 int sonic_hsc_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                      int64_t m, const uint8_t* yzs, const uint8_t* hsc, int* accepted);
+
+/* hscVerify (Signature.hs:74-90) for any sparse bivariate Laurent polynomial, the counterpart of sonic_hsc_prove_poly */
+int sonic_hsc_verify_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t* x_exps, const int64_t* y_exps, const uint8_t* coeffs,
+                          int64_t m, const uint8_t* yzs, const uint8_t* hsc, int* accepted);
 
 /* ---- device memory for callers without a HIP binding ---- */
 int sonic_dev_alloc(size_t bytes, void** out);

@@ -73,7 +73,28 @@ def main():
     muls = [{"k": hx(k), "point": pt(ref.g1_mul(ref.G1_GEN, k))} for k in [1, 2, 3, ref.R - 1, (ref.R - 1) // 2] + [rng.randrange(ref.R) for _ in range(4)]]
     json.dump({"generator": "oracle/gen_golden.py", "d": d, "x": hx(x), "alpha": hx(alpha), "srs": elems, "polys": polys, "gen_multiples": muls},
               open(os.path.join(OUT, "commitment_small.json"), "w"), indent=1)
+    gen_fs()
     print("wrote", OUT)
+
+
+def gen_fs():
+    """Fiat-Shamir proofs (ref.prove_fs) of three of the circuits above: seed -> the transcript the hashes yield -> proof bytes"""
+    base = json.load(open(os.path.join(OUT, "prove_small.json")))["cases"]
+    cases = []
+    for c in base:
+        if c["name"] not in ("example1", "rnd_n2", "rnd_n8"):
+            continue
+        iv = lambda v: int(v, 16)    # noqa: E731
+        circ = ([[iv(v) for v in r] for r in c["wL"]], [[iv(v) for v in r] for r in c["wR"]], [[iv(v) for v in r] for r in c["wO"]], [iv(v) for v in c["cs"]])
+        asg = ([iv(v) for v in c["aL"]], [iv(v) for v in c["aR"]], [iv(v) for v in c["aO"]])
+        srs = ref.SRS(c["d"], iv(c["x"]), iv(c["alpha"]))
+        seed = bytes([len(c["name"])] * 32)
+        proof, _o, tr = ref.prove_fs(srs, asg, circ, seed)
+        assert ref.verify_exponent(srs, circ, asg, tr, proof)
+        cases.append({"name": c["name"], "seed": seed.hex(), "circuit_digest": ref.fs_circuit_digest(circ).hex(),
+                      "transcript": [hx(v) for v in tr], "proof": ref.proof_to_bytes(proof).hex()})
+    json.dump({"generator": "oracle/gen_golden.py (gen_fs): inputs are the cases of the same name in prove_small.json", "cases": cases},
+              open(os.path.join(OUT, "fs_small.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

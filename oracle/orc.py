@@ -35,6 +35,8 @@ def lib():
         L = _LIB
         L.orc_srs_new.restype = C.c_void_p
         L.orc_srs_new.argtypes = [C.c_long, C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_srs_from_points.restype = C.c_void_p
+        L.orc_srs_from_points.argtypes = [C.c_long, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_srs_free.argtypes = [C.c_void_p]
         L.orc_srs_d.restype = C.c_long
         L.orc_srs_d.argtypes = [C.c_void_p]
@@ -95,6 +97,18 @@ class SRS:
         self.h = lib().orc_srs_new(d, fr_bytes(x), fr_bytes(alpha), threads)
         if not self.h:
             raise OracleError(3)
+
+    @classmethod
+    def from_points(cls, d: int, basis0: np.ndarray, basis1: np.ndarray, threads: int = 8) -> "SRS":
+        """the record constructor: canonical bytes, uint8 [(2d+1), 96] per basis (validated: canonical, on the curve)"""
+        b0, b1 = np.ascontiguousarray(basis0, np.uint8), np.ascontiguousarray(basis1, np.uint8)
+        assert b0.size == 96 * (2 * d + 1) and b1.size == 96 * (2 * d + 1)
+        self = cls.__new__(cls)
+        self.d = d
+        self.h = lib().orc_srs_from_points(d, _p(b0), _p(b1), threads)
+        if not self.h:
+            raise OracleError(3)
+        return self
 
     def points(self, basis: int, e0: int, n: int) -> np.ndarray:
         out = np.zeros((n, 96), np.uint8)

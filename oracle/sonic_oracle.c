@@ -505,6 +505,23 @@ API void *orc_srs_new(long d, const uint8_t *x32, const uint8_t *alpha32, int th
   parallel_for(2 * d + 1, threads, srs_fill, &c);
   return s;
 }
+/* the record constructor `SRS{..}` (SRS.hs:11-22) from canonical bytes, (2d+1) x 96 per basis: lets a CPU baseline run on an SRS
+ * that was generated elsewhere (set-up is not part of prove()).  Every point must be canonical and on the curve. */
+typedef struct { srs_t *s; const uint8_t *b0, *b1; int bad; } srs_pts_ctx;
+static void srs_from_bytes_range(void *vctx, long lo, long hi, int tid) {
+  (void)tid; srs_pts_ctx *c = vctx;
+  for (long i = lo; i < hi; i++)
+    if (g1a_from_bytes(&c->s->g[i], c->b0 + 96 * i) || g1a_from_bytes(&c->s->ga[i], c->b1 + 96 * i)) c->bad = 1;
+}
+API void *orc_srs_from_points(long d, const uint8_t *b0, const uint8_t *b1, int threads) {
+  ensure_init();
+  srs_t *s = malloc(sizeof *s); s->d = d;
+  s->g = malloc(sizeof(g1a_t) * (2 * d + 1)); s->ga = malloc(sizeof(g1a_t) * (2 * d + 1));
+  srs_pts_ctx c = {s, b0, b1, 0};
+  parallel_for(2 * d + 1, threads, srs_from_bytes_range, &c);
+  if (c.bad) { free(s->g); free(s->ga); free(s); return NULL; }
+  return s;
+}
 API void orc_srs_free(void *srs) { srs_t *s = srs; if (!s) return; free(s->g); free(s->ga); free(s); }
 API long orc_srs_d(const void *srs) { return ((const srs_t *)srs)->d; }
 /* copy points e0..e0+n-1 of a basis as canonical bytes */

@@ -530,6 +530,90 @@ def verify_exponent(srs: SRS, circuit, assignment, transcript, proof) -> bool:
 # --------------------------------------------------------------------------------------
 # Circuits: the reference's fixed examples and generator (test/Test/Reference.hs)
 # --------------------------------------------------------------------------------------
+
+# ---- opt-in Fiat-Shamir transcript (restates sonic_amd/csrc/fs.hpp) -----------------------------------------
+# The reference draws its challenges with `rnd`: y after R (Protocol.hs:66), z after T (:76), y_j / z_j after the openings
+# (:84-85), u after the S_j (Signature.hs:48), v after C and the W'_j, Q_j (:60).  Here each draw is SHA-256 of what precedes
+# it, in that order.  hashlib stands in for the product's own SHA-256.
+import hashlib as _hashlib
+
+
+def _le64(v: int) -> bytes:
+    return int(v).to_bytes(8, "little")
+
+
+def fs_wide(d0: bytes, d1: bytes) -> int:
+    return int.from_bytes(d0 + d1, "little") % R
+
+
+def fs_circuit_digest(circuit) -> bytes:
+    wL, wR, wO, cs = circuit
+    n, m = len(wL[0]), len(wL)
+    h = _hashlib.sha256(b"sonic-hip/circuit/v1" + _le64(n) + _le64(m))
+    for w in (wL, wR, wO):
+        for row in w:
+            for v in row:
+                h.update(fr_to_bytes(v))
+    for c in cs:
+        h.update(fr_to_bytes(c))
+    return h.digest()
+
+
+def fs_blinders(seed: bytes):
+    out = []
+    for i in range(4):
+        d = [_hashlib.sha256(b"sonic-hip/blinder/v1" + seed + i.to_bytes(4, "little") + bytes([half])).digest() for half in (0, 1)]
+        out.append(fs_wide(d[0], d[1]))
+    return out
+
+
+class FsTranscript:
+    def __init__(self, n: int, m: int, d: int, digest: bytes):
+        self.st = _hashlib.sha256(b"sonic-hip/fs/v1" + _le64(n) + _le64(m) + _le64(d) + digest).digest()
+
+    def absorb(self, label: bytes, data: bytes):
+        self.st = _hashlib.sha256(self.st + label + data).digest()
+
+    def challenge(self, label: bytes, i: int) -> int:
+        d = [_hashlib.sha256(self.st + label + i.to_bytes(4, "little") + bytes([half])).digest() for half in (0, 1)]
+        return fs_wide(d[0], d[1]) or 1
+
+
+def fs_challenges_of_proof(n: int, m: int, d: int, digest: bytes, pb: bytes):
+    """y, z, [y_j], [z_j], u, v as a proof's canonical bytes determine them"""
+    t = FsTranscript(n, m, d, digest)
+    t.absorb(b"R", pb[0:96])
+    y = t.challenge(b"y", 0)
+    t.absorb(b"T", pb[96:192])
+    z = t.challenge(b"z", 0)
+    t.absorb(b"open", pb[192:576])
+    ys = [t.challenge(b"yj", j) for j in range(m)]
+    zs = [t.challenge(b"zj", j) for j in range(m)]
+    hs, hw = 576, 576 + 224 * m
+    t.absorb(b"hscS", pb[hs:hw])
+    u = t.challenge(b"u", 0)
+    qv = hw + 224 * m
+    t.absorb(b"hscW", pb[qv + 96:qv + 192] + pb[hw:qv])
+    v = t.challenge(b"v", 0)
+    return y, z, ys, zs, u, v
+
+
+def prove_fs(srs: SRS, assignment, circuit, seed: bytes):
+    """prove with every draw replaced by the hash of what precedes it.  Every proof element depends only on draws made before
+    it (that is what lets the reference draw them on the way), so proving with the draws known so far and re-deriving the next
+    one from the bytes reaches the fixed point after one round per draw site; the literal `prove` above does the proving."""
+    aL = assignment[0]
+    n, m = len(aL), len(circuit[0])
+    digest = fs_circuit_digest(circuit)
+    tr = fs_blinders(seed) + [1] * (4 + 2 * m)
+    for _ in range(6):
+        proof, _o = prove(srs, assignment, circuit, tr)
+        y, z, ys, zs, u, v = fs_challenges_of_proof(n, m, srs.d, digest, proof_to_bytes(proof))
+        tr = tr[:4] + [y, z] + ys + zs + [u, v]
+    proof, oracle = prove(srs, assignment, circuit, tr)
+    assert fs_challenges_of_proof(n, m, srs.d, digest, proof_to_bytes(proof)) == (y, z, ys, zs, u, v)
+    return proof, oracle, tr
+
 def arith_circuit_example1():
     """arithCircuitExample1 (test/Test/Reference.hs:38-50): n=1, Q=2."""
     wL, wR, wO = [[1], [0]], [[0], [1]], [[0], [0]]

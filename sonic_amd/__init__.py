@@ -22,7 +22,9 @@ from ._lib import SonicError, LIB_PATH  # noqa: F401,E402
 from .encoding import R_MODULUS, Q_MODULUS, fr_to_bytes, fr_from_bytes, g1_to_bytes, g1_from_bytes  # noqa: F401,E402
 from .srs import SRS  # noqa: F401,E402
 from .commitment import commit_poly, open_poly, pc_v, msm_g1, MsmLane  # noqa: F401,E402
+from .protocol import hsc_prove_poly, hsc_verify_poly  # noqa: F401,E402
+from .protocol import prove_fs, verify_fs, fs_challenges, fs_circuit_digest  # noqa: F401,E402
 from .protocol import prove, verify, hsc_prove, hsc_verify, Proof, HscProof, RndOracle, Prover, ProverPipeline, ArithCircuit, Assignment, GateWeights  # noqa: F401,E402
 
-__all__ = ["SRS", "commit_poly", "open_poly", "pc_v", "msm_g1", "MsmLane", "prove", "verify", "hsc_prove", "hsc_verify", "Proof", "HscProof", "RndOracle", "Prover", "ProverPipeline",
+__all__ = ["SRS", "commit_poly", "open_poly", "pc_v", "msm_g1", "MsmLane", "prove", "verify", "prove_fs", "verify_fs", "fs_challenges", "fs_circuit_digest", "hsc_prove", "hsc_verify", "hsc_prove_poly", "hsc_verify_poly", "Proof", "HscProof", "RndOracle", "Prover", "ProverPipeline",
            "ArithCircuit", "Assignment", "GateWeights", "SonicError"]

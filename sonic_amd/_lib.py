@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
         "sonic_srs_get_points": [vp, i32, i64, i64, vp],
         "sonic_srs_get_g2_points": [vp, i32, i64, i64, vp],
         "sonic_srs_save": [vp, cp, i32],
+        "sonic_srs_has_g2": [vp],
         "sonic_srs_set_g2_points": [vp, vp, vp],
         "sonic_srs_load": [cp, C.POINTER(vp)],
         "sonic_commit_poly": [vp, i64, i64, vp, vp, vp],
@@ -60,8 +61,15 @@ def lib() -> C.CDLL:
         "sonic_msm_lane_new": [C.POINTER(vp)],
         "sonic_msm_submit": [vp, vp, i32, i64, vp, i64],
         "sonic_msm_collect": [vp, vp, vp],
+        "sonic_msm_lane_new_on_stream": [vp, C.POINTER(vp)],
+        "sonic_msm_submit_dev": [vp, vp, i32, i64, vp, i64, vp],
+        "sonic_msm_exchange_layout": [vp, i32, C.POINTER(i64), C.POINTER(i64)],
+        "sonic_msm_accumulate_dev": [vp, vp, i32, i64, vp, i64, vp, i64],
+        "sonic_msm_reduce_slices_dev": [vp, vp, vp, i32, i64, i64, vp],
+        "sonic_msm_lane_sync": [vp],
         "sonic_ntt_fr": [vp, i32, i32],
         "sonic_poly_mul_fr": [vp, i64, vp, i64, vp],
+        "sonic_poly_mul_fr_dev": [vp, i64, vp, i64, vp],
         "sonic_msm_set_window": [i32],
         "sonic_msm_plan": [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "sonic_prove": [vp, i64, i64] + [vp] * 9,
@@ -71,7 +79,13 @@ def lib() -> C.CDLL:
         "sonic_prover_submit": [vp, vp],
         "sonic_prover_collect": [vp, vp],
         "sonic_prover_prepare": [vp],
+        "sonic_fs_circuit_digest": [i64, i64, vp, vp, vp, vp, vp],
+        "sonic_prover_prove_fs": [vp, cp, cp, vp, vp],
+        "sonic_fs_challenges": [i64, i64, i64, cp, vp, vp],
+        "sonic_verify_fs": [vp, i64, i64, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "sonic_prover_hsc_prove": [vp, i64, vp, cp, cp, vp],
+        "sonic_hsc_prove_poly": [vp, i64, vp, vp, vp, i64, vp, cp, cp, vp],
+        "sonic_hsc_verify_poly": [vp, i64, vp, vp, vp, i64, vp, vp, C.POINTER(i32)],
         "sonic_hsc_verify": [vp, i64, i64, vp, vp, vp, i64, vp, vp, C.POINTER(i32)],
         "sonic_pc_v": [vp, i64, cp, cp, cp, cp, C.POINTER(i32)],
         "sonic_verify": [vp, i64, i64, vp, vp, vp, vp, vp, cp, cp, vp, C.POINTER(i32)],
@@ -109,11 +123,12 @@ def lib() -> C.CDLL:
 
 EXPORTED = [
     "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_srs_new", "sonic_srs_from_points",
-    "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
+    "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_has_g2", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
-    "sonic_g1_sum_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_msm_set_window", "sonic_msm_plan",
+    "sonic_g1_sum_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_msm_lane_new_on_stream", "sonic_msm_submit_dev", "sonic_msm_exchange_layout",
+    "sonic_msm_accumulate_dev", "sonic_msm_reduce_slices_dev", "sonic_msm_lane_sync", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_poly_mul_fr_dev", "sonic_msm_set_window", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
-    "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare", "sonic_prover_hsc_prove", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
+    "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare", "sonic_fs_circuit_digest", "sonic_prover_prove_fs", "sonic_fs_challenges", "sonic_verify_fs", "sonic_prover_hsc_prove", "sonic_hsc_prove_poly", "sonic_hsc_verify_poly", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
     "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",
     "sonic_profile_names",
 ]

@@ -60,14 +60,17 @@ MsmWorkspace& shared_msm_ws() { if (!g_msm_ws) g_msm_ws = new MsmWorkspace(); re
 std::mutex& call_mutex() { return g_call_mu; }
 
 // ---- encodings ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, long n, int* err) {
+// inf_ok: index at which the point at infinity is accepted (-1: everywhere, as for the operands of sonic_msm_g1; -2: nowhere; an SRS has
+// exactly one such slot, the omitted g^alpha); elsewhere infinity sets err bit 8 -- g^{x^e} and g^{alpha x^e} are never the
+// identity for x, alpha != 0, and a zero-filled SRS must not pass for a valid one
+__global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, long n, int* err, long inf_ok) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(in + 96 * i);
   G1Affine p;
   for (int k = 0; k < 12; k++) { p.x.l[k] = w[k]; p.y.l[k] = w[12 + k]; }
   if (!fp_is_canonical(p.x) || !fp_is_canonical(p.y)) { atomicOr(err, 1); out[i] = G1Affine::inf(); return; }   // before is_inf: (q, q) is not O
-  if (p.is_inf()) { out[i] = p; return; }
+  if (p.is_inf()) { if (inf_ok != -1 && i != inf_ok) atomicOr(err, 8); out[i] = p; return; }
   p.x = fp_to_mont(p.x); p.y = fp_to_mont(p.y);
   Fq four = fp_dbl(fp_dbl(Fq::one()));
   if (fp_sqr(p.y) != fp_add(fp_mul(fp_sqr(p.x), p.x), four)) { atomicOr(err, 2); out[i] = G1Affine::inf(); return; }
@@ -205,8 +208,11 @@ void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std) { s->h
 
 // plan for an MSM over n consecutive SRS points: shared-bucket plan over the window tables unless the MSM is
 // tiny compared with the bucket set, the tables are off, or a test forces a window size
+// Entry encoding limits (msm.hip, k_part_scatter / entry_point): over window tables an entry packs the term index into 26 bits and
+// the window into 5, without tables the index has 31 bits.  MSMs of 2^26 terms and more therefore run over per-window buckets
+// even when the SRS has tables, and 2^31 terms are refused (msm_enqueue_batch, sonic_msm_plan).
 MsmPlan srs_msm_plan(const sonic_srs* s, long n) {
-  if (s->tab_W > 1 && msm_window_override() == 0 && n >= (1L << (s->tab_c - 1)) / 16)
+  if (s->tab_W > 1 && s->tab_W <= MSM_TABLE_MAX_WINDOWS && n < MSM_TABLE_MAX_TERMS && msm_window_override() == 0 && n >= (1L << (s->tab_c - 1)) / 16)
     return msm_plan_tables(n > 0 ? n : 1, s->tab_c, s->tab_W, 2 * s->d + 1);
   return msm_plan(n > 0 ? n : 1);
 }
@@ -256,7 +262,8 @@ int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis
   HIP_OK(hipMemsetAsync(err.p, 0, 4, st));
   for (int b = 0; b < 2; b++) {
     HIP_OK(hipMemcpyAsync(raw.p, b ? basis1 : basis0, 96 * n, hipMemcpyHostToDevice, st));
-    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), srs_basis_mut(s, b), n, err.as<int>());
+    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), srs_basis_mut(s, b), n, err.as<int>(),
+           b ? (long)d : -2L);        // basis 1 has the empty slot e = 0 (SRS.hs:38); basis 0 has none
     LAUNCH(k_points_subgroup_check, ceil_div(n, 256), 256, 0, st, (const G1Affine*)srs_basis_mut(s, b), n, err.as<int>());
   }
   int herr = 0;
@@ -264,7 +271,7 @@ int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis
   HIP_OK(hipStreamSynchronize(st));
   if (herr) {
     delete s;
-    set_error("sonic_srs_from_points: %s", (herr & 1) ? "non-canonical coordinate" : (herr & 2) ? "point not on curve" : "point outside the order-r subgroup");
+    set_error("sonic_srs_from_points: %s", (herr & 1) ? "non-canonical coordinate" : (herr & 2) ? "point not on curve" : (herr & 4) ? "point outside the order-r subgroup" : "point at infinity (only the omitted g^alpha, basis 1 slot e = 0, may be empty)");
     return SONIC_ERR_BAD_ENCODING;
   }
   srs_build_tables(st, s);
@@ -298,9 +305,14 @@ static int srs_ensure_g2(const sonic_srs_t* srs, hipStream_t st, const char* who
   if (srs->h.p) return SONIC_OK;
   if (!srs->have_trapdoor) { set_error("%s: this SRS has no G2 half (built from G1 points only)", who); return SONIC_ERR_INVALID_ARG; }
   const size_t cnt = (size_t)(2 * srs->d + 1);
-  srs->h.alloc(sizeof(G2Affine) * cnt);
-  srs->ha.alloc(sizeof(G2Affine) * cnt);
-  srs_generate_g2(st, srs->d, srs->x_std, srs->alpha_std, srs->h.as<G2Affine>(), srs->ha.as<G2Affine>());
+  // generated into local buffers and attached only when the generation has finished: a failure half way (e.g. no memory for
+  // its Jacobian scratch at large d) must leave the handle without a G2 half and with its trapdoor, not with uninitialised
+  // memory that a later call would serve -- all-zero bytes decode as the point at infinity, and a verifier whose three G2
+  // elements are at infinity accepts every proof
+  DevBuf h0(sizeof(G2Affine) * cnt), h1(sizeof(G2Affine) * cnt);
+  srs_generate_g2(st, srs->d, srs->x_std, srs->alpha_std, h0.as<G2Affine>(), h1.as<G2Affine>());
+  srs->h = std::move(h0);
+  srs->ha = std::move(h1);
   srs->wipe_trapdoor();          // x and alpha have served their last purpose
   return SONIC_OK;
 }
@@ -337,7 +349,7 @@ int sonic_srs_set_g2_points(sonic_srs_t* srs, const uint8_t* basis0, const uint8
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) {
-    set_error("sonic_srs_set_g2_points: %s", (herr & 1) ? "non-canonical coordinate" : (herr & 2) ? "point not on the twist" : "point outside the order-r subgroup");
+    set_error("sonic_srs_set_g2_points: %s", (herr & 1) ? "non-canonical coordinate" : (herr & 2) ? "point not on the twist" : (herr & 4) ? "point outside the order-r subgroup" : "point at infinity (h^{x^e}, h^{alpha x^e} are never the identity)");
     return SONIC_ERR_BAD_ENCODING;
   }
   std::lock_guard<std::mutex> g2(srs->g2_mu);
@@ -347,6 +359,12 @@ int sonic_srs_set_g2_points(sonic_srs_t* srs, const uint8_t* basis0, const uint8
   API_END
 }
 
+int sonic_srs_has_g2(const sonic_srs_t* srs) {
+  if (!srs) return 0;
+  std::lock_guard<std::mutex> g2(srs->g2_mu);
+  return (srs->h.p != nullptr || srs->have_trapdoor) ? 1 : 0;
+}
+
 // ---- on-disk SRS: "SONICSRS" | u32 version = 2 | u32 flags (bit 0: G2 half follows) | i64 d | basis0, basis1: (2d+1) x 96 B |
 // [h basis0, h basis1: (2d+1) x 192 B], canonical affine encodings.  The reference has no persistence at all; this
 // amortises SRS.new across runs, and with the G2 half a loaded SRS verifies as well as proves -- without the trapdoor.
@@ -354,7 +372,8 @@ static const char SRS_MAGIC[8] = {'S', 'O', 'N', 'I', 'C', 'S', 'R', 'S'};
 
 int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2) {
   API_BEGIN
-  if (!srs || !path) return SONIC_ERR_INVALID_ARG;
+  if (!srs || !path || with_g2 < 0 || with_g2 > 2) return SONIC_ERR_INVALID_ARG;
+  if (with_g2 == 2) with_g2 = sonic_srs_has_g2(srs) ? 1 : 0;          // "if the handle has (or can generate) it"
   if (with_g2) {
     std::lock_guard<std::mutex> g(call_mutex());
     int rc = srs_ensure_g2(srs, default_stream(), "sonic_srs_save");
@@ -411,6 +430,7 @@ int sonic_msm_set_window(int c) { msm_set_window_override(c); return SONIC_OK; }
 
 int sonic_msm_plan(const sonic_srs_t* srs, int64_t n, int* window_bits, int* windows, int* bucket_sets) {
   if (!srs || n < 0) return SONIC_ERR_INVALID_ARG;
+  if (n >= MSM_MAX_TERMS) { set_error("MSM of %ld terms: at most 2^31 - 1 (entry encoding)", (long)n); return SONIC_ERR_INVALID_ARG; }
   MsmPlan pl = srs_msm_plan(srs, n);
   if (window_bits) *window_bits = pl.c;
   if (windows) *windows = pl.W;
@@ -429,7 +449,7 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
   if (n > 0) {
     HIP_OK(hipMemcpyAsync(raw.p, points, 96 * n, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(sc.p, scalars, 32 * n, hipMemcpyHostToDevice, st));
-    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), pts.as<G1Affine>(), (long)n, err.as<int>());
+    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), pts.as<G1Affine>(), (long)n, err.as<int>(), -1L);
     fr_check_enqueue(st, sc.as<Fr>(), n, err.as<int>());
   }
   int herr = 0;
@@ -455,9 +475,10 @@ struct sonic_msm_lane {
   // 32 3.56, 64 4.03 ms per MSM); one MSM at a time wants the shortest chain (K = 8: 4.18, 16: 4.45, 32: 5.05 ms)
   int segment = 16;
   bool in_flight = false;
+  bool own_stream = true;        // false: the lane runs on a stream the caller owns (sonic_msm_lane_new_on_stream)
   std::mutex mu;
   ~sonic_msm_lane() {
-    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (st) { (void)hipStreamSynchronize(st); if (own_stream) (void)hipStreamDestroy(st); }
     if (h_slot) (void)hipHostFree(h_slot);
     if (h_err) (void)hipHostFree(h_err);
   }
@@ -475,9 +496,37 @@ int sonic_msm_lane_new(sonic_msm_lane_t** out) {
   *out = l.release();
   API_END
 }
+// A lane on a stream the caller owns -- e.g. torch.cuda.current_stream().cuda_stream, so that the lane's kernels, the caller's
+// RCCL collectives on the bucket / partial buffers and the caller's copies are ordered by the stream and need no host
+// synchronisation in between.  The stream must outlive the lane.
+int sonic_msm_lane_new_on_stream(void* hip_stream, sonic_msm_lane_t** out) {
+  API_BEGIN
+  if (!out) return SONIC_ERR_INVALID_ARG;
+  std::unique_ptr<sonic_msm_lane> l(new sonic_msm_lane());
+  l->st = static_cast<hipStream_t>(hip_stream);
+  l->own_stream = false;
+  l->segment = 8;               // ordered on the caller's stream, such a lane runs one MSM at a time: shortest chain
+  l->slot.alloc(sizeof(MsmSlot));
+  l->err.alloc(4);
+  HIP_OK(hipHostMalloc((void**)&l->h_slot, sizeof(MsmSlot), hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&l->h_err, 4, hipHostMallocDefault));
+  *out = l.release();
+  API_END
+}
 void sonic_msm_lane_free(sonic_msm_lane_t* l) { delete l; }
 
+static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, void* d_partial_out);
 int sonic_msm_submit(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n) {
+  return msm_submit_common(l, srs, basis, e0, d_scalars, n, nullptr);
+}
+// the same with the un-normalised 192-byte sum ALSO left in device memory (d_partial_out), queued on the lane's stream: the
+// operand of a cross-rank all-gather that never visits the host.  Only plans that leave one window sum (window tables) can do
+// that -- others need the host's Horner fold -- SONIC_ERR_INVALID_ARG otherwise (use sonic_msm_collect's out_partial then).
+int sonic_msm_submit_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, void* d_partial_out) {
+  if (!d_partial_out) return SONIC_ERR_INVALID_ARG;
+  return msm_submit_common(l, srs, basis, e0, d_scalars, n, d_partial_out);
+}
+static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, void* d_partial_out) {
   API_BEGIN
   if (!l || !srs || n < 0 || (n > 0 && !d_scalars) || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
   if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
@@ -488,9 +537,11 @@ int sonic_msm_submit(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int
   HIP_OK(hipMemsetAsync(l->err.p, 0, 4, st));
   fr_check_enqueue(st, dsc, n, l->err.as<int>());
   MsmPlan pl = srs_msm_plan(srs, n);
+  if (d_partial_out && pl.Wb != 1) { set_error("sonic_msm_submit_dev: this MSM leaves %d window sums for the host to fold (no window tables, or too few terms for them)", pl.Wb); return SONIC_ERR_INVALID_ARG; }
   if (pl.Wb == 1 && pl.NB >= (1 << 16)) msm_plan_set_segment(pl, l->segment);
   msm_enqueue(st, l->ws, pl, srs->basis(basis) + (e0 + srs->d), dsc, n, false, l->slot.as<MsmSlot>());
   l->Wb = pl.Wb;
+  if (d_partial_out) HIP_OK(hipMemcpyAsync(d_partial_out, &l->slot.as<MsmSlot>()->win[0], sizeof(G1XYZZ), hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(l->h_slot, l->slot.p, sizeof(int) * 4 + sizeof(G1XYZZ) * pl.Wb, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(l->h_err, l->err.p, 4, hipMemcpyDeviceToHost, st));
   l->in_flight = true;
@@ -542,6 +593,66 @@ int sonic_msm_g1_srs_dev(const sonic_srs_t* srs, int basis, int64_t e0, const vo
 }
 int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, uint8_t out_partial[192]) {
   return msm_srs_common(srs, basis, e0, d_scalars, nullptr, n, nullptr, out_partial);
+}
+
+// ---- one MSM over several GPUs, sharded by BUCKET range (strong scaling) ----------------------------------------------------
+// Every rank sorts and accumulates its term range into a full bucket set; the ranks exchange bucket ranges (all-to-all of
+// slice_len x 192 B per pair); each rank adds the slices it received and reduces its range with the range's weights; the
+// 192-byte partials are gathered and added as in the term-range scheme.  The reduction of the shared buckets -- which a
+// term-range shard repeats in full on every rank -- is divided by the number of ranks this way.
+int sonic_msm_exchange_layout(const sonic_srs_t* srs, int world, int64_t* n_buckets, int64_t* slice_len) {
+  if (!srs || world < 1 || !n_buckets || !slice_len) return SONIC_ERR_INVALID_ARG;
+  if (srs->tab_W <= 1) { set_error("bucket exchange needs the window tables of the SRS (one shared bucket set per MSM)"); return SONIC_ERR_INVALID_ARG; }
+  const int64_t NB = 1LL << (srs->tab_c - 1);
+  int64_t S = (NB + world - 1) / world;
+  S = (S + MSM_SLICE_QUANTUM - 1) / MSM_SLICE_QUANTUM * MSM_SLICE_QUANTUM;
+  *n_buckets = NB;
+  *slice_len = S;
+  return SONIC_OK;
+}
+
+int sonic_msm_accumulate_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
+                             void* d_buckets, int64_t capacity) {
+  API_BEGIN
+  if (!l || !srs || n < 0 || (n > 0 && !d_scalars) || (basis != 0 && basis != 1) || !d_buckets) return SONIC_ERR_INVALID_ARG;
+  if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
+  if (srs->tab_W <= 1) { set_error("sonic_msm_accumulate_dev needs the window tables of the SRS"); return SONIC_ERR_INVALID_ARG; }
+  const int64_t NB = 1LL << (srs->tab_c - 1);
+  if (capacity < NB) { set_error("sonic_msm_accumulate_dev: room for %ld buckets, the plan has %ld", (long)capacity, (long)NB); return SONIC_ERR_INVALID_ARG; }
+  std::lock_guard<std::mutex> g(l->mu);
+  hipStream_t st = l->st;
+  const Fr* dsc = static_cast<const Fr*>(d_scalars);
+  HIP_OK(hipMemsetAsync(l->err.p, 0, 4, st));
+  fr_check_enqueue(st, dsc, n, l->err.as<int>());
+  // always over the tables (a term-range share may be small against the bucket set; every rank must fill the SAME buckets)
+  MsmPlan pl = msm_plan_tables(n > 0 ? n : 1, srs->tab_c, srs->tab_W, 2 * srs->d + 1);
+  MsmJob job{srs->basis(basis) + (e0 + srs->d), dsc, (long)n, nullptr};
+  msm_enqueue_batch(st, l->ws, pl, &job, 1, false, static_cast<G1XYZZ*>(d_buckets));
+  if (capacity > NB) HIP_OK(hipMemsetAsync(static_cast<G1XYZZ*>(d_buckets) + NB, 0, sizeof(G1XYZZ) * (size_t)(capacity - NB), st));   // padding = infinity
+  HIP_OK(hipMemcpyAsync(l->h_err, l->err.p, 4, hipMemcpyDeviceToHost, st));
+  API_END
+}
+
+int sonic_msm_reduce_slices_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, const void* d_slices, int k, int64_t slice_len, int64_t bucket_base,
+                                void* d_partial_out) {
+  API_BEGIN
+  if (!l || !srs || !d_slices || k < 1 || !d_partial_out || slice_len < 1 || bucket_base < 0) return SONIC_ERR_INVALID_ARG;
+  if (slice_len % MSM_SLICE_QUANTUM || bucket_base % MSM_SLICE_QUANTUM) { set_error("sonic_msm_reduce_slices_dev: slice length and base must be multiples of %ld (sonic_msm_exchange_layout)", (long)MSM_SLICE_QUANTUM); return SONIC_ERR_INVALID_ARG; }
+  std::lock_guard<std::mutex> g(l->mu);
+  hipStream_t st = l->st;
+  msm_reduce_slices_enqueue(st, l->ws, static_cast<const G1XYZZ*>(d_slices), k, slice_len, bucket_base, srs->tab_c, l->slot.as<MsmSlot>());
+  HIP_OK(hipMemcpyAsync(d_partial_out, &l->slot.as<MsmSlot>()->win[0], sizeof(G1XYZZ), hipMemcpyDeviceToDevice, st));
+  API_END
+}
+
+// waits for what the lane has queued (accumulate / reduce / submit_dev) and reports a non-canonical scalar
+int sonic_msm_lane_sync(sonic_msm_lane_t* l) {
+  API_BEGIN
+  if (!l) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(l->mu);
+  HIP_OK(hipStreamSynchronize(l->st));
+  if (*l->h_err) { *l->h_err = 0; set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
+  API_END
 }
 
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]) {

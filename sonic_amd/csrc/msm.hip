@@ -547,19 +547,22 @@ __global__ __launch_bounds__(64, 2) void k_heavy_finish(const HeavyMeta* hm, con
 }
 
 // ---- bucket reduction: sum_b (b+1) * B_b per window -----------------------------------------
-__global__ __launch_bounds__(256, 1) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg,
+// sg_base: the set's first segment is segment sg_base of a longer bucket sequence (one rank's bucket range of an MSM whose buckets are
+// sharded across ranks, msm_reduce_slices_enqueue): bucket j of segment sg weighs (sg_base + sg) K + j + 1
+__global__ __launch_bounds__(256, 1) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg, int sg_base,
                                                         G1XYZZ* __restrict__ segres) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * nseg) return;
-  const int w = t / nseg, sg = t % nseg;
+  const int w = t / nseg, sl = t % nseg;
+  const G1XYZZ* B = buckets + (size_t)w * NB + (size_t)sl * K;
+  const int sg = sg_base + sl;
   const int k0 = sg * K;
-  const G1XYZZ* B = buckets + (size_t)w * NB + k0;
   G1XYZZ run = G1XYZZ::inf(), tot = G1XYZZ::inf();
   for (int j = K - 1; j >= 0; j--) {
     run = g1_add(run, B[j]);
     tot = g1_add(tot, run);          // ends as sum_j (j+1) B[j]
   }
-  if (nseg % 64 == 0) {
+  if (nseg % 64 == 0 && sg_base % 64 == 0) {
     // k0 * run with k0 = sg * K: the 64 lanes of a wave hold consecutive sg, so the bits of sg above the lane bits are
     // wave-uniform and their conditional additions are uniform branches; only the six lane bits pay for both paths
     // (a per-lane double-and-add executes an addition at every bit as soon as any lane needs one).
@@ -640,9 +643,18 @@ G1XYZZ msm_finish_host(const MsmSlot& s) {
 // ---------------------------------------------------------------------------------------------
 bool msm_can_batch(const MsmPlan& pl) { return pl.Wb == 1 && pl.NB >= (1 << PART_LOW_BITS); }
 
-void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const MsmJob* jobs, int k, bool scalars_mont) {
+void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const MsmJob* jobs, int k, bool scalars_mont, G1XYZZ* ext_buckets) {
   if (k < 1 || k > MSM_MAX_JOBS) throw std::runtime_error("msm_enqueue_batch: 1..MSM_MAX_JOBS jobs");
+  if (ext_buckets && (k != 1 || pl.Wb != 1)) throw std::runtime_error("msm_enqueue_batch: bucket hand-off needs one job over a shared bucket set");
   if (k > 1 && !msm_can_batch(pl)) throw std::runtime_error("msm_enqueue_batch: plan cannot be batched");
+  for (int j = 0; j < k; j++) {
+    const bool tables = pl.table_stride != 0;
+    if (jobs[j].n >= (tables ? MSM_TABLE_MAX_TERMS : MSM_MAX_TERMS) || (tables && pl.W > MSM_TABLE_MAX_WINDOWS) || pl.W > MSM_MAX_WINDOWS) {
+      set_error("MSM of %ld terms over %d windows does not fit the entry encoding (%s)", jobs[j].n, pl.W,
+                tables ? "window tables: < 2^26 terms, <= 32 windows" : "< 2^31 terms, <= 64 windows");
+      throw HipFail{SONIC_ERR_INVALID_ARG};
+    }
+  }
   MsmBatchDev batch;
   memset(&batch, 0, sizeof batch);
   batch.k = k;
@@ -654,6 +666,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   }
   if (batch.tile0[k] == 0) for (int j = 1; j <= k; j++) batch.tile0[j] = 1;      // nothing to do: one idle workgroup keeps the chain uniform
   ws.reserve(n_total > 0 ? n_total : 1, pl, k);
+  G1XYZZ* const buckets = ext_buckets ? ext_buckets : ws.buckets.as<G1XYZZ>();
   const uint32_t jobstride = (uint32_t)pl.Wb * pl.NB;              // buckets per job
   const size_t M = (size_t)k * jobstride;
   const int keystride = pl.Wb == 1 ? 0 : pl.NB;
@@ -693,15 +706,16 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     LAUNCH(k_border_scatter, nblk, 256, 0, st, (const uint32_t*)off, (uint32_t)M, nblk, (const uint32_t*)hist_sc, ws.order.as<uint32_t>());
   }
   LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
-         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, ws.buckets.as<G1XYZZ>(), hm, hrecs,
+         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs,
          ws.heavy_items.as<HeavyItem>());
   LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
          pl.table_stride, (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
   LAUNCH(k_heavy_finish, HEAVY_GRID / 2, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
-         (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), ws.buckets.as<G1XYZZ>());
+         (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
+  if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)
   const int sets = k * pl.Wb;
   LAUNCH(k_bucket_segments, ceil_div((long)sets * pl.nseg, 256), 256, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), sets,
-         pl.NB, pl.K, pl.nseg, ws.segres.as<G1XYZZ>());
+         pl.NB, pl.K, pl.nseg, 0, ws.segres.as<G1XYZZ>());
   if (pl.nseg > 4096) {
     // sets with tens of thousands of segments: 256-way groups first (nseg is a power of two), then one tree per set
     const int group = 256, ngroups = pl.nseg / group;
@@ -710,6 +724,49 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     LAUNCH(k_window_sum, sets, 256, 0, st, (const G1XYZZ*)part, pl.Wb, pl.c, ngroups, batch);
   } else {
     LAUNCH(k_window_sum, sets, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), pl.Wb, pl.c, pl.nseg, batch);
+  }
+}
+
+// ---- one rank's share of an MSM whose BUCKETS are sharded across ranks ---------------------------------------------------
+// Every rank accumulates its term range into a full bucket set (msm_enqueue_batch with ext_buckets), the ranks exchange bucket
+// ranges (all-to-all), and each rank then owns `k` slices of ONE range of `len` buckets starting at bucket `base`:
+//   sum_{i < len} (base + i + 1) * (sum_s slices[s][i])
+// -- the element-wise curve addition of what the ranks sent, then the usual running sums with the range's weights.
+__global__ __launch_bounds__(256, 1) void k_sum_slices(const G1XYZZ* __restrict__ slices, int k, long len, G1XYZZ* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  G1XYZZ acc = slices[i];
+  for (int s = 1; s < k; s++) acc = g1_add(acc, slices[(size_t)s * len + i]);
+  out[i] = acc;
+}
+
+void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot) {
+  // buckets per running-sum segment of a slice: a rank's 1/world of the buckets leaves most of the chip idle, so the chain, not the
+  // work, is what counts -- shorter segments, more threads (tuning knob SONIC_SLICE_SEGMENT: 1, 2, 4 or 8)
+  static const int K_env = getenv("SONIC_SLICE_SEGMENT") ? atoi(getenv("SONIC_SLICE_SEGMENT")) : 0;
+  const int K = (K_env == 1 || K_env == 2 || K_env == 4 || K_env == 8) ? K_env : MSM_SLICE_SEGMENT;
+  if (k < 1 || len < K || len % MSM_SLICE_QUANTUM || base % MSM_SLICE_QUANTUM || base + len >= (1L << 31))
+    throw std::runtime_error("msm_reduce_slices_enqueue: slice length and base must be multiples of MSM_SLICE_QUANTUM");
+  const int nseg = (int)(len / K);
+  ws.buckets.ensure((size_t)len * sizeof(G1XYZZ));
+  ws.segres.ensure(((size_t)nseg + nseg / 256 + 2) * sizeof(G1XYZZ));
+  const G1XYZZ* B = d_slices;
+  if (k > 1) {
+    LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+    B = ws.buckets.as<G1XYZZ>();
+  }
+  LAUNCH(k_bucket_segments, ceil_div((long)nseg, 256), 256, 0, st, B, 1, (int)len, K, nseg, (int)(base / K), ws.segres.as<G1XYZZ>());
+  MsmBatchDev batch;
+  memset(&batch, 0, sizeof batch);
+  batch.k = 1;
+  batch.slot[0] = d_slot;
+  if (nseg > 4096) {
+    const int group = 256, ngroups = nseg / group;
+    G1XYZZ* part = ws.segres.as<G1XYZZ>() + (size_t)nseg;
+    LAUNCH(k_group_sum, ngroups, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), (long)nseg, group, part);
+    LAUNCH(k_window_sum, 1, 256, 0, st, (const G1XYZZ*)part, 1, c, ngroups, batch);
+  } else {
+    LAUNCH(k_window_sum, 1, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), 1, c, nseg, batch);
   }
 }
 

@@ -36,6 +36,11 @@ MsmPlan msm_plan_tables(long n, int c, int W, long table_stride);
 void msm_plan_set_segment(MsmPlan& p, int K);
 
 constexpr int MSM_MAX_WINDOWS = 64;
+// sorted entry = term index | window << 26 | sign << 31 over window tables (index < 2^26, window < 32), term index | sign << 31
+// otherwise: msm_enqueue_batch refuses anything else with SONIC_ERR_INVALID_ARG (srs_msm_plan never plans it)
+constexpr long MSM_TABLE_MAX_TERMS = 1L << 26;
+constexpr int MSM_TABLE_MAX_WINDOWS = 32;
+constexpr long MSM_MAX_TERMS = 1L << 31;
 
 // Per-MSM hand-off between the bulk kernels and the (deferred, batched) tail: the per-window sums.
 struct MsmSlot {
@@ -61,7 +66,15 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Af
 constexpr int MSM_MAX_JOBS = 8;
 struct MsmJob { const G1Affine* points; const Fr* scalars; long n; MsmSlot* slot; };
 bool msm_can_batch(const MsmPlan& pl);
-void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const MsmJob* jobs, int k, bool scalars_mont);
+// ext_buckets (k == 1, shared-bucket plan): the chain stops after the accumulation and leaves the NB bucket sums there
+// instead of reducing them -- the first half of an MSM whose buckets are sharded across ranks.
+void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const MsmJob* jobs, int k, bool scalars_mont,
+                       G1XYZZ* ext_buckets = nullptr);
+// The second half on the rank that owns bucket range [base, base + len): adds the k slices it received element-wise and
+// reduces them with the range's weights into d_slot (one window sum).  len and base are multiples of MSM_SLICE_QUANTUM.
+constexpr int MSM_SLICE_SEGMENT = 8;          // buckets per running-sum segment of a slice (shortest chain: nothing hides it)
+constexpr long MSM_SLICE_QUANTUM = 16384;     // = 2048 segments: whole 256-segment groups and wave-uniform segment bits
+void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot);
 
 // Host tail: Horner over the slot's window sums -> un-normalised XYZZ sum.
 G1XYZZ msm_finish_host(const MsmSlot& s);

@@ -300,4 +300,18 @@ void sparse_to_dense_enqueue(hipStream_t st, const int64_t* exps, const Fr* coef
   if (nt > 0) LAUNCH(k_sparse_to_dense, ceil_div(nt, 256), 256, 0, st, exps, coeffs, nt, lo, dense);
 }
 
+
+// out[i] = c[i] * b^{e[i]} for the terms of a sparse polynomial (e may be negative: pair = {b, b^-1}): one variable of a sparse
+// bivariate Laurent polynomial substituted (evalX / evalY, Utils.hs:17-21, on poly's sparse form)
+__global__ __launch_bounds__(256) void k_scale_terms(const int64_t* __restrict__ e, const Fr* __restrict__ c, long nt, const Fr* __restrict__ pair, Fr* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nt) return;
+  const int64_t ex = e[i];
+  const Fr base = ex >= 0 ? pair[0] : pair[1];
+  out[i] = fp_mul(c[i], fp_pow_u64(base, (uint64_t)(ex >= 0 ? ex : -ex)));
+}
+void scale_terms_enqueue(hipStream_t st, const int64_t* e, const Fr* c, long nt, const Fr* pair, Fr* out) {
+  if (nt > 0) LAUNCH(k_scale_terms, ceil_div(nt, 256), 256, 0, st, e, c, nt, pair, out);
+}
+
 }  // namespace sonic

@@ -15,6 +15,7 @@ void sub_k_of_y_enqueue(hipStream_t st, Fr* slot, const Fr* cs, const Fr* ypow_n
 void flag_nonzero_enqueue(hipStream_t st, const Fr* a, long n, int* flags, int bit);
 void fr_with_inverse_enqueue(hipStream_t st, const Fr* in, int k, Fr* out);
 void fr_mul_scalar_enqueue(hipStream_t st, const Fr* a, const Fr* b, Fr* out);
+void scale_terms_enqueue(hipStream_t st, const int64_t* e, const Fr* c, long nt, const Fr* pair, Fr* out);
 void sparse_to_dense_enqueue(hipStream_t st, const int64_t* exps, const Fr* coeffs, long nt, long lo, Fr* dense);
 
 }  // namespace sonic

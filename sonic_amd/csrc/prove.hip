@@ -20,10 +20,20 @@
 #include <vector>
 #include "internal.hpp"
 #include "poly.hpp"
+#include "fs.hpp"
 
 namespace sonic {
 
 enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
+// phases of a proof = the points at which the reference's prover draws (Protocol.hs:58,66,76,84-85; Signature.hs:48,60): what can be
+// computed once the draws up to there are known
+enum { PH_R = 1,      // R                                   (blinders)
+       PH_T = 2,      // T                                   (+ y)
+       PH_OPEN = 3,   // a, W_a, b, W_b, W_t, s              (+ z)
+       PH_HSCS = 4,   // S_j, s_j, W_j                       (+ y_j, z_j)
+       PH_HSCW = 5,   // C, s'_j, W'_j, Q_j                  (+ u)
+       PH_QV = 6,     // Q_v                                 (+ v)
+       PH_ALL = 0x7e };
 // Buckets per running-sum segment inside prove().  More buckets per segment = fewer small scalar multiplications (less work),
 // fewer = shorter dependent chains.  Batched groups hide their chains under other groups' accumulation, so they take the
 // work-optimal end; the group that finishes last has nothing left to hide under and takes a short chain.  Measured
@@ -173,6 +183,10 @@ struct sonic_prover {
   bool graph_tried = false;
   long proofs_done = 0;
   bool in_flight = false;                    // between sonic_prover_submit and sonic_prover_collect
+  // Which steps of the proof an enqueue runs (bit = phase; PH_ALL normally).  The Fiat-Shamir mode (sonic_prover_prove_fs) proves in
+  // six passes, each running exactly the MSMs whose challenges have become known: results of earlier passes stay in `slots` / `frout`.
+  uint32_t phases = 0x7e;
+  DevBuf frstd;                              // frout in standard form (frout itself stays Montgomery across passes)
   std::chrono::steady_clock::time_point t_begin, t_enq;
   bool prepared = false;
   DevBuf cq;
@@ -301,6 +315,10 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   HIP_OK(hipHostMalloc((void**)&p->h_fr, 32 * (3 + 2 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_flags, 4, hipHostMallocDefault));
   p->frout.alloc(sizeof(Fr) * (3 + 2 * Q));
+  p->frstd.alloc(sizeof(Fr) * (3 + 2 * Q));
+  HIP_OK(hipMemsetAsync(p->frout.p, 0, sizeof(Fr) * (3 + 2 * Q), st));
+  HIP_OK(hipMemsetAsync(p->slots.p, 0, sizeof(MsmSlot) * (7 + 5 * Q), st));          // W = 0: an empty sum until the slot's MSM has run
+  memset(p->h_slots, 0, sizeof(MsmSlot) * (7 + 5 * Q));
   auto mkev = [](hipEvent_t* e) { HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming)); };
   mkev(&p->ev_r1); mkev(&p->ev_sy0); mkev(&p->ev_t); mkev(&p->ev_su);
   p->ev_syj.resize(Q, nullptr);
@@ -372,7 +390,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
   // first one grows the workspaces), every address in it is owned by the handle.
-  const bool want_graph = p->use_graph && p->proofs_done >= 1 && !profiler().on;
+  const bool want_graph = p->use_graph && p->proofs_done >= 1 && !profiler().on && p->phases == PH_ALL;
   const bool replay = want_graph && p->graph != nullptr;
   const bool capturing = want_graph && !replay && !p->graph_tried;
   struct CaptureGuard {        // an error while capturing must not leave the stream in capture mode
@@ -407,11 +425,14 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   Lane* cur = nullptr;
   auto begin_group = [&](hipEvent_t e) { cur = &p->pick(e); cur->njobs = 0; };
   auto flush_group = [&](bool last = false) { run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last); cur->njobs = 0; };
-  auto commit = [&](const Fr* poly, long lo, long len, long maxm, long slot) {
+  auto on = [&](int ph) { return ((p->phases >> ph) & 1u) != 0; };
+  auto commit = [&](int ph, const Fr* poly, long lo, long len, long maxm, long slot) {
+    if (!on(ph)) return;
     if (cur->njobs == MSM_MAX_JOBS) flush_group();
     cur->jobs[cur->njobs++] = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
   };
-  auto open = [&](const Fr* poly, long lo, long len, const Fr* zp, Fr* fz, long slot) {
+  auto open = [&](int ph, const Fr* poly, long lo, long len, const Fr* zp, Fr* fz, long slot) {
+    if (!on(ph)) return;
     if (cur->njobs == MSM_MAX_JOBS) flush_group();
     Scratch& sc = cur->sc[cur->njobs];
     cur->jobs[cur->njobs++] = open_job(cur->st, srs, sc, poly, lo, len, zp, fz, &slots[slot], flags);
@@ -426,7 +447,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
   HIP_OK(hipMemcpyAsync(p->kpow.p, pw + (2 * n + 1), sizeof(Fr) * Q, hipMemcpyDeviceToDevice, ms));   // y^{n+1..n+Q} for k(y); pw is reused below
   ready(p->ev_sy0);
-  {
+  if (on(PH_T) || on(PH_OPEN)) {
     // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y), on its own stream          Protocol.hs:69-73, Constraints.hs:56-68
     hipStream_t ts = p->ts;
     HIP_OK(hipStreamWaitEvent(ts, p->ev_sy0, 0));          // ev_sy0 follows ev_r1 on the main stream
@@ -457,38 +478,40 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
 
   // ---- the MSM groups, largest first where its input allows ----
   Lane& lane_t = p->t_lane(p->ev_sy0);
-  eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);         // s(z,y)       :83
+  if (on(PH_OPEN)) eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);         // s(z,y)       :83
   begin_group(p->ev_r1);
-  commit(r1, r_lo, r_len, n, 0);                                                       // R            :63
-  open(r1, r_lo, r_len, pZ, &frout[0], 2);                                             // (a, W_a)     :79
-  open(r1, r_lo, r_len, pYZ, &frout[1], 3);                                            // (b, W_b)     :80
+  commit(PH_R, r1, r_lo, r_len, n, 0);                                                 // R            :63
+  open(PH_OPEN, r1, r_lo, r_len, pZ, &frout[0], 2);                                    // (a, W_a)     :79
+  open(PH_OPEN, r1, r_lo, r_len, pYZ, &frout[1], 3);                                   // (b, W_b)     :80
   flush_group();
   for (long j = 0; j < Q; j++) {
     Fr* syj = p->syj[j].as<Fr>();
     begin_group(p->ev_syj[j]);
-    if (p->prepared) commit(p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);            // S_j (diagonal part)   Signature.hs:42
-    else commit(syj, s_lo, s_len, d, 5 + 2 * j);                                     // S_j                   :42
-    open(syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);                        // (s_j, W_j)    :43
-    open(syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                          // W'_j          :54
+    if (p->prepared) commit(PH_HSCS, p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);   // S_j (diagonal part)   Signature.hs:42
+    else commit(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j                   :42
+    open(PH_HSCS, syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);               // (s_j, W_j)    :43
+    open(PH_HSCW, syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                 // W'_j          :54
     flush_group();
-    if (p->prepared)                                                                  // sum_q y_j^{n+q} C_q, Q-term MSM
+    if (p->prepared && on(PH_HSCS))                                                   // sum_q y_j^{n+q} C_q, Q-term MSM
       msm_enqueue(cur->st, cur->ws, p->cq_tab.p ? msm_plan_tables(Q, CQ_TAB_C, CQ_TAB_W, Q) : msm_plan(Q),
                   p->cq_tab.p ? p->cq_tab.as<G1Affine>() : p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
   }
   begin_group(p->ev_su);
-  commit(su, u_lo, u_len, d, 6 + 4 * Q);                                             // C             :52
-  for (long j = 0; j < Q; j++) open(su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
-  open(su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                                     // Q_v           :63
+  commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                    // C             :52
+  for (long j = 0; j < Q; j++) open(PH_HSCW, su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
+  open(PH_QV, su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                              // Q_v           :63
   flush_group();
-  HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
+  if (on(PH_T) || on(PH_OPEN)) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
   cur = &lane_t; cur->njobs = 0;
-  commit(t, t_lo, t_len, d, 1);                                                        // T            Protocol.hs:73
-  open(t, t_lo, t_len, pZ, nullptr, 4);                                                // W_t          :81
+  commit(PH_T, t, t_lo, t_len, d, 1);                                                  // T            Protocol.hs:73
+  open(PH_OPEN, t, t_lo, t_len, pZ, nullptr, 4);                                       // W_t          :81
   flush_group(true);
   for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
-  fr_from_mont_enqueue(ms, frout, 3 + 2 * Q);
+  Fr* frstd = p->frstd.as<Fr>();
+  HIP_OK(hipMemcpyAsync(frstd, frout, sizeof(Fr) * (3 + 2 * Q), hipMemcpyDeviceToDevice, ms));
+  fr_from_mont_enqueue(ms, frstd, 3 + 2 * Q);
   HIP_OK(hipMemcpyAsync(p->h_slots, slots, sizeof(MsmSlot) * KS, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(p->h_fr, frout, 32 * (3 + 2 * Q), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(p->h_fr, frstd, 32 * (3 + 2 * Q), hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(p->h_flags, flags, 4, hipMemcpyDeviceToHost, st));
   }  // !replay
   if (capturing) {
@@ -534,7 +557,8 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
       sums[i] = s;
     };
     bool folded = true;
-    for (int i = 0; i < K; i++) folded = folded && hs[i].W == 1;
+    const int KS = K + (p->prepared ? (int)Q : 0);          // the C_q halves of the S_j are folded by tail() too
+    for (int i = 0; i < KS; i++) folded = folded && hs[i].W == 1;
     if (folded) {
       for (int i = 0; i < K; i++) tail(i);
     } else {
@@ -593,6 +617,74 @@ int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof) {
   if (!p->in_flight) { set_error("sonic_prover_collect: nothing was submitted"); return SONIC_ERR_INVALID_ARG; }
   p->in_flight = false;
   return prove_finish(p, out_proof);
+}
+
+// ---- opt-in Fiat-Shamir transcript (fs.hpp) ----------------------------------------------------------------------
+// The challenges of the reference are `rnd` draws made AFTER certain proof elements exist; as hashes of those elements they
+// serialise the proof: R -> y -> T -> z -> openings -> y_j, z_j -> S_j.. -> u -> C.. -> v -> Q_v.  sonic_prover_prove_fs walks
+// that chain in six passes over the same enqueue (prove_enqueue with one phase bit each): every MSM of the proof still runs
+// exactly once, the polynomial building before it is repeated per pass (cheap), and between passes the host waits, reads the new
+// elements' canonical bytes and hashes.  The caller-supplied transcript stays the default and fast path (one pass, no waits).
+int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO, const uint8_t* cs, uint8_t out[32]) {
+  if (n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !out) return SONIC_ERR_INVALID_ARG;
+  Sha256 h;
+  h.update("sonic-hip/circuit/v1", 20);
+  FsTranscript::le64(h, n); FsTranscript::le64(h, Q);
+  h.update(wL, (size_t)(32 * Q * n)); h.update(wR, (size_t)(32 * Q * n)); h.update(wO, (size_t)(32 * Q * n)); h.update(cs, (size_t)(32 * Q));
+  h.finish(out);
+  return SONIC_OK;
+}
+
+int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t* proof, uint8_t* out) {
+  if (n < 1 || Q < 1 || d < 1 || !circuit_digest || !proof || !out) return SONIC_ERR_INVALID_ARG;
+  fs_challenges_of_proof(n, Q, d, circuit_digest, proof, out);
+  return SONIC_OK;
+}
+
+int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], const uint8_t blinder_seed[32], uint8_t* out_proof,
+                          uint8_t* out_transcript) {
+  if (!p || !circuit_digest || !blinder_seed || !out_proof) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  int rc = prove_args_ok(p, "sonic_prover_prove_fs");
+  if (rc) return rc;
+  const long n = p->n, Q = p->Q, d = srs_d(p->srs);
+  std::vector<uint8_t> tr(32 * (size_t)(8 + 2 * Q), 0), pf(sonic_proof_size(Q));
+  for (long k = 0; k < 4; k++) fs_blinder(blinder_seed, (uint32_t)k, &tr[32 * k]);
+  for (long k = 4; k < 8 + 2 * Q; k++) tr[32 * k] = 1;               // not drawn yet: any invertible value (results that use it are not read)
+  FsTranscript t;
+  t.init(n, Q, d, circuit_digest);
+  auto pass = [&](int ph) {
+    p->phases = 1u << ph;
+    int r = prove_enqueue(p, tr.data());
+    if (!r) r = prove_finish(p, pf.data());
+    else if (p->st) (void)hipStreamSynchronize(p->st);
+    p->phases = PH_ALL;
+    return r;
+  };
+  const uint8_t* R = pf.data(), * T = R + 96, * open = R + 192, * hscS = R + 576, * hscW = hscS + Q * 224, * Cc = hscW + Q * 224 + 96;
+  if ((rc = pass(PH_R))) return rc;
+  t.absorb("R", R, 96);
+  t.challenge("y", 0, &tr[32 * 4]);
+  if ((rc = pass(PH_T))) return rc;
+  t.absorb("T", T, 96);
+  t.challenge("z", 0, &tr[32 * 5]);
+  if ((rc = pass(PH_OPEN))) return rc;
+  t.absorb("open", open, 384);
+  for (long j = 0; j < Q; j++) { t.challenge("yj", (uint32_t)j, &tr[32 * (6 + j)]); t.challenge("zj", (uint32_t)j, &tr[32 * (6 + Q + j)]); }
+  if ((rc = pass(PH_HSCS))) return rc;
+  t.absorb("hscS", hscS, (size_t)Q * 224);
+  t.challenge("u", 0, &tr[32 * (6 + 2 * Q)]);
+  if ((rc = pass(PH_HSCW))) return rc;
+  {
+    std::string w(reinterpret_cast<const char*>(Cc), 96);
+    w.append(reinterpret_cast<const char*>(hscW), (size_t)Q * 224);
+    t.absorb("hscW", reinterpret_cast<const uint8_t*>(w.data()), w.size());
+  }
+  t.challenge("v", 0, &tr[32 * (7 + 2 * Q)]);
+  if ((rc = pass(PH_QV))) return rc;
+  memcpy(out_proof, pf.data(), pf.size());
+  if (out_transcript) memcpy(out_transcript, tr.data(), tr.size());
+  return SONIC_OK;
 }
 
 // Circuit-only precomputation for handles that prove more than once: C_q = Commit(d, P_q), P_q the q-th constraint's
@@ -768,6 +860,141 @@ int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, con
   API_END
 }
 
+// hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof (Signature.hs:32-72) for ANY sparse bivariate Laurent polynomial
+// s(X,Y) = sum_i c_i X^{ex_i} Y^{ey_i} (the reference's own signature; sonic_prover_hsc_prove above is the same sub-protocol for the
+// s(X,Y) of a circuit handle).  evalY y_j / evalX u (Utils.hs:17-21) scale every term by a power of the evaluation point and sum
+// the terms that share the remaining exponent; the commitments and openings are the usual MSM groups.
+struct BivTerms {
+  long nt = 0, lo = 0, len = 0;       // dense range of the variable that is kept
+  DevBuf keep, other, coeff;          // per term, sorted by the kept exponent: kept exponent, substituted exponent, coefficient (Montgomery)
+};
+static int biv_upload(hipStream_t st, int64_t nt, const int64_t* keep, const int64_t* other, const uint8_t* coeffs, BivTerms& out, int* d_flags) {
+  out.nt = nt;
+  long lo = 0, hi = 0;                // the range always holds exponent 0 (openPoly puts -f(z) there, CommitmentScheme.hs:43)
+  for (int64_t i = 0; i < nt; i++) { lo = std::min<long>(lo, keep[i]); hi = std::max<long>(hi, keep[i]); }
+  out.lo = lo; out.len = hi - lo + 1;
+  std::vector<int64_t> order(nt), k(nt), o(nt);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return keep[a] < keep[b]; });
+  std::vector<uint8_t> c(32 * (size_t)(nt ? nt : 1));
+  for (int64_t i = 0; i < nt; i++) { k[i] = keep[order[i]]; o[i] = other[order[i]]; memcpy(&c[32 * (size_t)i], coeffs + 32 * order[i], 32); }
+  out.keep.alloc(8 * (size_t)(nt ? nt : 1)); out.other.alloc(8 * (size_t)(nt ? nt : 1)); out.coeff.alloc(32 * (size_t)(nt ? nt : 1));
+  if (nt) {
+    HIP_OK(hipMemcpyAsync(out.keep.p, k.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(out.other.p, o.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(out.coeff.p, c.data(), 32 * (size_t)nt, hipMemcpyHostToDevice, st));
+    fr_to_mont_enqueue(st, out.coeff.as<Fr>(), nt, d_flags);
+  }
+  HIP_OK(hipStreamSynchronize(st));   // host staging goes out of scope
+  return SONIC_OK;
+}
+// dense[e - lo] = sum over the terms with kept exponent e of c * b^{other exponent}
+static void biv_eval_enqueue(hipStream_t st, const BivTerms& t, const Fr* pair, DevBuf& scaled, Fr* dense) {
+  HIP_OK(hipMemsetAsync(dense, 0, sizeof(Fr) * t.len, st));
+  scaled.ensure(sizeof(Fr) * (size_t)(t.nt ? t.nt : 1));
+  scale_terms_enqueue(st, t.other.as<int64_t>(), t.coeff.as<Fr>(), t.nt, pair, scaled.as<Fr>());
+  sparse_to_dense_enqueue(st, t.keep.as<int64_t>(), scaled.as<Fr>(), t.nt, t.lo, dense);
+}
+
+int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t* x_exps, const int64_t* y_exps, const uint8_t* coeffs,
+                         int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out) {
+  API_BEGIN
+  if (!srs || n_terms < 0 || (n_terms > 0 && (!x_exps || !y_exps || !coeffs)) || m < 0 || (m > 0 && !yzs) || !u || !v || !out) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  const long d = srs_d(srs);
+  bool neg_x = false, neg_y = false;
+  for (int64_t i = 0; i < n_terms; i++) {
+    neg_x = neg_x || x_exps[i] < 0; neg_y = neg_y || y_exps[i] < 0;
+    if (x_exps[i] < -8 * (d + 8) || x_exps[i] > 8 * (d + 8) || y_exps[i] < -8 * (d + 8) || y_exps[i] > 8 * (d + 8)) {
+      set_error("hscProve: exponent (%ld, %ld) is far outside the SRS", (long)x_exps[i], (long)y_exps[i]); return SONIC_ERR_SRS_INDEX; }
+  }
+  // `pow x e` with negative e (Utils.hs:18,21): substituting 0 divides by zero; so does opening at 0 a polynomial with negative exponents
+  for (int64_t j = 0; j < m; j++) {
+    if (bytes_are_zero(yzs + 64 * j, 32) && neg_y) { set_error("hscProve: y_%ld = 0 and s(X,Y) has negative powers of Y", (long)j); return SONIC_ERR_INEXACT_DIVISION; }
+    if (bytes_are_zero(yzs + 64 * j + 32, 32) && neg_x) { set_error("hscProve: z_%ld = 0 and s(X,Y) has negative powers of X", (long)j); return SONIC_ERR_INEXACT_DIVISION; }
+  }
+  if ((bytes_are_zero(u, 32) && neg_x) || (bytes_are_zero(v, 32) && neg_y)) { set_error("hscProve: u or v is zero and s(X,Y) has negative powers"); return SONIC_ERR_INEXACT_DIVISION; }
+  const long NS = 2 * m + 2, K = 4 * m + 2;
+  DevBuf S(sizeof(Fr) * NS), PR(sizeof(Fr) * 2 * NS), slots(sizeof(MsmSlot) * K), frout(sizeof(Fr) * (2 * m + 1)), flags(4), scaled;
+  int* fl = flags.as<int>();
+  HIP_OK(hipMemsetAsync(fl, 0, 4, st));
+  HIP_OK(hipMemsetAsync(frout.p, 0, sizeof(Fr) * (2 * m + 1), st));
+  BivTerms byx, byy;
+  biv_upload(st, n_terms, x_exps, y_exps, coeffs, byx, fl);      // keeps X: s(X, y_j)
+  biv_upload(st, n_terms, y_exps, x_exps, coeffs, byy, fl);      // keeps Y: s(u, Y)
+  {
+    std::vector<uint8_t> h(32 * (size_t)NS);
+    for (long j = 0; j < m; j++) { memcpy(&h[32 * j], yzs + 64 * j, 32); memcpy(&h[32 * (m + j)], yzs + 64 * j + 32, 32); }
+    memcpy(&h[32 * (2 * m)], u, 32); memcpy(&h[32 * (2 * m + 1)], v, 32);
+    HIP_OK(hipMemcpyAsync(S.p, h.data(), h.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+  }
+  fr_to_mont_enqueue(st, S.as<Fr>(), NS, fl);
+  fr_with_inverse_enqueue(st, S.as<Fr>(), (int)NS, PR.as<Fr>());
+  const Fr* P0 = PR.as<Fr>();
+  auto pY = [&](long j) { return P0 + 2 * j; };
+  auto pZ = [&](long j) { return P0 + 2 * (m + j); };
+  const Fr *pU = P0 + 2 * (2 * m), *pV = P0 + 2 * (2 * m + 1);
+  auto is_zero_pt = [&](const uint8_t* b) { return bytes_are_zero(b, 32); };
+  MsmSlot* sl = slots.as<MsmSlot>();
+  Fr* fo = frout.as<Fr>();
+  DevBuf sy(sizeof(Fr) * byx.len), su(sizeof(Fr) * byy.len);
+  Scratch sc[MSM_MAX_JOBS];
+  MsmWorkspace& ws = shared_msm_ws();
+  // an opening at 0 is only defined without negative exponents (checked above), where it is a shift (open_job_at_zero)
+  auto open_any = [&](Scratch& s_, const Fr* poly, long lo, long len, const Fr* zp, bool zero, Fr* fz, MsmSlot* slot) {
+    return zero ? open_job_at_zero(st, srs, poly, len, fz ? fz : s_.fz_discard.as<Fr>(), slot, fl)
+                : open_job(st, srs, s_, poly, lo, len, zp, fz, slot, fl);
+  };
+  for (auto& s_ : sc) s_.fz_discard.ensure(sizeof(Fr));
+  // slots: S_j = 3j, W_j = 3j + 1, W'_j = 3j + 2;  Q_j = 3m + j;  Q_v = 4m;  C = 4m + 1.   frout: s_j = j, s'_j = m + j
+  for (long j = 0; j < m; j++) {                                                       // Signature.hs:40-45, 54
+    biv_eval_enqueue(st, byx, pY(j), scaled, sy.as<Fr>());                             // evalY y_j sXY
+    MsmJob jobs[3];
+    jobs[0] = commit_job(st, srs, sy.as<Fr>(), byx.lo, byx.len, d, &sl[3 * j], fl);
+    jobs[1] = open_any(sc[1], sy.as<Fr>(), byx.lo, byx.len, pZ(j), is_zero_pt(yzs + 64 * j + 32), &fo[j], &sl[3 * j + 1]);
+    jobs[2] = open_any(sc[2], sy.as<Fr>(), byx.lo, byx.len, pU, is_zero_pt(u), nullptr, &sl[3 * j + 2]);
+    run_jobs(st, srs, ws, jobs, 3);
+  }
+  biv_eval_enqueue(st, byy, pU, scaled, su.as<Fr>());                                  // evalX u sXY          :51
+  {
+    MsmJob jobs[MSM_MAX_JOBS];
+    int k = 0;
+    auto flush = [&] { run_jobs(st, srs, ws, jobs, k); k = 0; };
+    jobs[k++] = commit_job(st, srs, su.as<Fr>(), byy.lo, byy.len, d, &sl[4 * m + 1], fl);                              // C    :52
+    for (long j = 0; j < m; j++) {                                                                                     // Q_j  :55
+      if (k == MSM_MAX_JOBS) flush();
+      jobs[k] = open_any(sc[k], su.as<Fr>(), byy.lo, byy.len, pY(j), is_zero_pt(yzs + 64 * j), &fo[m + j], &sl[3 * m + j]);
+      k++;
+    }
+    if (k == MSM_MAX_JOBS) flush();
+    jobs[k] = open_any(sc[k], su.as<Fr>(), byy.lo, byy.len, pV, is_zero_pt(v), &fo[2 * m], &sl[4 * m]);                // Q_v  :63
+    k++;
+    flush();
+  }
+  fr_from_mont_enqueue(st, fo, 2 * m + 1);
+  std::vector<MsmSlot> hs((size_t)K);
+  std::vector<uint8_t> hfr(32 * (size_t)(2 * m + 1));
+  HIP_OK(hipMemcpyAsync(hs.data(), sl, sizeof(MsmSlot) * K, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(hfr.data(), fo, hfr.size(), hipMemcpyDeviceToHost, st));
+  int hflags = read_flags(st, flags);
+  if (hflags) return flags_to_status(hflags, "hscProve");
+  std::vector<uint8_t> pts(96 * (size_t)K);
+  {
+    std::vector<G1XYZZ> sums((size_t)K);
+    for (long i = 0; i < K; i++) sums[i] = msm_finish_host(hs[i]);
+    g1_canonical_bytes_host_batch(sums.data(), (int)K, pts.data());
+  }
+  uint8_t* o = out;
+  auto putG = [&](long i) { memcpy(o, &pts[96 * (size_t)i], 96); o += 96; };
+  auto putF = [&](const uint8_t* b) { memcpy(o, b, 32); o += 32; };
+  for (long j = 0; j < m; j++) { putG(3 * j); putF(&hfr[32 * j]); putG(3 * j + 1); }                 // hscS
+  for (long j = 0; j < m; j++) { putF(&hfr[32 * (m + j)]); putG(3 * j + 2); putG(3 * m + j); }       // hscW
+  putG(4 * m); putG(4 * m + 1); putF(u); putF(v);                                                   // Qv, C, u, v
+  API_END
+}
+
 int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                 const uint8_t* cs, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript,
                 uint8_t* out_proof) {
@@ -911,6 +1138,40 @@ int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb
   int fl = read_flags(st, flags);
   if (fl) return flags_to_status(fl, "sonic_poly_mul_fr");
   HIP_OK(hipMemcpy(out, fa.p, 32 * rl, hipMemcpyDeviceToHost));
+  API_END
+}
+
+// the same product with both operands and the result resident in HBM (canonical Fr, device pointers; d_out: na + nb - 1
+// elements): what bench.py times for the NTT roofline -- the three transforms and the pointwise product alone on the chip
+int sonic_poly_mul_fr_dev(const void* d_a, int64_t na, const void* d_b, int64_t nb, void* d_out) {
+  API_BEGIN
+  if (!d_a || !d_b || !d_out || na < 1 || nb < 1) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(call_mutex());
+  hipStream_t st = default_stream();
+  const long rl = na + nb - 1;
+  int lg = 0;
+  while ((1L << lg) < rl) lg++;
+  const long M = 1L << lg;
+  static DevBuf* fa = new DevBuf(); static DevBuf* fb = new DevBuf(); static DevBuf* flags = new DevBuf(4);
+  fa->ensure(sizeof(Fr) * M); fb->ensure(sizeof(Fr) * M);
+  HIP_OK(hipMemsetAsync(flags->p, 0, 4, st));
+  HIP_OK(hipMemsetAsync(fa->p, 0, sizeof(Fr) * M, st));
+  HIP_OK(hipMemsetAsync(fb->p, 0, sizeof(Fr) * M, st));
+  HIP_OK(hipMemcpyAsync(fa->p, d_a, 32 * na, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(fb->p, d_b, 32 * nb, hipMemcpyDeviceToDevice, st));
+  fr_to_mont_enqueue(st, fa->as<Fr>(), na, flags->as<int>());
+  fr_to_mont_enqueue(st, fb->as<Fr>(), nb, flags->as<int>());
+  if (lg > 0) {
+    shared_ntt().ensure(st, lg);
+    ntt_forward_enqueue(st, shared_ntt(), fa->as<Fr>(), lg);
+    ntt_forward_enqueue(st, shared_ntt(), fb->as<Fr>(), lg);
+  }
+  fr_pointwise_mul_enqueue(st, fa->as<Fr>(), fb->as<Fr>(), M);
+  if (lg > 0) ntt_inverse_enqueue(st, shared_ntt(), fa->as<Fr>(), lg);
+  fr_from_mont_enqueue(st, fa->as<Fr>(), rl);
+  HIP_OK(hipMemcpyAsync(d_out, fa->p, 32 * rl, hipMemcpyDeviceToDevice, st));
+  int fl = read_flags(st, *flags);
+  if (fl) return flags_to_status(fl, "sonic_poly_mul_fr_dev");
   API_END
 }
 

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_g2_points_to_bytes(const G2Affine* __re
 
 // Caller-supplied G2 elements (an SRS file, sonic_srs_set_g2_points): canonical coordinates, on the twist
 // y^2 = x^3 + 4(u + 1), and r P = O (E'(Fq2) has a large cofactor and the pairing is bilinear only on the order-r
-// subgroup).  err bits as on the G1 side: 1 non-canonical, 2 off the curve, 4 outside the subgroup.
+// subgroup).  err bits as on the G1 side: 1 non-canonical, 2 off the curve, 4 outside the subgroup, 8 the point at infinity.
 __global__ __launch_bounds__(64, 1) void k_g2_points_from_bytes(const uint8_t* __restrict__ in, G2Affine* __restrict__ out, long n, int* err) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(64, 1) void k_g2_points_from_bytes(const uint8_t* _
   }
   uint32_t nz = 0;
   for (int k = 0; k < 48; k++) nz |= w[k];
-  if (!nz) { out[i] = G2Affine::inf(); return; }
+  // h^{x^e} and h^{alpha x^e} are never the identity (x, alpha != 0): a zero-filled section must not validate -- the verifier's
+  // pairing with a G2 element at infinity is 1, and with all three at infinity it would accept every proof
+  if (!nz) { atomicOr(err, 8); out[i] = G2Affine::inf(); return; }
   p.x.c0 = fp_to_mont(p.x.c0); p.x.c1 = fp_to_mont(p.x.c1); p.y.c0 = fp_to_mont(p.y.c0); p.y.c1 = fp_to_mont(p.y.c1);
   Fq2 b; b.c0 = fp_dbl(fp_dbl(Fq::one())); b.c1 = b.c0;
   if (!(f2_sqr(p.y) == f2_add(f2_mul(f2_sqr(p.x), p.x), b))) { atomicOr(err, 2); out[i] = G2Affine::inf(); return; }

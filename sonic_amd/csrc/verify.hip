@@ -12,11 +12,13 @@
 // polynomial-basis pairing of rounds 1-2, now tests/pairing_plain.hpp, took 170 ms).
 #include <string.h>
 #include <algorithm>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include "internal.hpp"
 #include "g2.hpp"
 #include "pairing.hpp"
+#include "fs.hpp"
 
 namespace sonic {
 namespace {
@@ -67,6 +69,9 @@ int fetch_g2(const sonic_srs* srs, int basis, int64_t e, G2Affine& out) {
   int rc = sonic_srs_get_g2_points(srs, basis, e, 1, b);
   if (rc) return rc;
   load_g2(b, out);
+  // fail closed: the Miller loop of a G2 element at infinity is 1, so a verifier key at infinity would accept anything.  No valid
+  // SRS (x, alpha != 0) holds one; sonic_srs_set_g2_points / sonic_srs_load refuse them, this is the second line of defence.
+  if (out.is_inf()) { set_error("verifier: the SRS holds the point at infinity as G2 element (basis %d, exponent %ld)", basis, (long)e); return SONIC_ERR_BAD_ENCODING; }
   return SONIC_OK;
 }
 
@@ -115,15 +120,31 @@ int run_checks(const sonic_srs* srs, const VerifierKey& vk, const std::vector<Pc
   }
   std::vector<char> ok(checks.size(), 0);
   const int nt = (int)std::min<size_t>(checks.size(), 16);
+  auto work = [&](int w, int stride) {
+    for (size_t i = w; i < checks.size(); i += stride)
+      ok[i] = pc_v_equation(vk, elems[which[i]], checks[i].F, checks[i].z, checks[i].val, checks[i].W) ? 1 : 0;
+  };
   std::vector<std::thread> th;
-  for (int w = 0; w < nt; w++)
-    th.emplace_back([&, w] {
-      for (size_t i = w; i < checks.size(); i += nt)
-        ok[i] = pc_v_equation(vk, elems[which[i]], checks[i].F, checks[i].z, checks[i].val, checks[i].W) ? 1 : 0;
-    });
+  int started = 0;
+  try {
+    for (; started < nt; started++) th.emplace_back(work, started, nt);
+  } catch (const std::system_error&) {}        // thread limit of the host process: the calling thread takes the rest
+  for (int w = started; w < nt; w++) work(w, nt);
   for (auto& t : th) t.join();
   for (char c : ok) all = all && c;
   return SONIC_OK;
+}
+
+// the 3m + 1 pcV checks of hscVerify (Signature.hs:82-89) once s(u,v) is known
+void hsc_push_checks(int64_t d, int64_t m, const std::vector<Fr>& ys, const std::vector<Fr>& zs, const std::vector<G1Affine>& Sj, const std::vector<Fr>& sj,
+                     const std::vector<G1Affine>& Wj, const std::vector<Fr>& spj, const std::vector<G1Affine>& Wpj, const std::vector<G1Affine>& Qj,
+                     const G1Affine& Qv, const G1Affine& C, const Fr& u, const Fr& v, const Fr& sv, std::vector<PcvCheck>& checks) {
+  for (int64_t j = 0; j < m; j++) {                                // Signature.hs:82-88
+    checks.push_back(PcvCheck{d, Sj[j], zs[j], sj[j], Wj[j]});
+    checks.push_back(PcvCheck{d, Sj[j], u, spj[j], Wpj[j]});
+    checks.push_back(PcvCheck{d, C, ys[j], spj[j], Qj[j]});
+  }
+  checks.push_back(PcvCheck{d, C, v, sv, Qv});                     // Signature.hs:89
 }
 
 // hscVerify srs sXY yzs proof (Signature.hs:74-90) for the s(X,Y) of a circuit (Constraints.hs:34-53): s(u,v) on the host,
@@ -149,13 +170,7 @@ int hsc_checks(const sonic_srs* srs, const VerifierKey& vk, int64_t n, int64_t Q
     Wi = fp_sub(fp_sub(Wi, vp), vm);
     sv = fp_add(sv, fp_add(fp_add(fp_mul(um, Ui), fp_mul(up, Vi)), fp_mul(fp_mul(up, un), Wi)));
   }
-  const int64_t d = srs_d(srs);
-  for (int64_t j = 0; j < m; j++) {                                // Signature.hs:82-88
-    checks.push_back(PcvCheck{d, Sj[j], zs[j], sj[j], Wj[j]});
-    checks.push_back(PcvCheck{d, Sj[j], u, spj[j], Wpj[j]});
-    checks.push_back(PcvCheck{d, C, ys[j], spj[j], Qj[j]});
-  }
-  checks.push_back(PcvCheck{d, C, v, sv, Qv});                     // Signature.hs:89
+  hsc_push_checks(srs_d(srs), m, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, sv, checks);
   return SONIC_OK;
 }
 
@@ -181,6 +196,7 @@ int sonic_pc_v(const sonic_srs_t* srs, int64_t max, const uint8_t commitment[96]
     *accepted = ok ? 1 : 0;
     return rc;
   } catch (const HipFail& f) { return f.code; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
 }
 
 // verify srs circuit proof y z yzs  (Protocol.hs:111-130); yzs = Q pairs (y_j, z_j), 64 bytes each
@@ -223,6 +239,28 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
     *accepted = all ? 1 : 0;
     return SONIC_OK;
   } catch (const HipFail& f) { return f.code; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
+}
+
+// verify for a proof made by sonic_prover_prove_fs: the challenges y, z, (y_j, z_j) are not handed over (RndOracle) but recomputed from
+// the statement and the proof (fs.hpp), and the proof's u, v must be the ones its own transcript yields
+int sonic_verify_fs(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+                    const uint8_t* cs, const uint8_t* proof, int* accepted) {
+  try {
+    if (!srs || n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !proof || !accepted) return SONIC_ERR_INVALID_ARG;
+    *accepted = 0;
+    uint8_t digest[32];
+    int rc = sonic_fs_circuit_digest(n, Q, wL, wR, wO, cs, digest);
+    if (rc) return rc;
+    std::vector<uint8_t> ch(32 * (size_t)(4 + 2 * Q));
+    fs_challenges_of_proof(n, Q, srs_d(srs), digest, proof, ch.data());
+    const uint8_t* uv = proof + sonic_proof_size(Q) - 64;
+    if (memcmp(uv, &ch[32 * (2 + 2 * Q)], 64) != 0) return SONIC_OK;          // u, v are not this transcript's: rejected
+    std::vector<uint8_t> yzs(64 * (size_t)Q);
+    for (int64_t j = 0; j < Q; j++) { memcpy(&yzs[64 * j], &ch[32 * (2 + j)], 32); memcpy(&yzs[64 * j + 32], &ch[32 * (2 + Q + j)], 32); }
+    return sonic_verify(srs, n, Q, wL, wR, wO, cs, proof, &ch[0], &ch[32], yzs.data(), accepted);
+  } catch (const HipFail& f) { return f.code; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
 }
 
 // hscVerify :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> HscProof -> Bool (Signature.hs:74-90) for the s(X,Y) of a circuit;
@@ -256,6 +294,52 @@ int sonic_hsc_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
     *accepted = all ? 1 : 0;
     return SONIC_OK;
   } catch (const HipFail& f) { return f.code; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
+}
+
+
+// hscVerify :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> HscProof -> Bool (Signature.hs:74-90) for any sparse bivariate Laurent polynomial
+// (the counterpart of sonic_hsc_prove_poly): s(u,v) = eval (evalY v sXY) u on the host, then the 3m + 1 pcV checks
+int sonic_hsc_verify_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t* x_exps, const int64_t* y_exps, const uint8_t* coeffs,
+                          int64_t m, const uint8_t* yzs, const uint8_t* hsc, int* accepted) {
+  try {
+    if (!srs || n_terms < 0 || (n_terms > 0 && (!x_exps || !y_exps || !coeffs)) || m < 0 || (m > 0 && !yzs) || !hsc || !accepted) return SONIC_ERR_INVALID_ARG;
+    *accepted = 0;
+    const uint8_t* p = hsc;
+    auto G = [&](G1Affine& o) { bool k = load_g1(p, o); p += 96; return k; };
+    auto F = [&](Fr& o) { bool k = load_fr(p, o); p += 32; return k; };
+    std::vector<G1Affine> Sj(m), Wj(m), Wpj(m), Qj(m);
+    std::vector<Fr> sj(m), spj(m), ys(m), zs(m);
+    G1Affine Qv, C; Fr u, v;
+    bool enc = true;
+    for (int64_t j = 0; j < m; j++) enc = enc && G(Sj[j]) && F(sj[j]) && G(Wj[j]);
+    for (int64_t j = 0; j < m; j++) enc = enc && F(spj[j]) && G(Wpj[j]) && G(Qj[j]);
+    enc = enc && G(Qv) && G(C) && F(u) && F(v);
+    for (int64_t j = 0; j < m; j++) enc = enc && load_fr(yzs + 64 * j, ys[j]) && load_fr(yzs + 64 * j + 32, zs[j]);
+    if (!enc) { set_error("hscVerify: non-canonical field element, or point off the curve or outside the order-r subgroup"); return SONIC_ERR_BAD_ENCODING; }
+    Fr sv = Fr::zero();
+    const Fr uinv = u.is_zero() ? u : fp_inv(u), vinv = v.is_zero() ? v : fp_inv(v);
+    for (int64_t i = 0; i < n_terms; i++) {
+      Fr c;
+      if (!load_fr(coeffs + 32 * i, c)) { set_error("hscVerify: non-canonical coefficient"); return SONIC_ERR_BAD_ENCODING; }
+      const int64_t ex = x_exps[i], ey = y_exps[i];
+      if ((ex < 0 && u.is_zero()) || (ey < 0 && v.is_zero())) { set_error("hscVerify: u or v is zero and s(X,Y) has negative powers"); return SONIC_ERR_INEXACT_DIVISION; }
+      const Fr px = fr_pow(ex >= 0 ? u : uinv, (uint64_t)(ex >= 0 ? ex : -ex)), py = fr_pow(ey >= 0 ? v : vinv, (uint64_t)(ey >= 0 ? ey : -ey));
+      sv = fp_add(sv, fp_mul(c, fp_mul(px, py)));
+    }
+    VerifierKey vk;
+    int rc = fetch_g2(srs, 1, 0, vk.h_alpha);
+    if (!rc) rc = fetch_g2(srs, 1, 1, vk.h_alpha_x);
+    if (rc) return rc;
+    bool all = true;
+    std::vector<PcvCheck> checks;
+    hsc_push_checks(srs_d(srs), m, ys, zs, Sj, sj, Wj, spj, Wpj, Qj, Qv, C, u, v, sv, checks);
+    rc = run_checks(srs, vk, checks, all);
+    if (rc) return rc;
+    *accepted = all ? 1 : 0;
+    return SONIC_OK;
+  } catch (const HipFail& f) { return f.code; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
 }
 
 }  // extern "C"

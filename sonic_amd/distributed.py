@@ -1,15 +1,25 @@
 """Multi-GPU plumbing for the one step of the path that shards inside a single MSM.
 
-sum_i s_i * P_i is a sum of independent terms: rank r takes a contiguous slice of the term range on
-its own (replicated) SRS, runs the full bucket method on the slice, and contributes one un-normalised
-XYZZ partial (192 bytes).  RCCL has no elliptic-curve reduction op, so the exchange is an all-gather of
-the partials followed by k-1 curve additions + one normalisation on every rank
-(sonic_g1_sum_partials).  prove() itself shards by proof and needs no collective.
+sum_i s_i * P_i (the folds at src/Sonic/CommitmentScheme.hs:25-29, 45-48) is a sum of independent terms; one process per GPU,
+SRS replicated, and two ways of splitting ONE MSM over the ranks:
+
+* by TERM range (`ShardedMsm.run_terms`, weak-scaling layout of bench.py): rank r runs the whole bucket method on its slice and
+  contributes one un-normalised XYZZ partial (192 bytes); all-gather of the partials, k-1 curve additions + one normalisation on
+  every rank.  No bulk traffic, but every rank reduces a full bucket set, which does not shrink with the shard.
+* by BUCKET range (`ShardedMsm.run_buckets`, strong scaling): rank r accumulates its term slice into a full bucket set, the ranks
+  exchange bucket ranges with ONE all-to-all (n_buckets x 192 B / world per pair: 12.6 MB at 2^19 buckets over 8 ranks), each
+  rank adds the slices it received and reduces only its 1/world of the buckets; then the same 192-byte all-gather.
+
+RCCL has no elliptic-curve reduction op, so both end in a gather + local curve additions, never an all-reduce.  The collectives
+run on device tensors ordered on one HIP stream with the lane's kernels (sonic_msm_lane_new_on_stream): nothing visits the host
+between the scalars in HBM and the gathered partials, which come back in ONE device-to-host copy.  With the gloo backend (tests:
+several ranks on one GPU, or no GPU at all) the same exchanges are staged through host tensors.  prove() itself shards by proof
+and needs no collective.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -34,19 +44,28 @@ def split_range(n: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, min(n, lo + per)
 
 
+def _pg_active() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def allgather_partials(partial: np.ndarray, world: int, device=None) -> np.ndarray:
-    """all-gather of the 192-byte partials over torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU)"""
+    """all-gather of HOST 192-byte partials over torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU).  Runs the
+    collective whenever a process group exists -- also a group of one rank; without a group (a plain single-process run) it is
+    the identity.  The device-resident exchange is ShardedMsm."""
     part = np.ascontiguousarray(partial, np.uint8).reshape(PARTIAL_BYTES)
-    if world == 1:
+    if not _pg_active():
+        if world != 1:
+            raise RuntimeError("allgather_partials: world > 1 without a process group")
         return part.copy()
     import torch
     import torch.distributed as dist
     mine = torch.from_numpy(part.copy())
     if device is not None:
         mine = mine.to(device)
-    out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine)
-    return np.concatenate([o.cpu().numpy() for o in out])
+    out = torch.empty(world * PARTIAL_BYTES, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.cpu().numpy()
 
 
 def sum_partials(partials: np.ndarray, k: int) -> bytes:
@@ -55,3 +74,134 @@ def sum_partials(partials: np.ndarray, k: int) -> bytes:
     out = C.create_string_buffer(96)
     _lib.check(_lib.lib().sonic_g1_sum_partials(p.ctypes.data, k, out))
     return out.raw
+
+
+def exchange_layout(srs, world: int) -> Tuple[int, int]:
+    """(buckets of the shared bucket set, slice length S) for a bucket exchange over `world` ranks"""
+    nb, s = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib().sonic_msm_exchange_layout(srs._h, world, C.byref(nb), C.byref(s)))
+    return nb.value, s.value
+
+
+class ShardedMsm:
+    """One rank's end of MSMs that are split over the ranks of the default process group (or of a single process when no
+    group exists).  Owns a HIP stream (torch), a lane on that stream, and the device tensors the collectives move.
+
+    device: torch cuda device of this rank.  staged=None: collectives on device tensors iff the backend is nccl."""
+
+    def __init__(self, srs, rank: int, world: int, device, staged: Optional[bool] = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.srs, self.rank, self.world, self.device = srs, rank, world, device
+        self.pg = _pg_active()
+        if world > 1 and not self.pg:
+            raise RuntimeError("ShardedMsm: world > 1 needs an initialised process group")
+        if staged is None:
+            staged = self.pg and dist.get_backend() != "nccl"
+        self.staged = staged
+        self.stream = torch.cuda.Stream(device=device)
+        self._lane = C.c_void_p()
+        _lib.check(_lib.lib().sonic_msm_lane_new_on_stream(C.c_void_p(self.stream.cuda_stream), C.byref(self._lane)))
+        with torch.cuda.stream(self.stream):          # allocated and cleared on the stream everything else here is ordered on
+            self.part = torch.zeros(PARTIAL_BYTES, dtype=torch.uint8, device=device)
+            self.gathered = torch.zeros(world * PARTIAL_BYTES, dtype=torch.uint8, device=device)
+        self.buckets = self.recv = None
+        self.n_buckets = self.slice_len = 0
+        self._layout_world = 0
+
+    # -- shared tail: all-gather of the 192-byte partials (device tensors, or staged through the host for gloo), ONE copy to the host
+    def _gather_and_sum(self) -> bytes:
+        torch, dist = self.torch, self.dist
+        if self.pg and not self.staged:
+            dist.all_gather_into_tensor(self.gathered, self.part)
+            host = self.gathered.cpu()                                   # the one device-to-host copy (waits for the stream)
+        elif self.pg:
+            mine = self.part.cpu()
+            host = torch.empty(self.world * PARTIAL_BYTES, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, mine)
+        else:
+            host = self.part.cpu()
+        _lib.check(_lib.lib().sonic_msm_lane_sync(self._lane))            # the stream has drained: reports non-canonical scalars
+        return sum_partials(host.numpy(), self.world)
+
+    def run_terms(self, basis: int, e0: int, d_scalars, n: int) -> bytes:
+        """this rank's term slice [e0, e0 + n) through the whole bucket method; partials gathered on the device"""
+        L = _lib.lib()
+        sets = C.c_int()
+        _lib.check(L.sonic_msm_plan(self.srs._h, n, None, None, C.byref(sets)))
+        with self.torch.cuda.stream(self.stream):
+            if n > 0 and sets.value == 1:
+                _lib.check(L.sonic_msm_submit_dev(self._lane, self.srs._h, basis, e0, d_scalars, n, C.c_void_p(self.part.data_ptr())))
+            elif n > 0:
+                # no single window sum on the device (no window tables, or a slice too small for them): the host folds the
+                # window sums (sonic_msm_collect) and the partial goes back up for the gather
+                _lib.check(L.sonic_msm_submit(self._lane, self.srs._h, basis, e0, d_scalars, n))
+                h = C.create_string_buffer(PARTIAL_BYTES)
+                _lib.check(L.sonic_msm_collect(self._lane, None, h))
+                self.part.copy_(self.torch.frombuffer(bytearray(h.raw), dtype=self.torch.uint8))
+            else:
+                self.part.zero_()
+            res = self._gather_and_sum()
+        if n > 0 and sets.value == 1:
+            _lib.check(L.sonic_msm_collect(self._lane, None, None))       # closes the submit (stream already drained)
+        return res
+
+    def _ensure_exchange(self, world: int):
+        if self.buckets is None or self.buckets.numel() != world * self.slice_len * PARTIAL_BYTES or self._layout_world != world:
+            self.n_buckets, self.slice_len = exchange_layout(self.srs, world)
+            self._layout_world = world
+            nbytes = world * self.slice_len * PARTIAL_BYTES
+            with self.torch.cuda.stream(self.stream):
+                self.buckets = self.torch.zeros(nbytes, dtype=self.torch.uint8, device=self.device)
+                self.recv = self.torch.zeros(nbytes, dtype=self.torch.uint8, device=self.device)
+
+    def run_buckets(self, basis: int, e0: int, d_scalars, n: int) -> bytes:
+        """this rank's term slice accumulated into a full bucket set, bucket ranges exchanged (all-to-all), 1/world of the
+        buckets reduced here, partials gathered"""
+        L, torch, dist = _lib.lib(), self.torch, self.dist
+        self._ensure_exchange(self.world)
+        S = self.slice_len
+        with torch.cuda.stream(self.stream):
+            _lib.check(L.sonic_msm_accumulate_dev(self._lane, self.srs._h, basis, e0, d_scalars, n,
+                                                  C.c_void_p(self.buckets.data_ptr()), self.world * S))
+            if self.pg and not self.staged:
+                dist.all_to_all_single(self.recv, self.buckets)           # equal splits: S x 192 B per pair
+            elif self.pg:
+                src = self.buckets.cpu()
+                dst = torch.empty_like(src)
+                dist.all_to_all_single(dst, src)
+                self.recv.copy_(dst)
+            else:
+                self.recv.copy_(self.buckets)
+            _lib.check(L.sonic_msm_reduce_slices_dev(self._lane, self.srs._h, C.c_void_p(self.recv.data_ptr()), self.world, S,
+                                                     self.rank * S, C.c_void_p(self.part.data_ptr())))
+            return self._gather_and_sum()
+
+    def run_buckets_emulated(self, basis: int, e0: int, d_scalars, n: int, world_emul: int, rank_emul: int = 0) -> None:
+        """TIMING ONLY (one GPU standing in for one of `world_emul` ranks): the accumulation of a 1/world share of the terms, a
+        device-to-device copy of as many bytes as this rank's all-to-all would send and receive, the element-wise addition of
+        world_emul slices and the reduction of 1/world_emul of the buckets.  The slices added are this rank's own, so the
+        value is meaningless; the work and the traffic are those of the real exchange minus the xGMI hop."""
+        L, torch = _lib.lib(), self.torch
+        self._ensure_exchange(world_emul)
+        S = self.slice_len
+        with torch.cuda.stream(self.stream):
+            _lib.check(L.sonic_msm_accumulate_dev(self._lane, self.srs._h, basis, e0, d_scalars, n,
+                                                  C.c_void_p(self.buckets.data_ptr()), world_emul * S))
+            self.recv.copy_(self.buckets)
+            _lib.check(L.sonic_msm_reduce_slices_dev(self._lane, self.srs._h, C.c_void_p(self.recv.data_ptr()), world_emul, S,
+                                                     rank_emul * S, C.c_void_p(self.part.data_ptr())))
+            self.part.cpu()
+        _lib.check(L.sonic_msm_lane_sync(self._lane))
+
+    def close(self):
+        if self._lane:
+            _lib.lib().sonic_msm_lane_free(self._lane)
+            self._lane = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -179,6 +179,14 @@ class Prover:
         _lib.check(_lib.lib().sonic_prover_collect(self._h, out))
         return out.raw
 
+    def prove_fs(self, circuit_digest: bytes, blinder_seed: bytes):
+        """prove with the opt-in Fiat-Shamir transcript (sonic_prover_prove_fs): returns (proof bytes, the 8 + 2Q transcript values
+        the proof was made with); six waits for the GPU instead of one"""
+        out = C.create_string_buffer(_lib.lib().sonic_proof_size(self.Q))
+        tr = C.create_string_buffer(32 * transcript_len(self.Q))
+        _lib.check(_lib.lib().sonic_prover_prove_fs(self._h, bytes(circuit_digest), bytes(blinder_seed), out, tr))
+        return out.raw, [int.from_bytes(tr.raw[32 * i:32 * i + 32], "little") for i in range(transcript_len(self.Q))]
+
     def hsc_prove(self, yzs, u: int, v: int) -> HscProof:
         """hscProve srs sXY yzs (Signature.hs:32-72) for the s(X,Y) of this handle's circuit; u, v: its two `rnd` draws"""
         yzs = list(yzs)
@@ -256,6 +264,59 @@ def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: O
     return Proof.from_bytes(raw, Q), oracle
 
 
+def _circuit_arrays(circuit: ArithCircuit):
+    w = circuit.weights
+    wL, wR, wO = fr_matrix(w.wL), fr_matrix(w.wR), fr_matrix(w.wO)
+    cs = fr_array(circuit.cs)
+    Q = cs.shape[0]
+    if Q < 1 or wL.shape[0] % Q or wL.shape[0] == 0 or wR.shape != wL.shape or wO.shape != wL.shape:
+        raise ValueError("need Q >= 1 weight rows of equal length n >= 1 in wL, wR, wO")
+    return wL, wR, wO, cs, wL.shape[0] // Q, Q
+
+
+def fs_circuit_digest(circuit: ArithCircuit) -> bytes:
+    """SHA-256 of (n, Q, wL, wR, wO, cs): the statement part of the Fiat-Shamir transcript, once per circuit"""
+    wL, wR, wO, cs, n, Q = _circuit_arrays(circuit)
+    out = C.create_string_buffer(32)
+    _lib.check(_lib.lib().sonic_fs_circuit_digest(n, Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data, cs.ctypes.data, out))
+    return out.raw
+
+
+def fs_challenges(srs: SRS, circuit: ArithCircuit, proof: Proof) -> RndOracle:
+    """the RndOracle a Fiat-Shamir proof determines (sonic_fs_challenges)"""
+    wL, wR, wO, cs, n, Q = _circuit_arrays(circuit)
+    out = C.create_string_buffer(32 * (4 + 2 * Q))
+    _lib.check(_lib.lib().sonic_fs_challenges(n, Q, srs.srsD, fs_circuit_digest(circuit), proof.to_bytes(), out))
+    v = [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(4 + 2 * Q)]
+    return RndOracle(v[0], v[1], list(zip(v[2:2 + Q], v[2 + Q:2 + 2 * Q])))
+
+
+def prove_fs(srs: SRS, assignment: Assignment, circuit: ArithCircuit, blinder_seed: Optional[bytes] = None):
+    """prove with every `rnd` draw of the reference (Protocol.hs:58,66,76,84-85; Signature.hs:48,60) replaced by the hash of what
+    precedes it: (Proof, RndOracle); the blinders come from `blinder_seed` (32 bytes, default fresh)"""
+    seed = secrets.token_bytes(32) if blinder_seed is None else bytes(blinder_seed)
+    p = Prover(srs, circuit, prepare=False)
+    try:
+        p.set_assignment(assignment)
+        raw, t = p.prove_fs(fs_circuit_digest(circuit), seed)
+    finally:
+        p.close()
+    Q = p.Q
+    return Proof.from_bytes(raw, Q), RndOracle(t[4], t[5], list(zip(t[6:6 + Q], t[6 + Q:6 + 2 * Q])))
+
+
+def verify_fs(srs: SRS, circuit: ArithCircuit, proof: Proof) -> bool:
+    """verify for a Fiat-Shamir proof: the challenges are recomputed from the circuit and the proof (sonic_verify_fs)"""
+    wL, wR, wO, cs, n, Q = _circuit_arrays(circuit)
+    h = proof.prHscProof
+    if len(h.hscS) != Q or len(h.hscW) != Q:
+        return False
+    raw = proof.to_bytes()
+    ok = C.c_int(0)
+    _lib.check(_lib.lib().sonic_verify_fs(srs._h, n, Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data, cs.ctypes.data, raw, C.byref(ok)))
+    return bool(ok.value)
+
+
 def hsc_prove(srs: SRS, circuit: ArithCircuit, yzs, u: Optional[int] = None, v: Optional[int] = None, rng=None) -> HscProof:
     """hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof (Signature.hs:32-72), with sXY = sPoly of `circuit`'s weights
     (Constraints.hs:34-53); u, v default to fresh draws"""
@@ -265,6 +326,43 @@ def hsc_prove(srs: SRS, circuit: ArithCircuit, yzs, u: Optional[int] = None, v: 
         return p.hsc_prove(yzs, draw() if u is None else u, draw() if v is None else v)
     finally:
         p.close()
+
+
+def _biv_terms(sXY):
+    """BiVLaurent Fr as {x_exp: {y_exp: coeff}} (X outside, Y inside, like poly's nested sparse form) or [(x_exp, y_exp, coeff)]"""
+    if isinstance(sXY, dict):
+        items = [(ex, ey, c) for ex, inner in sXY.items() for ey, c in inner.items()]
+    else:
+        items = [(ex, ey, c) for ex, ey, c in sXY]
+    xe = np.array([t[0] for t in items], dtype=np.int64)
+    ye = np.array([t[1] for t in items], dtype=np.int64)
+    return xe, ye, fr_array([t[2] for t in items])
+
+
+def hsc_prove_poly(srs: SRS, sXY, yzs, u: Optional[int] = None, v: Optional[int] = None, rng=None) -> HscProof:
+    """hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof (Signature.hs:32-72) for ANY sparse bivariate Laurent
+    polynomial (sonic_hsc_prove_poly); u, v: its two `rnd` draws (default fresh)"""
+    draw = (lambda: rng.randrange(1, R_MODULUS)) if rng is not None else (lambda: secrets.randbelow(R_MODULUS - 1) + 1)
+    xe, ye, cf = _biv_terms(sXY)
+    yzs = list(yzs)
+    flat = fr_array([x for pair in yzs for x in pair])
+    out = C.create_string_buffer(_lib.lib().sonic_hsc_proof_size(len(yzs)))
+    _lib.check(_lib.lib().sonic_hsc_prove_poly(srs._h, len(xe), xe.ctypes.data, ye.ctypes.data, cf.ctypes.data, len(yzs), flat.ctypes.data,
+                                               fr_to_bytes(draw() if u is None else u), fr_to_bytes(draw() if v is None else v), out))
+    return _hsc_from_bytes(out.raw, len(yzs))
+
+
+def hsc_verify_poly(srs: SRS, sXY, yzs, proof: HscProof) -> bool:
+    """hscVerify :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> HscProof -> Bool (Signature.hs:74-90) for any sparse bivariate polynomial"""
+    xe, ye, cf = _biv_terms(sXY)
+    yzs = list(yzs)
+    if len(proof.hscS) != len(yzs) or len(proof.hscW) != len(yzs):
+        return False
+    flat = fr_array([x for pair in yzs for x in pair])
+    ok = C.c_int(0)
+    _lib.check(_lib.lib().sonic_hsc_verify_poly(srs._h, len(xe), xe.ctypes.data, ye.ctypes.data, cf.ctypes.data, len(yzs), flat.ctypes.data,
+                                                _hsc_to_bytes(proof), C.byref(ok)))
+    return bool(ok.value)
 
 
 def hsc_verify(srs: SRS, circuit: ArithCircuit, yzs, proof: HscProof) -> bool:

@@ -44,10 +44,15 @@ class SRS:
         assert b0.size == 192 * (2 * self.srsD + 1) and b1.size == 192 * (2 * self.srsD + 1)
         _lib.check(_lib.lib().sonic_srs_set_g2_points(self._h, b0.ctypes.data, b1.ctypes.data))
 
-    def save(self, path: str, g2: bool = True) -> None:
+    def has_g2(self) -> bool:
+        """whether the handle holds the verifier half or can still generate it (sonic_srs_has_g2)"""
+        return bool(_lib.lib().sonic_srs_has_g2(self._h))
+
+    def save(self, path: str, g2=None) -> None:
         """write the SRS to disk (format in include/sonic_hip.h): the G1 bases and, with g2, the G2 bases, so that the
-        loaded handle can verify as well as prove.  The file never holds the trapdoor."""
-        _lib.check(_lib.lib().sonic_srs_save(self._h, str(path).encode(), 1 if g2 else 0))
+        loaded handle can verify as well as prove.  g2=None (default): include the G2 half if the handle has it -- handles made
+        from G1 points only, or loaded from a version-1 file, save as they are.  The file never holds the trapdoor."""
+        _lib.check(_lib.lib().sonic_srs_save(self._h, str(path).encode(), 2 if g2 is None else (1 if g2 else 0)))
 
     @classmethod
     def load(cls, path: str) -> "SRS":

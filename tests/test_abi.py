@@ -60,3 +60,19 @@ def test_product_never_touches_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle/", r"libsonic_oracle", r"sonic_ref", r"\borc\."):
                     assert not re.search(pat, src), (f, pat)
+
+
+def _build_harness(tmp_path):
+    exe = str(tmp_path / "abi_harness")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "abi_harness.c"), "-L" + os.path.join(ROOT, "sonic_amd", "csrc"), "-lsonic_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "sonic_amd", "csrc"), "-o", exe])
+    return exe
+
+
+@pytest.mark.skipif(_have_gpu(), reason="this box has a GPU: tests/test_gpu_parity.py runs the harness to the end")
+def test_c99_harness_builds_and_refuses_without_gpu(built, tmp_path):
+    """the boundary from plain C99 (the compile-checked stand-in for the Haskell `foreign import ccall` shim of INTEGRATION.md):
+    the header is C99-clean, every entry point the harness binds links, and without a GPU the first call says so (exit 77)"""
+    out = subprocess.run([_build_harness(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 77 and "SONIC_ERR_NO_DEVICE" in out.stderr and "no CPU fallback" in out.stderr

@@ -1,7 +1,10 @@
 """The N > 1 path on a GPU box with one GPU: two ranks (gloo) share the device.  Each rank reduces its slice of a range-sharded
 MSM with the real kernels (sonic_msm_g1_srs_partial_dev), the 192-byte partials are all-gathered and summed, and the result must
-be the oracle's full MSM; then bench.py itself is run as the driver runs it for N = 2 (torch.distributed.run), with gloo because
-two RCCL ranks cannot share one device."""
+be the oracle's full MSM -- and so must the two schemes of sonic_amd.distributed.ShardedMsm: term ranges with the partials
+gathered, and term ranges + the all-to-all of bucket ranges (both staged through host tensors here, because two RCCL ranks cannot
+share one device; tests/test_gpu_configs.py runs the same code over RCCL with one rank).  At 2^21 terms per rank (an N = 2^22 MSM,
+BASELINE.json configs[3] on two ranks) the reference value is the closed-form trapdoor exponent of a geometric scalar vector.
+Then bench.py itself is run as the driver runs it for N = 2 (torch.distributed.run)."""
 import json
 import os
 import socket
@@ -22,6 +25,61 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def _worker_big(rank, world, port, q):
+    """N = 2^22 over two ranks: 2^21 terms each, SRS d = 2^21 on both (replicated), scalars 1, x0, x0^2, ..."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import sonic_amd
+    from oracle import orc
+    from sonic_amd import _lib, distributed as sd
+    from util import R
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = _lib.lib()
+        _lib.check(L.sonic_init(0))
+        d, x, alpha, x0 = 1 << 21, 0x123456789abcdef, 0xfedcba987654321, 0x1000000000000007
+        N = 1 << 22
+        srs = sonic_amd.SRS.new(d, x, alpha)
+        lo, hi = sd.split_range(N, world, rank)
+        buf = bytearray(32 * (hi - lo))
+        v = pow(x0, lo, R)
+        for i in range(hi - lo):
+            buf[32 * i:32 * i + 32] = v.to_bytes(32, "little")
+            v = v * x0 % R
+        mine = np.frombuffer(bytes(buf), np.uint8)
+        dsc = C.c_void_p()
+        _lib.check(L.sonic_dev_alloc(mine.size, C.byref(dsc)))
+        _lib.check(L.sonic_dev_upload(dsc, mine.ctypes.data, mine.size))
+        xx = x0 * x % R
+        want = orc.g1_mul(orc.g1_gen(), pow(x, -d, R) * (pow(xx, N, R) - 1) % R * pow(xx - 1, -1, R) % R)
+        sh = sd.ShardedMsm(srs, rank, world, torch.device("cuda", 0))
+        ok_terms = sh.run_terms(0, -d + lo, dsc, hi - lo) == want
+        ok_buckets = sh.run_buckets(0, -d + lo, dsc, hi - lo) == want
+        sh.close()
+        L.sonic_dev_free(dsc)
+        q.put((rank, ok_terms and ok_buckets))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_msm_2p22_two_ranks_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_big, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
 
 
 def _worker(rank, world, port, n_terms, q):
@@ -53,7 +111,19 @@ def _worker(rank, world, port, n_terms, q):
             L.sonic_dev_free(dsc)
         got = sd.sum_partials(sd.allgather_partials(part, world), world)
         osrs = orc.SRS(d, x, alpha, threads=4)
-        q.put((rank, got == orc.msm_srs(osrs, 0, e0, sc, 1, 4)))
+        want = orc.msm_srs(osrs, 0, e0, sc, 1, 4)
+        # the same through ShardedMsm: partials gathered from device tensors, and the bucket exchange (staged: gloo)
+        import torch
+        sh = sd.ShardedMsm(srs, rank, world, torch.device("cuda", 0))
+        assert sh.staged
+        dmine = C.c_void_p()
+        mine = np.ascontiguousarray(sc[lo:hi]) if hi > lo else np.zeros((1, 32), np.uint8)
+        _lib.check(L.sonic_dev_alloc(mine.size, C.byref(dmine)))
+        _lib.check(L.sonic_dev_upload(dmine, mine.ctypes.data, mine.size))
+        ok2 = sh.run_terms(0, e0 + lo, dmine, hi - lo) == want
+        ok3 = sh.run_buckets(0, e0 + lo, dmine, hi - lo) == want
+        sh.close()
+        q.put((rank, got == want and ok2 and ok3))
     finally:
         dist.destroy_process_group()
 
@@ -85,3 +155,5 @@ def test_bench_two_ranks_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["msm"]["value"] > 0
     assert j["roofline"]["bound"] == "hbm" and j["cpu_baseline"] is None
+    assert j["msm_strong"]["scaling"] == "strong" and j["msm_strong"]["n_gpus"] == 2 and j["msm_strong"]["same_result_as_term_range_sharding"]
+    assert "all-to-all" in j["msm_strong"]["method"]

@@ -128,6 +128,76 @@ def test_srs_file_round_trip(sonic, orc, srs_pair, tmp_path):
         sonic.SRS.load(bad)
 
 
+def test_srs_refuses_points_at_infinity(sonic, srs_pair, tmp_path):
+    """no power of a generator is the identity (x, alpha != 0): an SRS file whose G2 section is zero-filled must not load -- a
+    verifier key at infinity pairs to 1 and would accept every proof -- and neither may a G1 basis with an empty slot other than
+    the omitted g^alpha.  A handle without a G2 half saves (default: G2 only if present) and reloads as it is."""
+    d, x, alpha, g, o = srs_pair
+    n = 2 * d + 1
+    path = tmp_path / "srs.bin"
+    g.save(path)
+    assert g.has_g2()
+    raw = bytearray(path.read_bytes())
+    g2_off = 24 + 2 * n * 96
+    bad = tmp_path / "bad.bin"
+    z = bytearray(raw)
+    z[g2_off:] = bytes(len(raw) - g2_off)              # whole G2 section zeroed
+    bad.write_bytes(bytes(z))
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.SRS.load(bad)
+    assert e.value.code == 3 and "infinity" in e.value.message
+    z = bytearray(raw)
+    k = g2_off + 192 * (n + d + 1)                     # one element: hPositiveAlphaX[1], a verifier-key element
+    z[k:k + 192] = bytes(192)
+    bad.write_bytes(bytes(z))
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.SRS.load(bad)
+    assert e.value.code == 3
+    z = bytearray(raw)
+    z[24 + 96 * 3:24 + 96 * 4] = bytes(96)             # a G1 element of basis 0
+    bad.write_bytes(bytes(z))
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.SRS.load(bad)
+    assert e.value.code == 3 and "infinity" in e.value.message
+    b0, b1 = g.points(0, -d, n), g.points(1, -d, n)
+    assert not b1[d].any()                             # the omitted g^alpha (SRS.hs:38) is the one empty slot
+    with pytest.raises(sonic.SonicError):
+        sonic.SRS.from_points(d, np.zeros_like(b0), b1)
+    h = sonic.SRS.from_points(d, b0, b1)
+    assert not h.has_g2()
+    with pytest.raises(sonic.SonicError):
+        h.set_g2_points(np.zeros((n, 192), np.uint8), np.zeros((n, 192), np.uint8))
+    assert not h.has_g2()
+    p1 = tmp_path / "g1only.bin"
+    h.save(p1)                                         # default: the G2 half only if the handle has it
+    assert p1.stat().st_size == 24 + 2 * n * 96
+    with pytest.raises(sonic.SonicError) as e:
+        h.save(p1, g2=True)
+    assert e.value.code == 7
+    l = sonic.SRS.load(p1)
+    assert not l.has_g2() and np.array_equal(l.points(1, -d, n), b1)
+    l.save(tmp_path / "again.bin")
+    assert (tmp_path / "again.bin").read_bytes() == p1.read_bytes()
+
+
+def test_msm_entry_encoding_limits(sonic, srs_pair):
+    """a sorted entry packs the term index into 26 bits (+ 5 window bits) over window tables and into 31 bits otherwise: an MSM
+    of 2^26 terms and more is planned over per-window buckets, one of 2^31 terms is refused -- by check, not by running out of
+    memory first"""
+    import ctypes as C
+    from sonic_amd import _lib
+    L = _lib.lib()
+    d, x, alpha, g, o = srs_pair
+    c, w, sets = C.c_int(), C.c_int(), C.c_int()
+    _lib.check(L.sonic_msm_plan(g._h, (1 << 26) - 1, C.byref(c), C.byref(w), C.byref(sets)))
+    tables = sets.value == 1
+    assert w.value <= 32 or not tables
+    _lib.check(L.sonic_msm_plan(g._h, 1 << 26, C.byref(c), C.byref(w), C.byref(sets)))
+    assert sets.value == w.value and w.value <= 64      # no shared bucket set: the index field of the table path would overflow
+    assert L.sonic_msm_plan(g._h, 1 << 31, C.byref(c), C.byref(w), C.byref(sets)) == 7
+    assert "2^31" in _lib.last_error()
+
+
 def test_srs_points_must_be_in_the_subgroup(sonic, srs_pair):
     """E(Fq) has cofactor points -- (0, 2) has order 3 -- and MSMs over an SRS fold scalars with r P = O, so the record
     constructor refuses points outside the order-r subgroup; the same for the G2 vectors (a point on the twist is almost
@@ -662,6 +732,73 @@ def test_hsc_prove_and_verify_standalone(sonic, ref):
     assert e.value.code == 4
 
 
+def test_hsc_prove_arbitrary_bivariate_polynomial(sonic, ref):
+    """hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof with the reference's own signature (Signature.hs:32-37): polynomials
+    that are NOT the s(X,Y) of a circuit -- dense blocks, a single monomial, positive exponents only (where evaluation points may
+    be 0), repeated terms -- every element against the literal restatement; hscVerify (host pairings) accepts, and rejects a
+    tampered proof, another polynomial and other points"""
+    pyr = random.Random(808)
+    d = 40
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    g, s = sonic.SRS.new(d, x, alpha), ref.SRS(d, x, alpha)
+
+    def rnd_poly(xr, yr, density):
+        p = {}
+        for ex in xr:
+            for ey in yr:
+                if ex != 0 and ey != 0 and pyr.random() < density:       # X^0 / Y^0 would need the omitted g^alpha (SRS.hs:38)
+                    p.setdefault(ex, {})[ey] = pyr.randrange(1, R)
+        return p
+    polys = [rnd_poly(range(-9, 12), range(-7, 6), 0.3), rnd_poly(range(-3, 4), range(-30, 31), 0.5), {5: {-4: 77}},
+             rnd_poly(range(1, 20), range(1, 9), 0.4)]
+    for k, sXY in enumerate(polys):
+        for m in (0, 1, 3):
+            yzs = [(pyr.randrange(1, R), pyr.randrange(1, R)) for _ in range(m)]
+            u, v = pyr.randrange(1, R), pyr.randrange(1, R)
+            got = sonic.hsc_prove_poly(g, sXY, yzs, u, v)
+            want = ref.hsc_prove(s, sXY, yzs, u, v)
+            assert (got.hscS, got.hscW, got.hscQv, got.hscC, got.hscU, got.hscV) == \
+                (want["hscS"], want["hscW"], want["hscQv"], want["hscC"], want["hscU"], want["hscV"]), (k, m)
+            assert sonic.hsc_verify_poly(g, sXY, yzs, got)
+            if m:
+                import dataclasses
+                sjp, wjp, qj = got.hscW[0]
+                assert not sonic.hsc_verify_poly(g, sXY, yzs, dataclasses.replace(got, hscW=[((sjp + 1) % R, wjp, qj)] + got.hscW[1:]))
+                assert not sonic.hsc_verify_poly(g, sXY, [((yzs[0][0] + 1) % R, yzs[0][1])] + yzs[1:], got)
+                other = {ex: dict(inner) for ex, inner in sXY.items()}
+                ex0 = next(iter(other))
+                ey0 = next(iter(other[ex0]))
+                other[ex0][ey0] = (other[ex0][ey0] + 1) % R
+                assert not sonic.hsc_verify_poly(g, other, yzs, got)
+    # the list form, with a repeated exponent pair (summed) and terms out of order
+    terms = [(3, 2, 5), (-2, 1, 9), (3, 2, 6), (1, -1, 4)]
+    got = sonic.hsc_prove_poly(g, terms, [(11, 13)], 17, 19)
+    want = ref.hsc_prove(s, {3: {2: 11}, -2: {1: 9}, 1: {-1: 4}}, [(11, 13)], 17, 19)
+    assert (got.hscS, got.hscW, got.hscQv, got.hscC) == (want["hscS"], want["hscW"], want["hscQv"], want["hscC"])
+    # zero as an evaluation point: fine without negative powers of that variable (z_j = 0: the opening is a shift), an error with them
+    pos = polys[3]
+    got = sonic.hsc_prove_poly(g, pos, [(7, 0)], 3, 5)
+    want = ref.hsc_prove(s, pos, [(7, 0)], 3, 5)
+    assert (got.hscS, got.hscW, got.hscQv, got.hscC) == (want["hscS"], want["hscW"], want["hscQv"], want["hscC"])
+    assert sonic.hsc_verify_poly(g, pos, [(7, 0)], got)
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.hsc_prove_poly(g, polys[0], [(7, 0)], 3, 5)
+    assert e.value.code == 4
+    # a term that needs an SRS element beyond d, and the omitted g^alpha (an X^0 term of s(X, y_j)): index errors as in the reference
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.hsc_prove_poly(g, {d + 1: {1: 1}}, [(2, 3)], 5, 7)
+    assert e.value.code == 2
+    with pytest.raises(sonic.SonicError) as e:
+        sonic.hsc_prove_poly(g, {0: {1: 1}, 2: {1: 1}}, [(2, 3)], 5, 7)
+    assert e.value.code == 2
+    # the s(X,Y) of a circuit through the generic entry point == the circuit entry point
+    circ, asg = ref.rnd_circuit(pyr, 4, 3)
+    yzs = [(pyr.randrange(1, R), pyr.randrange(1, R)) for _ in range(2)]
+    a = sonic.hsc_prove_poly(g, ref.s_poly(*circ[:3]), yzs, 21, 23)
+    b = sonic.hsc_prove(g, sonic.ArithCircuit(sonic.GateWeights(*circ[:3]), circ[3]), yzs, 21, 23)
+    assert a == b
+
+
 def test_product_verifier(sonic, ref, srs_pair):
     """verify . prove inside the product (test/Test/Protocol.hs:14-23): sonic_verify / sonic_pc_v (host pairings over the
     GPU-generated G2 elements) accept GPU proofs, reject tampered ones, and agree with the oracle's verifier"""
@@ -823,3 +960,12 @@ def test_msm_zero_and_identity_scalars(sonic, orc, srs_pair):
     p = sonic.g1_from_bytes(o.points(0, -1490, 1)[0].tobytes())
     Qm = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
     assert got == (p[0], (Qm - p[1]) % Qm)
+
+
+def test_c99_abi_harness(sonic, tmp_path):
+    """tests/host/abi_harness.c: examples/Main.hs (prove + verify), the resident handle, the Fiat-Shamir mode and the d < 7n error
+    through nothing but include/sonic_hip.h from plain C99 -- what a Haskell `foreign import ccall` shim binds"""
+    import subprocess
+    from test_abi import _build_harness
+    out = subprocess.run([_build_harness(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "abi_harness: OK" in out.stdout, out.stdout + out.stderr
