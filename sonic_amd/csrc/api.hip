@@ -5,6 +5,7 @@
 #include <memory>
 #include "internal.hpp"
 #include "g2.hpp"
+#include "srs_file.hpp"
 
 namespace sonic {
 
@@ -368,8 +369,6 @@ int sonic_srs_has_g2(const sonic_srs_t* srs) {
 // ---- on-disk SRS: "SONICSRS" | u32 version = 2 | u32 flags (bit 0: G2 half follows) | i64 d | basis0, basis1: (2d+1) x 96 B |
 // [h basis0, h basis1: (2d+1) x 192 B], canonical affine encodings.  The reference has no persistence at all; this
 // amortises SRS.new across runs, and with the G2 half a loaded SRS verifies as well as proves -- without the trapdoor.
-static const char SRS_MAGIC[8] = {'S', 'O', 'N', 'I', 'C', 'S', 'R', 'S'};
-
 int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2) {
   API_BEGIN
   if (!srs || !path || with_g2 < 0 || with_g2 > 2) return SONIC_ERR_INVALID_ARG;
@@ -381,9 +380,8 @@ int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2) {
   }
   FILE* f = fopen(path, "wb");
   if (!f) { set_error("sonic_srs_save: cannot open %s", path); return SONIC_ERR_INVALID_ARG; }
-  uint32_t ver = 2, flags = with_g2 ? 1u : 0u;
   int64_t d = srs->d;
-  bool ok = fwrite(SRS_MAGIC, 1, 8, f) == 8 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&flags, 4, 1, f) == 1 && fwrite(&d, 8, 1, f) == 1;
+  bool ok = srs_file_write_header(f, d, with_g2 != 0);
   const int64_t n = 2 * d + 1, CH = 1 << 16;
   std::vector<uint8_t> buf(192 * (size_t)CH);
   for (int b = 0; b < (with_g2 ? 4 : 2) && ok; b++)
@@ -402,19 +400,13 @@ int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2) {
 int sonic_srs_load(const char* path, sonic_srs_t** out) {
   API_BEGIN
   if (!path || !out) return SONIC_ERR_INVALID_ARG;
-  FILE* f = fopen(path, "rb");
-  if (!f) { set_error("sonic_srs_load: cannot open %s", path); return SONIC_ERR_INVALID_ARG; }
-  char magic[8]; uint32_t ver = 0, flags = 0; int64_t d = 0;
-  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, SRS_MAGIC, 8) == 0 && fread(&ver, 4, 1, f) == 1 && fread(&flags, 4, 1, f) == 1 &&
-            fread(&d, 8, 1, f) == 1 && (ver == 1 || ver == 2) && d >= 1 && d < (1LL << 40) && (flags & ~1u) == 0 && !(ver == 1 && flags);
-  if (!ok) { fclose(f); set_error("sonic_srs_load: %s is not a version-1/2 SRS file", path); return SONIC_ERR_BAD_ENCODING; }
-  const size_t n = (size_t)(2 * d + 1);
-  std::vector<uint8_t> b0(96 * n), b1(96 * n), h0, h1;
-  ok = fread(b0.data(), 96, n, f) == n && fread(b1.data(), 96, n, f) == n;
-  if (ok && (flags & 1u)) { h0.resize(192 * n); h1.resize(192 * n); ok = fread(h0.data(), 192, n, f) == n && fread(h1.data(), 192, n, f) == n; }
-  if (ok) ok = fgetc(f) == EOF;                                   // nothing may follow
-  fclose(f);
-  if (!ok) { set_error("sonic_srs_load: %s is truncated or has trailing bytes", path); return SONIC_ERR_BAD_ENCODING; }
+  SrsFile file;
+  std::string why;
+  const int frc = srs_file_read(path, file, why);             // header against the real file size before anything is allocated (srs_file.hpp)
+  if (frc) { set_error("sonic_srs_load: %s", why.c_str()); return frc == 1 ? SONIC_ERR_INVALID_ARG : SONIC_ERR_BAD_ENCODING; }
+  const int64_t d = file.d;
+  const uint32_t flags = file.flags;
+  std::vector<uint8_t>&b0 = file.g0, &b1 = file.g1, &h0 = file.h0, &h1 = file.h1;
   sonic_srs_t* s = nullptr;
   int rc = sonic_srs_from_points(d, b0.data(), b1.data(), &s);     // validates every point, rebuilds the window tables
   if (rc) return rc;

@@ -72,7 +72,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
                        G1XYZZ* ext_buckets = nullptr);
 // The second half on the rank that owns bucket range [base, base + len): adds the k slices it received element-wise and
 // reduces them with the range's weights into d_slot (one window sum).  len and base are multiples of MSM_SLICE_QUANTUM.
-constexpr int MSM_SLICE_SEGMENT = 8;          // buckets per running-sum segment of a slice (shortest chain: nothing hides it)
+constexpr int MSM_SLICE_SEGMENT = 2;          // buckets per running-sum segment of a slice: measured on one GPU doing 1/8 of an N = 2^22 MSM, K = 8 / 4 / 2 / 1: 2.62 / 2.54 / 2.46 / 2.47 ms per share
 constexpr long MSM_SLICE_QUANTUM = 16384;     // = 2048 segments: whole 256-segment groups and wave-uniform segment bits
 void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot);
 

@@ -276,13 +276,13 @@ srs = sonic_amd.SRS.new(d, 0x1234567, 0x7654321)
 N = 20000
 sc = rand_fr_array(np.random.default_rng(1), N)
 dsc = C.c_void_p(); _lib.check(L.sonic_dev_alloc(32 * N, C.byref(dsc))); _lib.check(L.sonic_dev_upload(dsc, sc.ctypes.data, 32 * N))
-want = C.create_string_buffer(96); _lib.check(L.sonic_msm_g1_srs_dev(srs._h, 0, -100, dsc, N, want))
+want = C.create_string_buffer(96); _lib.check(L.sonic_msm_g1_srs_dev(srs._h, 0, -10000, dsc, N, want))
 sh = sd.ShardedMsm(srs, 0, 1, dev)
 assert sh.pg and not sh.staged                    # device tensors over RCCL
-assert sh.run_terms(0, -100, dsc, N) == want.raw   # all_gather_into_tensor on the device
-assert sh.run_buckets(0, -100, dsc, N) == want.raw # all_to_all_single of the bucket ranges + all_gather_into_tensor
+assert sh.run_terms(0, -10000, dsc, N) == want.raw   # all_gather_into_tensor on the device
+assert sh.run_buckets(0, -10000, dsc, N) == want.raw # all_to_all_single of the bucket ranges + all_gather_into_tensor
 part = np.zeros(192, np.uint8)
-_lib.check(L.sonic_msm_g1_srs_partial_dev(srs._h, 0, -100, dsc, N, part.ctypes.data))
+_lib.check(L.sonic_msm_g1_srs_partial_dev(srs._h, 0, -10000, dsc, N, part.ctypes.data))
 assert sd.sum_partials(sd.allgather_partials(part, 1, device=dev), 1) == want.raw
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_WORLD1_OK")
