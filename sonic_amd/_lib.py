@@ -37,6 +37,15 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C sonic_amd/csrc). "
             "sonic_amd has no CPU fallback.")
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; loaded AFTER this library
+    # has pulled in /opt/rocm's, torch finds "No HIP GPUs" (two HSA runtimes cannot share the device).  Loaded first, torch's copy
+    # also serves this library (same SONAME).  torch is only plumbing here (device tensors and RCCL for the multi-GPU exchange), so
+    # it is imported when it is installed and ignored when it is not (the C harness and a Haskell host never see it).
+    if os.environ.get("SONIC_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, cp, i64, i32 = C.c_void_p, C.c_char_p, C.c_int64, C.c_int
     sig = {

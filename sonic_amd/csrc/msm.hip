@@ -36,6 +36,10 @@ namespace sonic {
 constexpr int PART_LOW_BITS = SONIC_PART_LOW_BITS;   // buckets per sort partition = 2^PART_LOW_BITS (8..10)
 constexpr int PART_TILE = 1024;            // scalars per tile in pass 1
 constexpr uint32_t PASS1_GRID = 1024;      // workgroups of pass 1 (grid-stride over the tiles)
+// workgroups of pass 2 (grid-stride over the (job, partition) pairs): one MSM over 2^19 buckets has 2048 partitions and keeps one
+// workgroup each; a batched group of three or four would otherwise queue 6144-8192 short workgroups behind the wave slots that other
+// groups' accumulations hold
+constexpr uint32_t PART_SORT_GRID = 2048;
 static_assert(PART_LOW_BITS >= 8 && PART_LOW_BITS <= 10, "k_part_sort scans 256 x {1, 2, 4} counters");
 
 static int g_window_override = 0;
@@ -47,7 +51,9 @@ static constexpr uint32_t HEAVY_SEG = 16384;  // entries per heavy work item (25
 // workgroup still waits for a free slot (1024 idle workgroups delayed the chain behind them by 1.4-3.4 ms in prove()).
 static constexpr int HEAVY_GRID = 128;
 
-struct HeavyMeta { uint32_t n_items, n_heavy; };
+// header of a chain, cleared by one memset at its start: the heavy-bucket counters and the size-class histogram / cursors of the
+// bucket ordering (k_part_sort, k_border_place)
+struct HeavyMeta { uint32_t n_items, n_heavy; uint32_t class_hist[256]; uint32_t class_cursor[256]; };
 struct HeavyRec { uint32_t bucket, base, nseg; };
 struct HeavyItem { uint32_t bucket, seg; };
 
@@ -113,9 +119,8 @@ void MsmWorkspace::reserve(long n, const MsmPlan& pl, int k) {
   entries.ensure(NW * 4);
   buckets.ensure(M * sizeof(G1XYZZ));
   segres.ensure((sets * pl.nseg + sets * (pl.nseg / 256 + 1) + 2) * sizeof(G1XYZZ));
-  scan_tmp.ensure(((M > part_hn ? M : part_hn) / 2048 + 4) * 4);
+  scan_tmp.ensure((part_hn / 2048 + 4) * 4);
   order.ensure((M + 1) * 4);
-  size_hist.ensure((256 * (M / 2048 + 1) + 1) * 4 * 2);
   size_t max_heavy = NW / pl.heavy_threshold + 1;
   size_t max_items = NW / HEAVY_SEG + max_heavy + 1;
   heavy_meta.ensure(sizeof(HeavyMeta) + max_heavy * sizeof(HeavyRec));
@@ -135,6 +140,8 @@ __device__ __forceinline__ bool fr_gt_half(const Fr& s) {
 }
 
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sh, uint32_t* total);
+// size class of a bucket for the largest-first ordering (256 classes; everything of 255 entries and more is class 0)
+__device__ __forceinline__ uint32_t size_class(uint32_t sz) { return 255u - (sz < 255u ? sz : 255u); }
 
 // ---- digits + two-pass partition sort ---------------------------------------------------------
 // Every (scalar, window) pair becomes an entry (point index | window | sign) that must end up grouped by its
@@ -286,19 +293,24 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
   }
 }
 
-// one workgroup per (job, partition): keys [job * jobstride + t * 1024, +1024): bucket offsets and final placement
+// one (job, partition) per trip of a grid-stride loop (capped grid: see PART_SORT_GRID): bucket offsets, final placement, and the
+// size classes of the partition's buckets added to class_hist (k_border_place)
 __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, const uint2* __restrict__ part,
                                                    const uint32_t* __restrict__ base, const uint32_t* __restrict__ total, size_t hn, int P,
-                                                   uint32_t jobstride, uint32_t* __restrict__ off, uint32_t* __restrict__ entries) {
+                                                   uint32_t jobstride, uint32_t* __restrict__ off, uint32_t* __restrict__ entries, uint32_t* __restrict__ class_hist) {
   __shared__ uint32_t cnt[1 << PART_LOW_BITS];
   __shared__ uint32_t sc4[256];
-  const int job = blockIdx.x / P, t = blockIdx.x % P;
+  __shared__ uint32_t chist[256];
+  const uint32_t M = (uint32_t)batch.k * jobstride;
+  const uint32_t nparts = (uint32_t)batch.k * (uint32_t)P;
+  chist[threadIdx.x] = 0;
+  for (uint32_t pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
+  const int job = pi / P, t = pi % P;
   const uint32_t nblk = batch.tile0[job + 1] - batch.tile0[job];
   const size_t idx = (size_t)P * batch.tile0[job] + (size_t)t * nblk, idx_next = idx + nblk;
   const uint32_t beg = idx < hn ? base[idx] : *total;
   const uint32_t end = idx_next < hn ? base[idx_next] : *total;
-  const uint32_t M = (uint32_t)batch.k * jobstride;
-  const bool last_block = blockIdx.x == gridDim.x - 1;
+  const bool last_block = pi == nparts - 1;
   for (int t = threadIdx.x; t < (1 << PART_LOW_BITS); t += 256) cnt[t] = 0;
   __syncthreads();
   // every lane of a wave must reach lds_take: round the trip count up to the wave
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
   for (int k = 0; k < CPT; k++) {
     const uint32_t local = (uint32_t)t * (1u << PART_LOW_BITS) + threadIdx.x * CPT + k;
     cnt[threadIdx.x * CPT + k] = ex;               // becomes the running cursor
-    if (local < jobstride) off[(uint32_t)job * jobstride + local] = beg + ex;
+    if (local < jobstride) { off[(uint32_t)job * jobstride + local] = beg + ex; atomicAdd(&chist[size_class(v[k])], 1u); }
     ex += v[k];
   }
   if (last_block && threadIdx.x == 0) off[M] = *total;
@@ -343,6 +355,10 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
       if (live) entries[beg + pos] = pay[j];
     }
   }
+  __syncthreads();
+  }
+  const uint32_t c = chist[threadIdx.x];
+  if (c) atomicAdd(&class_hist[threadIdx.x], c);
 }
 
 // ---- exclusive scan of u32 (three small kernels; tile = 2048) -------------------------------
@@ -400,31 +416,33 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, size_t m
 // One thread walks one bucket, so a wave runs as long as its largest bucket.  Bucket sizes are
 // Poisson around N / 2^(c-1) (and 4x that in the top window): in index order a wave idles ~30 % of its
 // lanes.  A counting sort of the buckets by size (256 classes) puts equal-length walks in the same wave.
-__device__ __forceinline__ uint32_t size_class(uint32_t sz) { return 255u - (sz < 255u ? sz : 255u); }
-__global__ __launch_bounds__(256) void k_border_hist(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t nblk, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[256];
+// The size classes are counted by k_part_sort as it computes the bucket sizes (class_hist, cleared with the heavy-bucket header at the
+// start of a chain); this kernel turns the 256 totals into class offsets (every workgroup scans them again: 256 words), reserves
+// its share of every class with one atomic per non-empty class and places its buckets.  Two launches (k_border_hist + three scan
+// launches + k_border_scatter before) became one; the order inside a class is arbitrary, which no result depends on.
+__global__ __launch_bounds__(256) void k_border_place(const uint32_t* __restrict__ off, uint32_t nbuckets, const uint32_t* __restrict__ class_hist,
+                                                      uint32_t* __restrict__ class_cursor, uint32_t* __restrict__ order) {
+  __shared__ uint32_t h[256], start[256], sc[256];
+  const uint32_t tot = class_hist[threadIdx.x];
+  const uint32_t cls_off = block_exclusive_scan_256(tot, sc, nullptr);
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * 2048;
+  uint32_t cls[8];
   for (int k = 0; k < 8; k++) {
-    uint32_t b = base + k * 256 + threadIdx.x;
-    if (b < nbuckets) atomicAdd(&h[size_class(off[b + 1] - off[b])], 1u);
+    const uint32_t b = base + k * 256 + threadIdx.x;
+    cls[k] = b < nbuckets ? size_class(off[b + 1] - off[b]) : 0xffffffffu;
+    if (cls[k] != 0xffffffffu) atomicAdd(&h[cls[k]], 1u);
   }
   __syncthreads();
-  hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
-}
-__global__ __launch_bounds__(256) void k_border_scatter(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t nblk,
-                                                        const uint32_t* __restrict__ hist_scanned, uint32_t* __restrict__ order) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = hist_scanned[threadIdx.x * nblk + blockIdx.x];
+  const uint32_t mine = h[threadIdx.x];
+  start[threadIdx.x] = cls_off + (mine ? atomicAdd(&class_cursor[threadIdx.x], mine) : 0u);
   __syncthreads();
-  const uint32_t base = blockIdx.x * 2048;
-  for (int k = 0; k < 8; k++) {
-    uint32_t b = base + k * 256 + threadIdx.x;
-    if (b < nbuckets) order[atomicAdd(&h[size_class(off[b + 1] - off[b])], 1u)] = b;
-  }
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int k = 0; k < 8; k++)
+    if (cls[k] != 0xffffffffu) order[start[cls[k]] + atomicAdd(&h[cls[k]], 1u)] = base + k * 256 + threadIdx.x;
 }
-
 // ---- bucket accumulation ---------------------------------------------------------------------
 // entry = point index | sign (bit 31); over window tables additionally the window in bits 26..30 and the
 // point of (i, w) is tab[w * stride + i] = 2^(c w) P_i
@@ -549,25 +567,61 @@ __global__ __launch_bounds__(64, 2) void k_heavy_finish(const HeavyMeta* hm, con
 // ---- bucket reduction: sum_b (b+1) * B_b per window -----------------------------------------
 // sg_base: the set's first segment is segment sg_base of a longer bucket sequence (one rank's bucket range of an MSM whose buckets are
 // sharded across ranks, msm_reduce_slices_enqueue): bucket j of segment sg weighs (sg_base + sg) K + j + 1
-__global__ __launch_bounds__(256, 1) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg, int sg_base,
+//
+// Registers: two XYZZ operands, the result and the temporaries of a full addition around the product routine's own 75 registers
+// are ~320 VGPRs when both running sums live in registers: one wave per SIMD.  `tot` is touched once per bucket, so it lives in
+// LDS (48 words per thread, word-major: conflict-free) while `run` takes the bucket in; the kernel then fits two waves per SIMD.
+#ifndef SONIC_SEGMENTS_LDS_TOT
+#define SONIC_SEGMENTS_LDS_TOT 1
+#endif
+struct LdsPoint {
+  uint32_t* base;      // &sh[threadIdx.x]; word w at base[w * 256]
+  __device__ __forceinline__ void store(const G1XYZZ& p) const {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
+#pragma unroll
+    for (int k = 0; k < 48; k++) base[k * 256] = w[k];
+  }
+  __device__ __forceinline__ G1XYZZ load() const {
+    G1XYZZ p;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+    for (int k = 0; k < 48; k++) w[k] = base[k * 256];
+    return p;
+  }
+};
+__global__ __launch_bounds__(256, SONIC_SEGMENTS_LDS_TOT ? 2 : 1) void k_bucket_segments(const G1XYZZ* __restrict__ buckets, int W, int NB, int K, int nseg, int sg_base,
                                                         G1XYZZ* __restrict__ segres) {
+#if SONIC_SEGMENTS_LDS_TOT
+  __shared__ uint32_t tot_sh[48 * 256];
+  const LdsPoint tl{tot_sh + threadIdx.x};
+#endif
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * nseg) return;
   const int w = t / nseg, sl = t % nseg;
   const G1XYZZ* B = buckets + (size_t)w * NB + (size_t)sl * K;
   const int sg = sg_base + sl;
   const int k0 = sg * K;
-  G1XYZZ run = G1XYZZ::inf(), tot = G1XYZZ::inf();
+  G1XYZZ run = G1XYZZ::inf();
+#if SONIC_SEGMENTS_LDS_TOT
+  tl.store(G1XYZZ::inf());
+  for (int j = K - 1; j >= 0; j--) {
+    run = g1_add(run, B[j]);
+    tl.store(g1_add(tl.load(), run));          // ends as sum_j (j+1) B[j]
+  }
+#else
+  G1XYZZ tot = G1XYZZ::inf();
   for (int j = K - 1; j >= 0; j--) {
     run = g1_add(run, B[j]);
     tot = g1_add(tot, run);          // ends as sum_j (j+1) B[j]
   }
+#endif
+  G1XYZZ acc = G1XYZZ::inf();
+  bool have_multiple = false;
   if (nseg % 64 == 0 && sg_base % 64 == 0) {
     // k0 * run with k0 = sg * K: the 64 lanes of a wave hold consecutive sg, so the bits of sg above the lane bits are
     // wave-uniform and their conditional additions are uniform branches; only the six lane bits pay for both paths
     // (a per-lane double-and-add executes an addition at every bit as soon as any lane needs one).
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)sg >> 6), lo = (uint32_t)sg & 63u;
-    G1XYZZ acc = G1XYZZ::inf();
     for (int i = 31 - __clz((int)(hi | 1u)); i >= 0; i--) {
       acc = g1_dbl(acc);
       if ((hi >> i) & 1u) acc = g1_add(acc, run);
@@ -577,10 +631,15 @@ __global__ __launch_bounds__(256, 1) void k_bucket_segments(const G1XYZZ* __rest
       if ((lo >> i) & 1u) acc = g1_add(acc, run);
     }
     for (int s = K; s > 1; s >>= 1) acc = g1_dbl(acc);
-    tot = g1_add(tot, acc);
+    have_multiple = true;
   } else if (k0) {
-    tot = g1_add(tot, g1_mul_small(run, (uint32_t)k0));
+    acc = g1_mul_small(run, (uint32_t)k0);
+    have_multiple = true;
   }
+#if SONIC_SEGMENTS_LDS_TOT
+  G1XYZZ tot = tl.load();
+#endif
+  if (have_multiple) tot = g1_add(tot, acc);
   segres[t] = tot;
 }
 
@@ -685,26 +744,19 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     uint32_t* total = tiles + ht;
     const uint32_t pgrid = pblk < PASS1_GRID ? pblk : PASS1_GRID;
     LAUNCH(k_part_hist, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, hist);
+    // (a single-launch chained scan with decoupled look-back was measured in round 3 and is not kept: 0.080 ms against 0.052 ms for
+    // these three launches on an empty chip, and no difference inside prove())
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
     LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, (const uint32_t*)hbase,
            ws.digits.as<uint2>());
-    LAUNCH(k_part_sort, k * P, 256, 0, st, batch, (const uint2*)ws.digits.as<uint2>(),
-           (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>());
+    const uint32_t nparts = (uint32_t)k * (uint32_t)P;
+    LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, 256, 0, st, batch, (const uint2*)ws.digits.as<uint2>(),
+           (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>(), hm->class_hist);
   }
-  {
-    const uint32_t nblk = (uint32_t)ceil_div((long)M, 2048);
-    uint32_t* hist = ws.size_hist.as<uint32_t>();
-    uint32_t* hist_sc = hist + (256 * nblk + 1);
-    const size_t hn = (size_t)256 * nblk;
-    const int ht = ceil_div((long)hn + 1, 2048);
-    LAUNCH(k_border_hist, nblk, 256, 0, st, (const uint32_t*)off, (uint32_t)M, nblk, hist);
-    LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
-    LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, tiles + ht);
-    LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hist_sc);
-    LAUNCH(k_border_scatter, nblk, 256, 0, st, (const uint32_t*)off, (uint32_t)M, nblk, (const uint32_t*)hist_sc, ws.order.as<uint32_t>());
-  }
+  LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
+         ws.order.as<uint32_t>());
   LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
          (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs,
          ws.heavy_items.as<HeavyItem>());

@@ -49,7 +49,7 @@ struct MsmSlot {
 };
 
 struct MsmWorkspace {
-  DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, size_hist, heavy_meta, heavy_items, heavy_partial;
+  DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, heavy_meta, heavy_items, heavy_partial;
   // n = total terms over the k jobs of a batch
   void reserve(long n, const MsmPlan& pl, int k = 1);
 };

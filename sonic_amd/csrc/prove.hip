@@ -14,6 +14,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <memory>
 #include <thread>
 #include <numeric>
@@ -422,18 +423,36 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   hipStream_t ms = st;
   p->next_lane = 0;
   auto ready = [&](hipEvent_t e) { HIP_OK(hipEventRecord(e, ms)); };
-  Lane* cur = nullptr;
-  auto begin_group = [&](hipEvent_t e) { cur = &p->pick(e); cur->njobs = 0; };
-  auto flush_group = [&](bool last = false) { run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last); cur->njobs = 0; };
   auto on = [&](int ph) { return ((p->phases >> ph) & 1u) != 0; };
+  Lane* cur = nullptr;
+  // SONIC_PROVE_PACK=1 packs consecutive groups into ONE batched chain as long as their MSMs fit MSM_MAX_JOBS (Q = 2: {R, W_a, W_b}
+  // with {S_1, W_1, W'_1}; {S_2, W_2, W'_2} with {C, Q_1, Q_2, Q_v}), the chain waiting for the later polynomial: fewer, wider
+  // chains.  Off by default -- measured in round 3 on one box, ms per proof streamed / one at a time, packed vs not:
+  // n = 2^14 5.59 / 6.40 vs 6.18 / 5.69, 2^16 12.19 / 13.08 vs 12.52 / 11.71, 2^18 35.9 / 38.9 vs 35.0 / 35.9, 2^20 127.5 / 129.5 vs
+  // 129.9 / 131.0: the chains of one proof overlap less, which costs the headline size more than the wider launches give.
+  static const bool pack = getenv("SONIC_PROVE_PACK") && atoi(getenv("SONIC_PROVE_PACK")) != 0;
+  std::vector<std::function<void()>> after_flush;       // small MSMs that use the lane's workspace after the batch (stream order)
+  auto flush_now = [&](bool last = false) {
+    if (!cur) return;
+    run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last);
+    cur->njobs = 0;
+    for (auto& f : after_flush) f();
+    after_flush.clear();
+  };
+  auto begin_group = [&](hipEvent_t e, int njobs_coming) {
+    if (pack && cur && cur->njobs > 0 && cur->njobs + njobs_coming <= MSM_MAX_JOBS) { HIP_OK(hipStreamWaitEvent(cur->st, e, 0)); return; }
+    flush_now();
+    cur = &p->pick(e); cur->njobs = 0;
+  };
+  auto flush_group = [&](bool last = false) { if (!pack || last) flush_now(last); };
   auto commit = [&](int ph, const Fr* poly, long lo, long len, long maxm, long slot) {
     if (!on(ph)) return;
-    if (cur->njobs == MSM_MAX_JOBS) flush_group();
+    if (cur->njobs == MSM_MAX_JOBS) flush_now();
     cur->jobs[cur->njobs++] = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
   };
   auto open = [&](int ph, const Fr* poly, long lo, long len, const Fr* zp, Fr* fz, long slot) {
     if (!on(ph)) return;
-    if (cur->njobs == MSM_MAX_JOBS) flush_group();
+    if (cur->njobs == MSM_MAX_JOBS) flush_now();
     Scratch& sc = cur->sc[cur->njobs];
     cur->jobs[cur->njobs++] = open_job(cur->st, srs, sc, poly, lo, len, zp, fz, &slots[slot], flags);
   };
@@ -479,28 +498,33 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // ---- the MSM groups, largest first where its input allows ----
   Lane& lane_t = p->t_lane(p->ev_sy0);
   if (on(PH_OPEN)) eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);         // s(z,y)       :83
-  begin_group(p->ev_r1);
+  begin_group(p->ev_r1, 3);
   commit(PH_R, r1, r_lo, r_len, n, 0);                                                 // R            :63
   open(PH_OPEN, r1, r_lo, r_len, pZ, &frout[0], 2);                                    // (a, W_a)     :79
   open(PH_OPEN, r1, r_lo, r_len, pYZ, &frout[1], 3);                                   // (b, W_b)     :80
   flush_group();
   for (long j = 0; j < Q; j++) {
     Fr* syj = p->syj[j].as<Fr>();
-    begin_group(p->ev_syj[j]);
+    begin_group(p->ev_syj[j], 3);
     if (p->prepared) commit(PH_HSCS, p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);   // S_j (diagonal part)   Signature.hs:42
     else commit(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j                   :42
     open(PH_HSCS, syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);               // (s_j, W_j)    :43
     open(PH_HSCW, syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                 // W'_j          :54
     flush_group();
-    if (p->prepared && on(PH_HSCS))                                                   // sum_q y_j^{n+q} C_q, Q-term MSM
-      msm_enqueue(cur->st, cur->ws, p->cq_tab.p ? msm_plan_tables(Q, CQ_TAB_C, CQ_TAB_W, Q) : msm_plan(Q),
-                  p->cq_tab.p ? p->cq_tab.as<G1Affine>() : p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
+    if (p->prepared && on(PH_HSCS)) {                                                 // sum_q y_j^{n+q} C_q, Q-term MSM
+      Lane* ln = cur;
+      auto small = [&, ln, j] {
+        msm_enqueue(ln->st, ln->ws, p->cq_tab.p ? msm_plan_tables(Q, CQ_TAB_C, CQ_TAB_W, Q) : msm_plan(Q),
+                    p->cq_tab.p ? p->cq_tab.as<G1Affine>() : p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
+      };
+      if (cur->njobs == 0) small(); else after_flush.push_back(small);
+    }
   }
-  begin_group(p->ev_su);
+  begin_group(p->ev_su, (int)std::min<long>(Q + 2, MSM_MAX_JOBS));
   commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                    // C             :52
   for (long j = 0; j < Q; j++) open(PH_HSCW, su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
   open(PH_QV, su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                              // Q_v           :63
-  flush_group();
+  flush_now();
   if (on(PH_T) || on(PH_OPEN)) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
   cur = &lane_t; cur->njobs = 0;
   commit(PH_T, t, t_lo, t_len, d, 1);                                                  // T            Protocol.hs:73
