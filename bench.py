@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pipelined-throughput leg (timelines of one solo proof)")
     ap.add_argument("--msm-lanes", type=int, default=3, help="lanes the standalone MSMs are streamed over (0: skip the streamed leg, e.g. for rocprofv3 / PMC passes over the solo kernels)")
     ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
+    ap.add_argument("--prove-only", action="store_true", help="nothing but the proofs (PMC pass for the per-kernel instruction budget of a proof)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -226,7 +227,7 @@ def main():
 
     # ---------------- NTT product alone on the chip (rank 0; roofline_ntt) ----------------
     ntt = None
-    if do_prove and rank == 0:
+    if do_prove and rank == 0 and not args.prove_only:
         na, nb = 3 * n + 5, 4 * n + 5                       # r(X,1) and r(X,y) + s(X,y): the shapes of tPoly's product (7n + 9 coefficients)
         lgM = (na + nb - 2).bit_length()
         M = 1 << lgM
@@ -268,7 +269,7 @@ def main():
     _lib.check(L.sonic_dev_upload(dsc, sc.ctypes.data, 32 * sc.shape[0]))
     msm = roofline = int_roofline = None
     accum_ms, kern_total = 0.0, 0.0
-    if not only_strong:
+    if not only_strong and not args.prove_only:
         basis, e0 = sd.msm_shard(rank, world, d, msm_n)
         # (1) one MSM after the other, every launch bracketed by HIP events: the dominant kernel's duration for the roofline
         #     (alone on the chip, as in the rocprofv3 summary of --msm-only) and the latency of one MSM.  The partial stays on
@@ -340,7 +341,7 @@ def main():
 
     # ---------------- timed: ONE 2^22-term MSM split over all ranks (strong scaling; BASELINE configs[3]) ----------------
     msm_strong = None
-    if not args.msm_only:
+    if not args.msm_only and not args.prove_only:
         sh = sd.ShardedMsm(srs, rank, world, device)
         lo, hi = sd.split_range(strong_n, world, rank)
         dmine = C.c_void_p(dsc.value + 32 * lo)

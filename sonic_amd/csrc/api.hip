@@ -530,7 +530,8 @@ static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
   fr_check_enqueue(st, dsc, n, l->err.as<int>());
   MsmPlan pl = srs_msm_plan(srs, n);
   if (d_partial_out && pl.Wb != 1) { set_error("sonic_msm_submit_dev: this MSM leaves %d window sums for the host to fold (no window tables, or too few terms for them)", pl.Wb); return SONIC_ERR_INVALID_ARG; }
-  if (pl.Wb == 1 && pl.NB >= (1 << 16)) msm_plan_set_segment(pl, l->segment);
+  static const int seg_env = getenv("SONIC_MSM_SEGMENT") ? atoi(getenv("SONIC_MSM_SEGMENT")) : 0;      // tuning knob: buckets per running-sum segment
+  if (pl.Wb == 1 && pl.NB >= (1 << 16)) msm_plan_set_segment(pl, seg_env > 0 ? seg_env : l->segment);
   msm_enqueue(st, l->ws, pl, srs->basis(basis) + (e0 + srs->d), dsc, n, false, l->slot.as<MsmSlot>());
   l->Wb = pl.Wb;
   if (d_partial_out) HIP_OK(hipMemcpyAsync(d_partial_out, &l->slot.as<MsmSlot>()->win[0], sizeof(G1XYZZ), hipMemcpyDeviceToDevice, st));

@@ -1,19 +1,24 @@
 #!/bin/bash
-# Collects the measurements DESIGN.md section 5 quotes, on one MI355X box:  bash tools/collect_profiles.sh r02
-# Writes gpurun_out/<tag>/...; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh does not touch profiles/).
+# Collects the measurements DESIGN.md section 5 quotes, on one MI355X box:  bash tools/collect_profiles.sh r03
+# Writes gpurun_out/<tag>/...; tools/publish_profiles.sh <tag> copies the summaries into profiles/ afterwards.
 # PMC passes are separate runs with one counter group each and no tracing, as MI355X_MICROARCH.md's HBM section prescribes.
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+python3 tools/cpu_scaling.py --log2 18 > $OUT/cpu_scaling.txt 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/microbench > $OUT/microbench.txt 2>&1
+./tools/ba_bench > $OUT/ba_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm_only -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 5 --warmup 1 > $OUT/msm_only.json 2> $OUT/msm_only.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python3 bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_SQ -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1 > $OUT/pmc_SQ.json 2> $OUT/pmc_SQ.err
+# VALU instruction budget of a proof (3 proofs: 1 warm-up + 2 timed, no pipeline, no stand-alone MSM leg to speak of)
+rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc_valu -o t -- python3 bench.py --no-cpu --no-pipeline --prove-only --steps 2 --warmup 1 > $OUT/pmc_valu.json 2> $OUT/pmc_valu.err
+python3 tools/valu_budget.py $(find $OUT/pmc_valu -name "*counter_collection.csv" | head -1) 3 > $OUT/valu_budget.txt 2>&1
 {
   echo "# python bench.py --no-cpu --log2n <k> (10 streamed proofs after 2 warm-up, Q = 2, d = 8n): ms per proof streamed / strictly sequential"
   for lg in 10 13 14 16 17 18 19 20; do
@@ -30,9 +35,15 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAI
     python3 bench.py --no-cpu --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  streamed %.2f ms  %.3g /s   one at a time %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value'], d['msm']['sequential']['ms_per_msm'], d['msm']['sequential']['scalar_muls_per_s']))"
   done
 } > $OUT/msm_sizes.txt
+{
+  echo "# python bench.py --msm-strong --emulate-world E --no-cpu --steps 10: one GPU doing ONE rank's share of an N = 2^22 MSM split over E ranks (UNMEASURED ON MULTI-GPU HARDWARE: device copy instead of the xGMI all-to-all)"
+  for E in 2 4 8; do
+    python3 bench.py --msm-strong --emulate-world $E --no-cpu --steps 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['msm_strong']; e=d['emulated_share']; print('E=$E  whole MSM on one GPU %.3f ms   one share %.3f ms   ratio %.2f   kernels %s' % (d['ms_per_msm'], e['ms_per_share'], e['speedup_vs_single'], {k: v for k, v in e['kernel_ms'].items() if v >= 0.02}))"
+  done
+} > $OUT/msm_strong_emulated.txt
 python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1
 python3 tools/throughput_mode.py --log2n 18 --proofs 16 >> $OUT/throughput_mode.txt 2>&1
 # timeline of one solo proof (no streaming): where the time of prove() goes
-rocprofv3 --kernel-trace --output-format csv -d $OUT/solo -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pipeline --msm-log2 10 > $OUT/solo.json 2> $OUT/solo.err
-python3 tools/timeline.py $OUT/solo/t_kernel_trace.csv 250 > $OUT/timeline_solo.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/solo -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pipeline --prove-only > $OUT/solo.json 2> $OUT/solo.err
+python3 tools/timeline.py $(find $OUT/solo -name "*kernel_trace.csv" | head -1) 250 > $OUT/timeline_solo.txt 2>&1
 find $OUT -name "*.csv" | head -40

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 --pmc passes of `bench.py --msm-only` (FETCH_SIZE, WRITE_SIZE; one counter per pass, as
-MI355X_MICROARCH.md's HBM section prescribes) into profiles/r02_pmc_msm.json: HBM bytes per launch of every MSM kernel.
+MI355X_MICROARCH.md's HBM section prescribes) into profiles/<round>_pmc_msm.json: HBM bytes per launch of every MSM kernel.
 
     python tools/pmc_summary.py <FETCH_SIZE_counter_collection.csv> <WRITE_SIZE_counter_collection.csv> <msm_n> <c> <W> <sets> > out.json
 
@@ -30,7 +30,7 @@ def main():
            "msm_n": msm_n, "plan": {"window_bits": c, "windows": W, "bucket_sets": sets},
            "method": "MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 128-B requests "
                      "as 64 B, so reads are doubled"}
-    msm_kernels = ["k_part_hist", "k_part_scatter", "k_part_sort", "k_border_hist", "k_border_scatter", "k_bucket_accum",
+    msm_kernels = ["k_part_hist", "k_part_scatter", "k_part_sort", "k_border_hist", "k_border_scatter", "k_border_place", "k_bucket_accum",
                    "k_heavy_accum", "k_heavy_finish", "k_bucket_segments", "k_group_sum", "k_window_sum"]
     total = 0
     for k in msm_kernels:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Copies the summaries of gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/ under the round's prefix, and derives
+# the two JSON files bench.py reads (kernel model, HBM traffic per kernel).   bash tools/publish_profiles.sh r03
+TAG=${1:-r03}
+IN=gpurun_out/$TAG
+P=profiles
+for f in bench.json microbench.txt ba_bench.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt; do
+  [ -f $IN/$f ] && cp $IN/$f $P/${TAG}_$f
+done
+cp $(find $IN/msm_only -name "*kernel_stats.csv" | head -1) $P/${TAG}_msm_only_kernel_stats.csv
+cp $(find $IN/bench_prof -name "*kernel_stats.csv" | head -1) $P/${TAG}_bench_kernel_stats.csv
+for C in FETCH_SIZE WRITE_SIZE SQ; do
+  cp $(find $IN/pmc_$C -name "*counter_collection.csv" | head -1) $P/${TAG}_pmc_${C}_counter_collection.csv
+done
+read c w s < <(python3 -c "import json; j=json.load(open('$IN/bench.json'))['int_roofline']['plan'] if json.load(open('$IN/bench.json')).get('int_roofline',{}).get('plan') else {'window_bits':20,'windows':13,'bucket_sets':1}; print(j['window_bits'], j['windows'], j['bucket_sets'])")
+python3 tools/pmc_summary.py $P/${TAG}_pmc_FETCH_SIZE_counter_collection.csv $P/${TAG}_pmc_WRITE_SIZE_counter_collection.csv 1048576 $c $w $s > $P/${TAG}_pmc_msm.json
+python3 tools/kernel_model.py $TAG $P/${TAG}_microbench.txt > /dev/null
+ls -la $P | grep ${TAG}_

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """VALU instruction budget of prove() per kernel, from a rocprofv3 --pmc SQ_INSTS_VALU pass:
-    rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d out -o t -- python3 bench.py --no-cpu --no-pipeline --steps 2 --warmup 1 --msm-log2 10 --msm-lanes 0
+    rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d out -o t -- python3 bench.py --no-cpu --no-pipeline --prove-only --steps 2 --warmup 1
     python tools/valu_budget.py out/t_counter_collection.csv <proofs in the run: warm-up + timed + 1 (the sequential leg runs none with --no-pipeline)>
 Streamed proofs are bound by instruction issue, so this -- not kernel durations, which overlap -- is where a proof's time goes."""
 import collections
