@@ -258,7 +258,9 @@ def main():
                "frac": round(alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_product": round(t_ms, 4),
                "algorithmic_bytes": alg, "algorithmic_bytes_rule": "288 M: each transform reads and writes M x 32 B once (3 x 64 M) + 96 M for the pointwise product (SURVEY 8d lower bound)",
                "hbm_passes_per_transform": passes, "bytes_by_design": float((3 * passes * 64 + 96) * M),
-               "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products"}
+               "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
+               "note": "the HBM roof is SURVEY 8d's framing; the transforms are bound by VALU issue (one Fr product + add + sub per butterfly, ~400 "
+                       "instructions): fusing three wide stages per pass or two LDS stages per round trip changed nothing (DESIGN.md A.7)"}
         for ptr in (da, db, do):
             L.sonic_dev_free(ptr)
 

@@ -532,6 +532,7 @@ static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
   if (d_partial_out && pl.Wb != 1) { set_error("sonic_msm_submit_dev: this MSM leaves %d window sums for the host to fold (no window tables, or too few terms for them)", pl.Wb); return SONIC_ERR_INVALID_ARG; }
   static const int seg_env = getenv("SONIC_MSM_SEGMENT") ? atoi(getenv("SONIC_MSM_SEGMENT")) : 0;      // tuning knob: buckets per running-sum segment
   if (pl.Wb == 1 && pl.NB >= (1 << 16)) msm_plan_set_segment(pl, seg_env > 0 ? seg_env : l->segment);
+  pl.accum_block = 64;           // a lane's MSM runs alone or beside other lanes' MSMs, not inside a proof (msm.hpp)
   msm_enqueue(st, l->ws, pl, srs->basis(basis) + (e0 + srs->d), dsc, n, false, l->slot.as<MsmSlot>());
   l->Wb = pl.Wb;
   if (d_partial_out) HIP_OK(hipMemcpyAsync(d_partial_out, &l->slot.as<MsmSlot>()->win[0], sizeof(G1XYZZ), hipMemcpyDeviceToDevice, st));
@@ -619,6 +620,7 @@ int sonic_msm_accumulate_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
   fr_check_enqueue(st, dsc, n, l->err.as<int>());
   // always over the tables (a term-range share may be small against the bucket set; every rank must fill the SAME buckets)
   MsmPlan pl = msm_plan_tables(n > 0 ? n : 1, srs->tab_c, srs->tab_W, 2 * srs->d + 1);
+  pl.accum_block = 64;
   MsmJob job{srs->basis(basis) + (e0 + srs->d), dsc, (long)n, nullptr};
   msm_enqueue_batch(st, l->ws, pl, &job, 1, false, static_cast<G1XYZZ*>(d_buckets));
   if (capacity > NB) HIP_OK(hipMemsetAsync(static_cast<G1XYZZ*>(d_buckets) + NB, 0, sizeof(G1XYZZ) * (size_t)(capacity - NB), st));   // padding = infinity

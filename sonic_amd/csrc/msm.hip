@@ -757,7 +757,9 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   }
   LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
          ws.order.as<uint32_t>());
-  LAUNCH(k_bucket_accum, ceil_div((long)M, 256), 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
+  static const int accum_env = [] { const char* e = getenv("SONIC_ACCUM_BLOCK"); const int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();   // tuning knob
+  const int accum_block = accum_env ? accum_env : ((pl.accum_block == 64 || pl.accum_block == 128) ? pl.accum_block : 256);
+  LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
          (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs,
          ws.heavy_items.as<HeavyItem>());
   LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,

@@ -23,6 +23,11 @@ struct MsmPlan {
   int K;        // buckets per running-sum segment
   int nseg;     // segments per window
   uint32_t heavy_threshold;
+  // threads per workgroup of the bucket accumulation.  256 inside prove() (several chains run side by side; measured in round 3:
+  // 34.7 ms per proof against 35.8-36.2 with 64 or 128); 64 for the stand-alone MSM lanes, where one-wave workgroups refill a freed
+  // wave slot without waiting for three more (k_bucket_accum 2.31-2.40 against 2.42-2.45 ms, MSM 2^20 streamed 3.22-3.24 against
+  // 3.33-3.59 ms).  SONIC_ACCUM_BLOCK overrides both.
+  int accum_block = 256;
   // fold scalars s > (r-1)/2 into r - s on the negated point: valid iff r P = O.  Every SRS element is in the r-torsion;
   // caller-supplied points of sonic_msm_g1 only have to be on the curve (E(Fq) has cofactor points, e.g. (0, 2) of order 3),
   // and s P then means the literal multiple the reference's `mul` computes, so that entry point does not fold.

@@ -384,7 +384,7 @@ def test_msm_point_with_zero_coordinate(sonic, orc, srs_pair):
     assert sonic.msm_g1(pts, sc) == orc.msm(pts, sc, 1, NCPU)
 
 
-@pytest.mark.parametrize("log2n", [0, 1, 3, 10, 11, 12, 14])
+@pytest.mark.parametrize("log2n", [0, 1, 3, 10, 11, 12, 13, 14, 15, 17, 18])      # 0, 1, 2, 3, 4, 6, 7 wide stages (radix-4 passes + an odd radix-2 one)
 def test_ntt_matches_oracle(sonic, orc, log2n):
     from sonic_amd import _lib
     n = 1 << log2n
