@@ -8,6 +8,7 @@ test/Test/Protocol.hs:21), so every group element of a proof has a discrete log 
 The GPU proof must equal, byte for byte, the proof rebuilt from those logs (one fixed-base scalar
 multiplication per element on the CPU oracle) and the evaluations -- which is exactly what verify / pcV /
 hscVerify accept (src/Sonic/Protocol.hs:111-130, src/Sonic/Signature.hs:74-90)."""
+import os
 import random
 
 import numpy as np
@@ -136,6 +137,40 @@ def test_prove_bytes_vs_oracle_mid_sizes(sonic, orc, log2n):
     for basis in (0, 1):
         assert np.array_equal(g.points(basis, d - 300, 300), o.points(basis, d - 300, 300))
         assert np.array_equal(g.points(basis, -d, 300), o.points(basis, -d, 300))
+
+
+def test_prove_bytes_vs_oracle_at_the_bench_size(sonic, orc):
+    """BASELINE.json configs[2] exactly as bench.py runs it (n = 2^18, Q = 2, d = 8n = 2^21): the complete proof, byte for byte, against
+    the C oracle's prove() on the host cores (~20-40 s).  The oracle takes the SRS points from the GPU-made SRS (set-up is not part of
+    prove(); generating 8 M points on the host would take minutes), so sampled SRS elements are first checked against the oracle's own
+    fixed-base multiples g^{x^e}, g^{alpha x^e}."""
+    n, Q = 1 << 18, 2
+    d = 8 * n
+    pyr = random.Random(1818)
+    x, alpha = pyr.randrange(2, R), pyr.randrange(2, R)
+    srs = sonic.SRS.new(d, x, alpha)
+    g = orc.g1_gen()
+    for e in [-d, -d + 1, -12345, -1, 0, 1, 2, 777777, d - 1, d] + [pyr.randrange(-d, d + 1) for _ in range(20)]:
+        xe = pow(x, e, R)
+        assert srs.points(0, e, 1)[0].tobytes() == orc.g1_mul(g, xe)
+        if e != 0:
+            assert srs.points(1, e, 1)[0].tobytes() == orc.g1_mul(g, alpha * xe % R)
+    cores = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1), threads=cores)
+    circ = big_circuit(1818, n, Q)
+    tr = fr_bytes([pyr.randrange(2, R) for _ in range(8 + 2 * Q)])
+    orc.set_mode(1, cores)
+    want = orc.prove(osrs, n, Q, circ["wL"], circ["wR"], circ["wO"], circ["cs"], circ["aL"], circ["aR"], circ["aO"], tr, True)
+    pr = sonic.Prover(srs, sonic.ArithCircuit(sonic.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"]))
+    pr.set_assignment(sonic.Assignment(circ["aL"], circ["aR"], circ["aO"]))
+    assert pr.prove_bytes(tr) == want
+    pr.close()
 
 
 def test_msm_full_size_properties(sonic, orc):
