@@ -128,12 +128,12 @@ def _worker(rank, world, port, n_terms, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_terms", [5000, 3])
-def test_range_sharded_msm_two_ranks_one_gpu(n_terms):
+@pytest.mark.parametrize("n_terms,world", [(5000, 2), (3, 2), (5000, 4), (3, 4)])       # 3 terms over 4 ranks: two ranks have nothing
+def test_range_sharded_msm_ranks_share_one_gpu(n_terms, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_terms, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_terms, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
