@@ -36,12 +36,24 @@ def sonic_protocol(circuit, assignment, x: int) -> bool:
     return S.verify(srs, circuit, proof, oracle.rndOracleY, oracle.rndOracleZ, oracle.rndOracleYZs)
 
 
+def sonic_protocol_fs(circuit, assignment, x: int) -> bool:
+    """the same with the opt-in Fiat-Shamir transcript: the proof carries its own challenges, the verifier recomputes them"""
+    n = len(assignment.aL)
+    srs = S.SRS.new(25 * n, x, secrets.randbelow(R - 1) + 1)
+    proof, _oracle = S.prove_fs(srs, assignment, circuit)
+    return S.verify_fs(srs, circuit, proof)
+
+
 def run_example() -> bool:
     x = secrets.randbelow(R - 1) + 1
     z = secrets.randbelow(R)
     circuit, assignment = arith_circuit_example(z)
     ok = sonic_protocol(circuit, assignment, x)
     print(f"Success: {ok}")
+    if "--fs" in sys.argv:
+        fs = sonic_protocol_fs(circuit, assignment, x)
+        print(f"Success (Fiat-Shamir transcript): {fs}")
+        ok = ok and fs
     return ok
 
 

@@ -692,6 +692,7 @@ def test_reference_example_program(sonic):
     spec.loader.exec_module(ex)
     assert ex.run_example() is True
     circuit, asg = ex.arith_circuit_example(5)
+    assert ex.sonic_protocol_fs(circuit, asg, 12345) is True           # the same with the Fiat-Shamir transcript
     bad = sonic.Assignment(asg.aL, asg.aR, [(asg.aO[0] + 1) % R, asg.aO[1]])
     with pytest.raises(sonic.SonicError) as e:
         ex.sonic_protocol(circuit, bad, 12345)
