@@ -798,7 +798,11 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
   // buckets per running-sum segment of a slice: a rank's 1/world of the buckets leaves most of the chip idle, so the chain, not the
   // work, is what counts -- shorter segments, more threads (tuning knob SONIC_SLICE_SEGMENT: 1, 2, 4 or 8)
   static const int K_env = getenv("SONIC_SLICE_SEGMENT") ? atoi(getenv("SONIC_SLICE_SEGMENT")) : 0;
-  const int K = (K_env == 1 || K_env == 2 || K_env == 4 || K_env == 8) ? K_env : MSM_SLICE_SEGMENT;
+  // default: 2 for the slices of 8 ranks (65536 buckets: the chip is nearly empty, the chain is what counts), growing with the slice so
+  // that there are never more than 65536 segments (one wave per SIMD), as for a whole bucket set
+  int K = MSM_SLICE_SEGMENT;
+  while (K < 8 && len / K > 65536) K *= 2;
+  if (K_env == 1 || K_env == 2 || K_env == 4 || K_env == 8) K = K_env;
   if (k < 1 || len < K || len % MSM_SLICE_QUANTUM || base % MSM_SLICE_QUANTUM || base + len >= (1L << 31))
     throw std::runtime_error("msm_reduce_slices_enqueue: slice length and base must be multiples of MSM_SLICE_QUANTUM");
   const int nseg = (int)(len / K);
