@@ -428,7 +428,8 @@ def main():
         # the on-hardware microbenchmarks), not constants in this file.
         pc, pw_, pb = C.c_int(), C.c_int(), C.c_int()
         L.sonic_msm_plan(srs._h, msm_n, C.byref(pc), C.byref(pw_), C.byref(pb))
-        roofline["bytes_by_design_per_launch"] = float((4 + 96) * pw_.value * msm_n) if pb.value == 1 else None   # 4-B sorted entry + 96-B table point per (term, window)
+        # by design the table method reads a 4-B sorted entry and one table point (one 128-B line since the tables are padded) per (term, window)
+        roofline["bytes_by_design_per_launch"] = float((4 + L.sonic_srs_point_bytes()) * pw_.value * msm_n) if pb.value == 1 else None
         model, model_src = load_profile_json("kernel_model.json")
         n_adds = pw_.value * msm_n - (1 << (pc.value - 1)) * pb.value
         adds_per_s = n_adds / (accum_ms * 1e-3) if accum_ms > 0 else 0.0

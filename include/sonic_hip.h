@@ -158,6 +158,9 @@ int sonic_ntt_fr(uint8_t* data, int log2n, int inverse);
 int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out);
 /* the same with operands and result resident in HBM (device pointers to canonical Fr; d_out: na + nb - 1 elements) */
 int sonic_poly_mul_fr_dev(const void* d_a, int64_t na, const void* d_b, int64_t nb, void* d_out);
+/* bytes between consecutive points of an SRS basis / window table in HBM (128: one HBM line per 96-byte point); what a bucket walk
+ * reads per (term, window) by design */
+int sonic_srs_point_bytes(void);
 /* MSM tuning knob for tests: window bits (0 = automatic) */
 int sonic_msm_set_window(int c);
 /* what an n-term MSM over this SRS will run as: window bits, number of windows, and bucket sets

@@ -80,6 +80,7 @@ def lib() -> C.CDLL:
         "sonic_poly_mul_fr": [vp, i64, vp, i64, vp],
         "sonic_poly_mul_fr_dev": [vp, i64, vp, i64, vp],
         "sonic_msm_set_window": [i32],
+        "sonic_srs_point_bytes": [],
         "sonic_msm_plan": [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "sonic_prove": [vp, i64, i64] + [vp] * 9,
         "sonic_prover_new": [vp, i64, i64, vp, vp, vp, vp, C.POINTER(vp)],
@@ -135,7 +136,7 @@ EXPORTED = [
     "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_has_g2", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
     "sonic_g1_sum_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_msm_lane_new_on_stream", "sonic_msm_submit_dev", "sonic_msm_exchange_layout",
-    "sonic_msm_accumulate_dev", "sonic_msm_reduce_slices_dev", "sonic_msm_lane_sync", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_poly_mul_fr_dev", "sonic_msm_set_window", "sonic_msm_plan",
+    "sonic_msm_accumulate_dev", "sonic_msm_reduce_slices_dev", "sonic_msm_lane_sync", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_poly_mul_fr_dev", "sonic_msm_set_window", "sonic_srs_point_bytes", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
     "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare", "sonic_fs_circuit_digest", "sonic_prover_prove_fs", "sonic_fs_challenges", "sonic_verify_fs", "sonic_prover_hsc_prove", "sonic_hsc_prove_poly", "sonic_hsc_verify_poly", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
     "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",

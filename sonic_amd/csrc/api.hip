@@ -64,7 +64,7 @@ std::mutex& call_mutex() { return g_call_mu; }
 // inf_ok: index at which the point at infinity is accepted (-1: everywhere, as for the operands of sonic_msm_g1; -2: nowhere; an SRS has
 // exactly one such slot, the omitted g^alpha); elsewhere infinity sets err bit 8 -- g^{x^e} and g^{alpha x^e} are never the
 // identity for x, alpha != 0, and a zero-filled SRS must not pass for a valid one
-__global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, long n, int* err, long inf_ok) {
+__global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __restrict__ in, PointArrayMut out, long n, int* err, long inf_ok) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(in + 96 * i);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_points_from_bytes(const uint8_t* __rest
 }
 // r P == O for every point (literal double-and-add over the bits of r): SRS elements must lie in the order-r subgroup because
 // MSMs over an SRS fold scalars with r P = O (msm.hpp).  Sets err bit 4 otherwise.
-__global__ __launch_bounds__(256) void k_points_subgroup_check(const G1Affine* __restrict__ in, long n, int* err) {
+__global__ __launch_bounds__(256) void k_points_subgroup_check(PointArray in, long n, int* err) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const G1Affine p = in[i];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_points_subgroup_check(const G1Affine* _
   }
   if (!acc.is_inf()) atomicOr(err, 4);
 }
-__global__ __launch_bounds__(256) void k_points_to_bytes(const G1Affine* __restrict__ in, uint8_t* __restrict__ out, long n) {
+__global__ __launch_bounds__(256) void k_points_to_bytes(PointArray in, uint8_t* __restrict__ out, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Affine p = in[i];
@@ -129,7 +129,7 @@ void fr_from_mont_enqueue(hipStream_t st, Fr* d, long n) { if (n > 0) LAUNCH(k_f
 void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err) { if (n > 0) LAUNCH(k_fr_check, ceil_div(n, 256), 256, 0, st, d, n, d_err); }
 
 // one MSM, finished and normalised, result on the host
-void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
+void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArray d_pts, const Fr* d_sc, long n, bool mont,
                   uint8_t* out96, uint8_t* out_partial192) {
   DevBuf slot(sizeof(MsmSlot));
   msm_enqueue(st, ws, pl, d_pts, d_sc, n, mont, slot.as<MsmSlot>());
@@ -169,11 +169,11 @@ struct sonic_srs {
     for (int i = 0; i < 8; i++) { a[i] = 0; b[i] = 0; }
     have_trapdoor = false;
   }
-  const G1Affine* basis(int b) const { return (b ? ga : g).as<G1Affine>(); }
+  PointArray basis(int b) const { return PointArray{(b ? ga : g).as<char>(), SONIC_SRS_POINT_BYTES}; }
 };
 
 namespace sonic {
-const G1Affine* srs_basis(const sonic_srs* s, int b) { return s->basis(b); }
+PointArray srs_basis(const sonic_srs* s, int b) { return s->basis(b); }
 int64_t srs_d(const sonic_srs* s) { return s->d; }
 int srs_tab_c(const sonic_srs* s) { return s->tab_c; }
 int srs_tab_W(const sonic_srs* s) { return s->tab_W; }
@@ -197,14 +197,14 @@ sonic_srs* srs_alloc(int64_t d) {
   const char* env = getenv("SONIC_MSM_TABLES");
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  const size_t need = 2 * n * sizeof(G1Affine) * (size_t)W;
+  const size_t need = 2 * n * (size_t)SONIC_SRS_POINT_BYTES * (size_t)W;
   if ((env && atoi(env) == 0) || need > free_b / 2) { c = 0; W = 1; }
   s->tab_c = c; s->tab_W = W;
-  s->g.alloc(sizeof(G1Affine) * n * W);
-  s->ga.alloc(sizeof(G1Affine) * n * W);
+  s->g.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
+  s->ga.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
   return s;
 }
-G1Affine* srs_basis_mut(sonic_srs* s, int b) { return (b ? s->ga : s->g).as<G1Affine>(); }
+PointArrayMut srs_basis_mut(sonic_srs* s, int b) { return PointArrayMut{(b ? s->ga : s->g).as<char>(), SONIC_SRS_POINT_BYTES}; }
 void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std) { s->have_trapdoor = true; s->x_std = x_std; s->alpha_std = alpha_std; }
 
 // plan for an MSM over n consecutive SRS points: shared-bucket plan over the window tables unless the MSM is
@@ -265,7 +265,7 @@ int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis
     HIP_OK(hipMemcpyAsync(raw.p, b ? basis1 : basis0, 96 * n, hipMemcpyHostToDevice, st));
     LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), srs_basis_mut(s, b), n, err.as<int>(),
            b ? (long)d : -2L);        // basis 1 has the empty slot e = 0 (SRS.hs:38); basis 0 has none
-    LAUNCH(k_points_subgroup_check, ceil_div(n, 256), 256, 0, st, (const G1Affine*)srs_basis_mut(s, b), n, err.as<int>());
+    LAUNCH(k_points_subgroup_check, ceil_div(n, 256), 256, 0, st, (PointArray)srs_basis_mut(s, b), n, err.as<int>());
   }
   int herr = 0;
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
@@ -419,6 +419,7 @@ int sonic_srs_load(const char* path, sonic_srs_t** out) {
 }
 
 int sonic_msm_set_window(int c) { msm_set_window_override(c); return SONIC_OK; }
+int sonic_srs_point_bytes(void) { return SONIC_SRS_POINT_BYTES; }
 
 int sonic_msm_plan(const sonic_srs_t* srs, int64_t n, int* window_bits, int* windows, int* bucket_sets) {
   if (!srs || n < 0) return SONIC_ERR_INVALID_ARG;
@@ -441,14 +442,15 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
   if (n > 0) {
     HIP_OK(hipMemcpyAsync(raw.p, points, 96 * n, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(sc.p, scalars, 32 * n, hipMemcpyHostToDevice, st));
-    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), pts.as<G1Affine>(), (long)n, err.as<int>(), -1L);
+    LAUNCH(k_points_from_bytes, ceil_div(n, 256), 256, 0, st, (const uint8_t*)raw.as<uint8_t>(), PointArrayMut{pts.as<char>(), (uint32_t)sizeof(G1Affine)}, (long)n,
+           err.as<int>(), -1L);
     fr_check_enqueue(st, sc.as<Fr>(), n, err.as<int>());
   }
   int herr = 0;
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) { set_error("sonic_msm_g1: non-canonical input or point not on curve"); return SONIC_ERR_BAD_ENCODING; }
-  msm_blocking(st, shared_msm_ws(), msm_plan(n > 0 ? n : 1, /*fold=*/false), pts.as<G1Affine>(), sc.as<Fr>(), n, false, out_g1, nullptr);
+  msm_blocking(st, shared_msm_ws(), msm_plan(n > 0 ? n : 1, /*fold=*/false), PointArray::packed(pts.as<G1Affine>()), sc.as<Fr>(), n, false, out_g1, nullptr);
   API_END
 }
 

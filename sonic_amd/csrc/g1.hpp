@@ -20,6 +20,29 @@ struct G1Affine {
   static HD G1Affine inf() { G1Affine p; p.x = Fq::zero(); p.y = Fq::zero(); return p; }
 };
 
+// Affine points at a byte stride.  Caller-supplied point arrays are packed (96 B); the SRS bases and their window tables sit at
+// SONIC_SRS_POINT_BYTES = 128: one HBM line per point.  A 96-B point at a 96-B stride straddles two 128-B lines half of the time, and
+// the bucket walks gather table points at random: padded, a gather touches one line instead of 1.5 (measured on the walk itself,
+// tools/ba_bench: 5.90 against 5.75 x 10^9 additions/s; HBM traffic of k_bucket_accum -1/3) for +33 % table memory -- HBM capacity
+// (288 GB) is what this design spends.
+#ifndef SONIC_SRS_POINT_BYTES
+#define SONIC_SRS_POINT_BYTES 128
+#endif
+struct PointArray {
+  const char* p;
+  uint32_t stride;
+  HD const G1Affine& operator[](size_t i) const { return *reinterpret_cast<const G1Affine*>(p + i * (size_t)stride); }
+  HD PointArray operator+(long i) const { return PointArray{p + i * (long)stride, stride}; }
+  static HD PointArray packed(const G1Affine* a) { return PointArray{reinterpret_cast<const char*>(a), (uint32_t)sizeof(G1Affine)}; }
+};
+struct PointArrayMut {
+  char* p;
+  uint32_t stride;
+  HD G1Affine& operator[](size_t i) const { return *reinterpret_cast<G1Affine*>(p + i * (size_t)stride); }
+  HD PointArrayMut operator+(long i) const { return PointArrayMut{p + i * (long)stride, stride}; }
+  HD operator PointArray() const { return PointArray{p, stride}; }
+};
+
 struct G1XYZZ {
   Fq x, y, zz, zzz;
   HD bool is_inf() const { return zz.is_zero_strict(); }     // ZZ = 0 is written, never computed: ZZ3 = ZZ1 * PP with PP != 0

@@ -13,8 +13,8 @@ MsmWorkspace& shared_msm_ws();
 std::mutex& call_mutex();
 
 // SRS handle internals (api.hip)
-const G1Affine* srs_basis(const sonic_srs* s, int b);
-G1Affine* srs_basis_mut(sonic_srs* s, int b);
+PointArray srs_basis(const sonic_srs* s, int b);            // table 0 of a basis, slot e + d; window table w follows at + w (2d+1)
+PointArrayMut srs_basis_mut(sonic_srs* s, int b);
 int64_t srs_d(const sonic_srs* s);
 sonic_srs* srs_alloc(int64_t d);
 
@@ -22,7 +22,7 @@ sonic_srs* srs_alloc(int64_t d);
 void fr_to_mont_enqueue(hipStream_t st, Fr* d, long n, int* d_err);
 void fr_from_mont_enqueue(hipStream_t st, Fr* d, long n);
 void fr_check_enqueue(hipStream_t st, const Fr* d, long n, int* d_err);
-void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_pts, const Fr* d_sc, long n, bool mont,
+void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArray d_pts, const Fr* d_sc, long n, bool mont,
                   uint8_t* out96, uint8_t* out_partial192);
 int srs_tab_c(const sonic_srs* s);
 int srs_tab_W(const sonic_srs* s);

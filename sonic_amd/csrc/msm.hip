@@ -158,7 +158,8 @@ __device__ __forceinline__ uint32_t size_class(uint32_t sz) { return 255u - (sz 
 struct MsmBatchDev {
   int k;
   uint32_t tile0[MSM_MAX_JOBS + 1];
-  const G1Affine* points[MSM_MAX_JOBS];
+  const char* points[MSM_MAX_JOBS];
+  uint32_t pt_stride;                    // bytes between the points of every job (PointArray)
   const Fr* scalars[MSM_MAX_JOBS];
   long n[MSM_MAX_JOBS];
   MsmSlot* slot[MSM_MAX_JOBS];
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
   const uint32_t b = order[t];
   const uint32_t beg = off[b], end = off[b + 1];
   const uint32_t cnt = end - beg;
-  const G1Affine* __restrict__ pts = batch.points[b / jobstride];
+  const PointArray pts{batch.points[b / jobstride], batch.pt_stride};
   if (cnt > heavy_t) {
     uint32_t ns = (cnt + HEAVY_SEG - 1) / HEAVY_SEG;
     uint32_t base = atomicAdd(&hm->n_items, ns);
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_heavy_accum(const MsmBatchDev batch,
   const uint32_t n_items = hm->n_items;
   for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
     const HeavyItem item = items[it];
-    const G1Affine* __restrict__ pts = batch.points[item.bucket / jobstride];
+    const PointArray pts{batch.points[item.bucket / jobstride], batch.pt_stride};
     const uint32_t beg = off[item.bucket] + item.seg * HEAVY_SEG;
     uint32_t end = beg + HEAVY_SEG;
     const uint32_t bend = off[item.bucket + 1];
@@ -717,9 +718,11 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   MsmBatchDev batch;
   memset(&batch, 0, sizeof batch);
   batch.k = k;
+  batch.pt_stride = jobs[0].points.stride;
   long n_total = 0;
   for (int j = 0; j < k; j++) {
-    batch.points[j] = jobs[j].points; batch.scalars[j] = jobs[j].scalars; batch.n[j] = jobs[j].n; batch.slot[j] = jobs[j].slot;
+    if (jobs[j].points.stride != jobs[0].points.stride) throw std::runtime_error("msm_enqueue_batch: the jobs of a batch must share the point stride");
+    batch.points[j] = jobs[j].points.p; batch.scalars[j] = jobs[j].scalars; batch.n[j] = jobs[j].n; batch.slot[j] = jobs[j].slot;
     batch.tile0[j + 1] = batch.tile0[j] + (uint32_t)ceil_div(jobs[j].n, PART_TILE);
     n_total += jobs[j].n;
   }
@@ -828,7 +831,7 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
   }
 }
 
-void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points, const Fr* d_scalars,
+void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArray d_points, const Fr* d_scalars,
                  long n, bool scalars_mont, MsmSlot* d_slot) {
   MsmJob job{d_points, d_scalars, n, d_slot};
   msm_enqueue_batch(st, ws, pl, &job, 1, scalars_mont);

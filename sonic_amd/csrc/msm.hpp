@@ -62,14 +62,14 @@ struct MsmWorkspace {
 // Queues one MSM on `st`: sum_i scalars[i] * points[i].  `scalars_mont` tells whether the Fr
 // values are in Montgomery form (polynomial coefficient arrays are) or standard form (ABI inputs).
 // Writes the W per-window sums into *d_slot.
-void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const G1Affine* d_points,
+void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArray d_points,
                  const Fr* d_scalars, long n, bool scalars_mont, MsmSlot* d_slot);
 
 // Several MSMs as ONE kernel chain (shared-bucket plans over window tables only): job j owns bucket set j, so the
 // latency-bound phases (running sums, trees, sort passes) run k times wider instead of k times in a row.  The jobs may
 // differ in size, points and scalars; they share the plan (c, W, table stride).  k <= MSM_MAX_JOBS.
 constexpr int MSM_MAX_JOBS = 8;
-struct MsmJob { const G1Affine* points; const Fr* scalars; long n; MsmSlot* slot; };
+struct MsmJob { PointArray points; const Fr* scalars; long n; MsmSlot* slot; };      // the jobs of a batch share the point stride
 bool msm_can_batch(const MsmPlan& pl);
 // ext_buckets (k == 1, shared-bucket plan): the chain stops after the accumulation and leaves the NB bucket sums there
 // instead of reducing them -- the first half of an MSM whose buckets are sharded across ranks.

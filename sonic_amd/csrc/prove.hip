@@ -515,7 +515,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
       Lane* ln = cur;
       auto small = [&, ln, j] {
         msm_enqueue(ln->st, ln->ws, p->cq_tab.p ? msm_plan_tables(Q, CQ_TAB_C, CQ_TAB_W, Q) : msm_plan(Q),
-                    p->cq_tab.p ? p->cq_tab.as<G1Affine>() : p->cq.as<G1Affine>(), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
+                    PointArray::packed(p->cq_tab.p ? p->cq_tab.as<G1Affine>() : p->cq.as<G1Affine>()), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
       };
       if (cur->njobs == 0) small(); else after_flush.push_back(small);
     }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_srs_points(const G1Affine* __restrict__
 }
 
 // Montgomery's trick over chunks of 64 points: one Fq inversion per chunk.
-__global__ __launch_bounds__(64) void k_batch_affine(const G1XYZZ* __restrict__ in, G1Affine* __restrict__ out, Fq* __restrict__ pref, long n) {
+__global__ __launch_bounds__(64) void k_batch_affine(const G1XYZZ* __restrict__ in, PointArrayMut out, Fq* __restrict__ pref, long n) {
   constexpr int CH = 64;
   long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long lo = c * CH, hi = lo + CH;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_batch_affine(const G1XYZZ* __restrict__ 
 }
 
 // dst[i] = 2^c * src[i]
-__global__ __launch_bounds__(256) void k_table_step(const G1Affine* __restrict__ src, G1XYZZ* __restrict__ dst, long m, int c) {
+__global__ __launch_bounds__(256) void k_table_step(PointArray src, G1XYZZ* __restrict__ dst, long m, int c) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const G1Affine p = src[i];
@@ -97,11 +97,11 @@ void srs_build_tables(hipStream_t st, sonic_srs* s) {
   const long cap = n < SLAB ? n : SLAB;
   DevBuf x(sizeof(G1XYZZ) * cap), pref(sizeof(Fq) * cap);
   for (int b = 0; b < 2; b++) {
-    G1Affine* tab = srs_basis_mut(s, b);
+    const PointArrayMut tab = srs_basis_mut(s, b);
     for (int w = 1; w < W; w++) {
       for (long base = 0; base < n; base += SLAB) {
         const long m = n - base < SLAB ? n - base : SLAB;
-        LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (const G1Affine*)(tab + (size_t)(w - 1) * n + base), x.as<G1XYZZ>(), m,
+        LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (PointArray)(tab + (long)((size_t)(w - 1) * n + base)), x.as<G1XYZZ>(), m,
                msm_even_width(W, w - 1));
         LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), tab + (size_t)w * n + base, pref.as<Fq>(), m);
       }

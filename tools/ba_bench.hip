@@ -77,6 +77,24 @@ __global__ __launch_bounds__(256, 2) void k_ba_round(const G1Affine* __restrict_
   }
 }
 
+// The fused XYZZ walk of k_bucket_accum on the same footing: every thread adds `B` table points, gathered at random places, into
+// one accumulator, two-deep software pipeline as in the kernel.  `stride` = bytes between table points: 96 (packed, as the SRS tables
+// are: half of the points straddle two 128-B lines) or 128 (one line per point, +33 % table memory).
+__global__ __launch_bounds__(256, 2) void k_walk(const char* __restrict__ pts, const uint2* __restrict__ idx, int B, uint32_t stride, G1XYZZ* __restrict__ out) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  auto pt = [&](uint32_t i) { return *reinterpret_cast<const G1Affine*>(pts + (size_t)i * stride); };
+  uint32_t e_cur = idx[tid].x, e_nxt = idx[nth + tid].x;
+  G1XYZZ acc = G1XYZZ::from_affine(pt(idx[tid].y));
+  G1Affine p_cur = pt(e_cur);
+  for (int i = 0; i < B; i++) {
+    const uint32_t e_nn = idx[(size_t)(i + 2 < B ? i + 2 : B - 1) * nth + tid].x;
+    const G1Affine p_nxt = pt(e_nxt);
+    acc = g1_add_mixed_walk(acc, p_cur);
+    p_cur = p_nxt; e_nxt = e_nn;
+  }
+  out[tid] = acc;
+}
+
 int main(int argc, char** argv) {
   CK(hipSetDevice(0));
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
@@ -111,6 +129,24 @@ int main(int argc, char** argv) {
         printf("%s operands  B=%3d  inversion = %3d products: %8.3f ms  %.3e additions/s  (%.2f TB/s by design)\n", gather ? "gathered " : "sequential", B, inv_cost,
                ms, adds / (ms * 1e-3), bytes / (ms * 1e-3) / 1e12);
       }
+  {
+    // the same 13 x 2^20 table points at a 96-B and at a 128-B stride (the 128-B table reuses the first 3/4 of the points)
+    const uint32_t T128 = (uint32_t)(((size_t)T * 96) / 128);
+    for (uint32_t stride : {96u, 128u}) {
+      const uint32_t Tn = stride == 96 ? T : T128;
+      const int B = 26;
+      hipLaunchKernelGGL(k_idx, (unsigned)((nth * B + 255) / 256), 256, 0, 0, idx, nth * B, Tn, 1);
+      hipLaunchKernelGGL(k_walk, blocks, threads, 0, 0, (const char*)pts, (const uint2*)idx, B, stride, (G1XYZZ*)out);
+      CK(hipDeviceSynchronize());
+      const int reps = 5;
+      hipEventRecord(e0, 0);
+      for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_walk, blocks, threads, 0, 0, (const char*)pts, (const uint2*)idx, B, stride, (G1XYZZ*)out);
+      hipEventRecord(e1, 0);
+      CK(hipEventSynchronize(e1));
+      float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("fused XYZZ walk, %u-B point stride, %d gathered points per thread: %8.3f ms  %.3e additions/s\n", stride, B, ms, (double)nth * B / (ms * 1e-3));
+    }
+  }
   printf("reference: fused XYZZ mixed addition 6.53e9 additions/s from registers only, 5.65e9/s inside k_bucket_accum (profiles/r02_microbench.txt, bench.py)\n");
   return 0;
 }
