@@ -147,6 +147,6 @@ int main(int argc, char** argv) {
       printf("fused XYZZ walk, %u-B point stride, %d gathered points per thread: %8.3f ms  %.3e additions/s\n", stride, B, ms, (double)nth * B / (ms * 1e-3));
     }
   }
-  printf("reference: fused XYZZ mixed addition 6.53e9 additions/s from registers only, 5.65e9/s inside k_bucket_accum (profiles/r02_microbench.txt, bench.py)\n");
+  printf("reference: fused XYZZ mixed addition 6.53e9 additions/s from registers only, 5.65e9/s inside k_bucket_accum (tools/microbench, bench.py)\n");
   return 0;
 }
