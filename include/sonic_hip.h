@@ -191,6 +191,29 @@ int sonic_prover_submit(sonic_prover_t* p, const uint8_t* transcript);
 int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof);
 void sonic_prover_free(sonic_prover_t* p);
 
+/* ---- ONE proof over several GPUs ----
+ * The 7 + 4Q commitments and openings of prove + hscProve (Protocol.hs:63,73,79-81; Signature.hs:40-45,51-57,63) are independent
+ * sums once the transcript is known.  Every rank (one process per GPU) makes a handle for the same circuit and assignment over its
+ * replica of the SRS and calls set_share(rank, world): the handle then builds only the polynomials its pieces read and runs a
+ * contiguous piece of the proof's MSMs laid end to end (a cut inside an MSM splits its term range), balanced by a cost model
+ * (sonic_amd/csrc/share_plan.hpp).  submit + collect_share (or prove_share) with the SAME transcript on every rank yield one share
+ * per rank -- un-normalised 192-byte partial sums per MSM, the evaluations the rank computed, its error flags: sonic_proof_share_size
+ * bytes; the caller all-gathers them (RCCL / any transport) and sonic_proof_from_shares lays out the proof, byte-identical to
+ * sonic_prover_prove on one GPU.  world <= 1 restores the whole proof.  Not available for sonic_prover_prove_fs (the Fiat-Shamir
+ * chain serialises the MSMs). */
+int sonic_prover_set_share(sonic_prover_t* p, int rank, int world);
+size_t sonic_proof_share_size(int64_t Q);
+int sonic_prover_prove_share(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_share);
+int sonic_prover_collect_share(sonic_prover_t* p, uint8_t* out_share);       /* after sonic_prover_submit */
+/* shares: world x sonic_proof_share_size(Q) bytes in any rank order; host only.  Fails with SONIC_ERR_INVALID_ARG unless the pieces
+ * of every MSM cover its terms exactly once and every evaluation is reported; a rank's error flags become the status sonic_prove
+ * would have returned. */
+int sonic_proof_from_shares(int64_t Q, int world, const uint8_t* shares, const uint8_t* transcript, uint8_t* out_proof);
+/* the plan itself (host only): out_lo_hi = 7 + 4Q pairs {lo, hi} in units of 1 / 2^20 of each MSM's terms, slot order R, T, W_a,
+ * W_b, W_t, [S_j, W_j]_j, [W'_j, Q_j]_j, Q_v, C; out_cost (may be NULL): the rank's modelled cost in MSM terms.  nb, w: buckets per
+ * set and windows of the MSM plan (0, 0: 2^19 and 13, an SRS with window tables at d >= 2^21). */
+int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int rank, int64_t nb, int w, uint32_t* out_lo_hi, double* out_cost);
+
 /* ---- opt-in Fiat-Shamir transcript ----
  * The reference draws its challenges with `rnd` (Protocol.hs:58,66,76,84-85; Signature.hs:48,60) and hands y, z, (y_j, z_j) to the
  * verifier as RndOracle.  In this mode each draw is instead SHA-256 of everything that precedes it, in that order (exact

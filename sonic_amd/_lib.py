@@ -89,6 +89,11 @@ def lib() -> C.CDLL:
         "sonic_prover_submit": [vp, vp],
         "sonic_prover_collect": [vp, vp],
         "sonic_prover_prepare": [vp],
+        "sonic_prover_set_share": [vp, i32, i32],
+        "sonic_prover_prove_share": [vp, vp, vp],
+        "sonic_prover_collect_share": [vp, vp],
+        "sonic_proof_from_shares": [i64, i32, vp, vp, vp],
+        "sonic_prove_share_plan": [i64, i64, i32, i32, i32, i64, i32, vp, C.POINTER(C.c_double)],
         "sonic_fs_circuit_digest": [i64, i64, vp, vp, vp, vp, vp],
         "sonic_prover_prove_fs": [vp, cp, cp, vp, vp],
         "sonic_fs_challenges": [i64, i64, i64, cp, vp, vp],
@@ -127,6 +132,8 @@ def lib() -> C.CDLL:
     L.sonic_proof_size.restype = C.c_size_t
     L.sonic_hsc_proof_size.argtypes = [i64]
     L.sonic_hsc_proof_size.restype = C.c_size_t
+    L.sonic_proof_share_size.argtypes = [i64]
+    L.sonic_proof_share_size.restype = C.c_size_t
     _lib = L
     return L
 
@@ -138,7 +145,8 @@ EXPORTED = [
     "sonic_g1_sum_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_msm_lane_new_on_stream", "sonic_msm_submit_dev", "sonic_msm_exchange_layout",
     "sonic_msm_accumulate_dev", "sonic_msm_reduce_slices_dev", "sonic_msm_lane_sync", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_poly_mul_fr_dev", "sonic_msm_set_window", "sonic_srs_point_bytes", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
-    "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare", "sonic_fs_circuit_digest", "sonic_prover_prove_fs", "sonic_fs_challenges", "sonic_verify_fs", "sonic_prover_hsc_prove", "sonic_hsc_prove_poly", "sonic_hsc_verify_poly", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
+    "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare",
+    "sonic_prover_set_share", "sonic_proof_share_size", "sonic_prover_prove_share", "sonic_prover_collect_share", "sonic_proof_from_shares", "sonic_prove_share_plan", "sonic_fs_circuit_digest", "sonic_prover_prove_fs", "sonic_fs_challenges", "sonic_verify_fs", "sonic_prover_hsc_prove", "sonic_hsc_prove_poly", "sonic_hsc_verify_poly", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
     "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",
     "sonic_profile_names",
 ]

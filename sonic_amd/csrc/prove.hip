@@ -22,6 +22,7 @@
 #include "internal.hpp"
 #include "poly.hpp"
 #include "fs.hpp"
+#include "share_plan.hpp"
 
 namespace sonic {
 
@@ -199,6 +200,13 @@ struct sonic_prover {
   std::vector<hipEvent_t> ev_syj;
   int log2m = 0;
   std::mutex mu;
+  // ONE proof over several GPUs (sonic_prover_set_share, share_plan.hpp): this handle runs rank share_rank's pieces of the proof's
+  // MSMs and reports un-normalised partial sums (sonic_prover_collect_share); share_world <= 1: the whole proof
+  int share_rank = 0, share_world = 0;
+  SharePlan share;
+  bool share_planned_prepared = false, share_planned = false;
+  std::vector<uint8_t> slot_ran;             // per slot (7 + 5Q): the last enqueue queued an MSM for it
+  std::vector<uint8_t> fr_valid;             // per evaluation (3 + 2Q): the last enqueue computed it
   // Lane N_LANES-1 carries the t(X,y) group (the largest, ready last); the other groups alternate over the rest, which
   // balances the point additions per lane (Q = 2: 55M / 51M / 48M) while one lane's sort and reduction phases run under
   // another lane's accumulation.  Streams beyond the 4 hardware queues would serialise behind each other.
@@ -366,6 +374,12 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // evaluation points feed `pow x e` with negative e (Utils.hs:18, poly's eval): x = 0 has no inverse
   for (long k = 4; k < 8 + 2 * Q; k++)
     if (bytes_are_zero(transcript + 32 * k, 32)) { set_error("prove: transcript element %ld is zero: Laurent evaluation at 0 divides by zero", k); return SONIC_ERR_INEXACT_DIVISION; }
+  if (p->share_world > 1 && (!p->share_planned || p->share_planned_prepared != p->prepared)) {
+    const MsmPlan mp = srs_msm_plan(srs, 3 * n);
+    p->share = share_plan(n, Q, p->prepared, p->share_world, mp.NB, mp.W, ShareCosts::from_env());
+    p->share_planned = true; p->share_planned_prepared = p->prepared;
+  }
+  if (p->share_world > 1 && p->phases != PH_ALL) { set_error("prove: a shared proof runs with a caller-supplied transcript only"); return SONIC_ERR_INVALID_ARG; }
   int* flags = p->flags.as<int>();
   memcpy(p->h_tr, transcript, 32 * (8 + 2 * Q));
   {
@@ -424,6 +438,35 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   p->next_lane = 0;
   auto ready = [&](hipEvent_t e) { HIP_OK(hipEventRecord(e, ms)); };
   auto on = [&](int ph) { return ((p->phases >> ph) & 1u) != 0; };
+  // one proof over several GPUs: this rank's pieces of the MSMs (share_plan.hpp); sh == nullptr: everything
+  const SlotShare* sh = p->share_world > 1 ? p->share.row(p->share_rank) : nullptr;
+  auto own = [&](long slot) { return !sh || sh[slot].hi > sh[slot].lo; };
+  auto first_piece = [&](long slot) { return !sh || (sh[slot].hi > sh[slot].lo && sh[slot].lo == 0); };
+  // cuts the job down to this rank's term range; false: nothing of it is left
+  auto my_piece = [&](MsmJob& job, long slot) {
+    if (sh) {
+      long t0, t1;
+      share_term_range(sh[slot], job.n, &t0, &t1);
+      job.points = job.points + t0; job.scalars += t0; job.n = t1 - t0;
+      if (job.n <= 0) return false;
+    }
+    p->slot_ran[(size_t)slot] = 1;
+    return true;
+  };
+  p->slot_ran.assign((size_t)(7 + 5 * Q), 0);
+  p->fr_valid.assign((size_t)(3 + 2 * Q), 0);
+  bool need_j_any = false, need_su = own(6 + 4 * Q) || own(5 + 4 * Q);
+  std::vector<uint8_t> need_j((size_t)Q, 0);
+  for (long j = 0; j < Q; j++) {
+    need_j[(size_t)j] = own(5 + 2 * j) || own(6 + 2 * j) || own(5 + 2 * Q + 2 * j);
+    need_j_any = need_j_any || need_j[(size_t)j];
+    need_su = need_su || own(6 + 2 * Q + 2 * j);
+  }
+  const bool need_g0 = own(0) || own(2) || own(3), need_T = own(1) || own(4);
+  // the group whose reduction nothing is left to hide under (the t group when this rank has a piece of it)
+  long last_j = -1;
+  for (long j = 0; j < Q; j++) if (need_j[(size_t)j]) last_j = j;
+  const int last_group = need_T ? 3 : need_su ? 2 : need_j_any ? 1 : 0;
   Lane* cur = nullptr;
   // SONIC_PROVE_PACK=1 packs consecutive groups into ONE batched chain as long as their MSMs fit MSM_MAX_JOBS (Q = 2: {R, W_a, W_b}
   // with {S_1, W_1, W'_1}; {S_2, W_2, W'_2} with {C, Q_1, Q_2, Q_v}), the chain waiting for the later polynomial: fewer, wider
@@ -446,27 +489,34 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   };
   auto flush_group = [&](bool last = false) { if (!pack || last) flush_now(last); };
   auto commit = [&](int ph, const Fr* poly, long lo, long len, long maxm, long slot) {
-    if (!on(ph)) return;
+    if (!on(ph) || !own(slot)) return;
     if (cur->njobs == MSM_MAX_JOBS) flush_now();
-    cur->jobs[cur->njobs++] = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
+    MsmJob job = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
+    if (my_piece(job, slot)) cur->jobs[cur->njobs++] = job;
   };
-  auto open = [&](int ph, const Fr* poly, long lo, long len, const Fr* zp, Fr* fz, long slot) {
-    if (!on(ph)) return;
+  // fr: index of the evaluation in frout (-1: not reported); every rank with a piece of the opening computes it (the quotient
+  // needs the prefix sums anyway), the rank whose piece starts at term 0 reports it
+  auto open = [&](int ph, const Fr* poly, long lo, long len, const Fr* zp, long fr, long slot) {
+    if (!on(ph) || !own(slot)) return;
     if (cur->njobs == MSM_MAX_JOBS) flush_now();
     Scratch& sc = cur->sc[cur->njobs];
-    cur->jobs[cur->njobs++] = open_job(cur->st, srs, sc, poly, lo, len, zp, fz, &slots[slot], flags);
+    MsmJob job = open_job(cur->st, srs, sc, poly, lo, len, zp, fr >= 0 ? &frout[fr] : nullptr, &slots[slot], flags);
+    if (fr >= 0 && first_piece(slot)) p->fr_valid[(size_t)fr] = 1;
+    if (my_piece(job, slot)) cur->jobs[cur->njobs++] = job;
   };
   Fr* sy = p->sy0.as<Fr>();
   // ---- all polynomials first (small kernels; queued behind a bucket accumulation they would each wait ~0.5 ms for CUs) ----
   // zkP_1: r'(X,1)                                                                   Protocol.hs:58-63
-  build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
+  if (need_g0 || need_T) build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
   ready(p->ev_r1);
   // s(X,y)                                                                           Protocol.hs:69-70
-  poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
-  s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
-  HIP_OK(hipMemcpyAsync(p->kpow.p, pw + (2 * n + 1), sizeof(Fr) * Q, hipMemcpyDeviceToDevice, ms));   // y^{n+1..n+Q} for k(y); pw is reused below
+  if (need_T) {
+    poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
+    s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
+    HIP_OK(hipMemcpyAsync(p->kpow.p, pw + (2 * n + 1), sizeof(Fr) * Q, hipMemcpyDeviceToDevice, ms));   // y^{n+1..n+Q} for k(y); pw is reused below
+  }
   ready(p->ev_sy0);
-  if (on(PH_T) || on(PH_OPEN)) {
+  if (need_T && (on(PH_T) || on(PH_OPEN))) {
     // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y), on its own stream          Protocol.hs:69-73, Constraints.hs:56-68
     hipStream_t ts = p->ts;
     HIP_OK(hipStreamWaitEvent(ts, p->ev_sy0, 0));          // ev_sy0 follows ev_r1 on the main stream
@@ -485,34 +535,46 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   Fr* t = fa;                                                                         // exponents [t_lo, t_lo + t_len)
   // hscProve: s(X, y_j), s(u, Y)                                                     Signature.hs:41,51
   for (long j = 0; j < Q; j++) {
-    poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
-    s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, p->syj[j].as<Fr>());
-    if (p->prepared) s_diag_part_enqueue(ms, pw, n, Q, p->diag[j].as<Fr>(), p->yq[j].as<Fr>());
+    if (need_j[(size_t)j]) {
+      poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
+      // a prepared handle that has only a piece of S_j's diagonal part does not read s(X, y_j) itself
+      if (!p->prepared || own(6 + 2 * j) || own(5 + 2 * Q + 2 * j)) s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, p->syj[j].as<Fr>());
+      if (p->prepared && own(5 + 2 * j)) s_diag_part_enqueue(ms, pw, n, Q, p->diag[j].as<Fr>(), p->yq[j].as<Fr>());
+    }
     ready(p->ev_syj[j]);
   }
-  poly_scale_powers_enqueue(ms, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);             // u^e, e in [-n, 2n]
   const long u_lo = -n, u_len = 2 * n + Q + 1;
-  s_of_u_enqueue(ms, wL, wR, wO, pw, n, Q, su, p->tmp);
+  if (need_su) {
+    poly_scale_powers_enqueue(ms, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);           // u^e, e in [-n, 2n]
+    s_of_u_enqueue(ms, wL, wR, wO, pw, n, Q, su, p->tmp);
+  }
   ready(p->ev_su);
 
   // ---- the MSM groups, largest first where its input allows ----
   Lane& lane_t = p->t_lane(p->ev_sy0);
-  if (on(PH_OPEN)) eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);         // s(z,y)       :83
-  begin_group(p->ev_r1, 3);
-  commit(PH_R, r1, r_lo, r_len, n, 0);                                                 // R            :63
-  open(PH_OPEN, r1, r_lo, r_len, pZ, &frout[0], 2);                                    // (a, W_a)     :79
-  open(PH_OPEN, r1, r_lo, r_len, pYZ, &frout[1], 3);                                   // (b, W_b)     :80
-  flush_group();
+  if (on(PH_OPEN) && first_piece(4)) {                                                 // s(z,y)       :83  (reported by the rank that starts W_t)
+    eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);
+    p->fr_valid[2] = 1;
+  }
+  if (need_g0) {
+    begin_group(p->ev_r1, 3);
+    commit(PH_R, r1, r_lo, r_len, n, 0);                                               // R            :63
+    open(PH_OPEN, r1, r_lo, r_len, pZ, 0, 2);                                          // (a, W_a)     :79
+    open(PH_OPEN, r1, r_lo, r_len, pYZ, 1, 3);                                         // (b, W_b)     :80
+    flush_group(last_group == 0);
+  }
   for (long j = 0; j < Q; j++) {
+    if (!need_j[(size_t)j]) continue;
     Fr* syj = p->syj[j].as<Fr>();
     begin_group(p->ev_syj[j], 3);
     if (p->prepared) commit(PH_HSCS, p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);   // S_j (diagonal part)   Signature.hs:42
     else commit(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j                   :42
-    open(PH_HSCS, syj, s_lo, s_len, pZj(j), &frout[3 + j], 6 + 2 * j);               // (s_j, W_j)    :43
-    open(PH_HSCW, syj, s_lo, s_len, pU, nullptr, 5 + 2 * Q + 2 * j);                 // W'_j          :54
-    flush_group();
-    if (p->prepared && on(PH_HSCS)) {                                                 // sum_q y_j^{n+q} C_q, Q-term MSM
+    open(PH_HSCS, syj, s_lo, s_len, pZj(j), 3 + j, 6 + 2 * j);                       // (s_j, W_j)    :43
+    open(PH_HSCW, syj, s_lo, s_len, pU, -1, 5 + 2 * Q + 2 * j);                      // W'_j          :54
+    flush_group(last_group == 1 && j == last_j);
+    if (p->prepared && on(PH_HSCS) && first_piece(5 + 2 * j)) {                       // sum_q y_j^{n+q} C_q, Q-term MSM
       Lane* ln = cur;
+      p->slot_ran[(size_t)((7 + 4 * Q) + j)] = 1;
       auto small = [&, ln, j] {
         msm_enqueue(ln->st, ln->ws, p->cq_tab.p ? msm_plan_tables(Q, CQ_TAB_C, CQ_TAB_W, Q) : msm_plan(Q),
                     PointArray::packed(p->cq_tab.p ? p->cq_tab.as<G1Affine>() : p->cq.as<G1Affine>()), p->yq[j].as<Fr>(), Q, true, &slots[(7 + 4 * Q) + j]);
@@ -520,16 +582,20 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
       if (cur->njobs == 0) small(); else after_flush.push_back(small);
     }
   }
-  begin_group(p->ev_su, (int)std::min<long>(Q + 2, MSM_MAX_JOBS));
-  commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                    // C             :52
-  for (long j = 0; j < Q; j++) open(PH_HSCW, su, u_lo, u_len, pYj(j), &frout[3 + Q + j], 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
-  open(PH_QV, su, u_lo, u_len, pV, nullptr, 5 + 4 * Q);                              // Q_v           :63
-  flush_now();
-  if (on(PH_T) || on(PH_OPEN)) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
-  cur = &lane_t; cur->njobs = 0;
-  commit(PH_T, t, t_lo, t_len, d, 1);                                                  // T            Protocol.hs:73
-  open(PH_OPEN, t, t_lo, t_len, pZ, nullptr, 4);                                       // W_t          :81
-  flush_group(true);
+  if (need_su) {
+    begin_group(p->ev_su, (int)std::min<long>(Q + 2, MSM_MAX_JOBS));
+    commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                  // C             :52
+    for (long j = 0; j < Q; j++) open(PH_HSCW, su, u_lo, u_len, pYj(j), 3 + Q + j, 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
+    open(PH_QV, su, u_lo, u_len, pV, -1, 5 + 4 * Q);                                 // Q_v           :63
+  }
+  flush_now(last_group == 2 && sh != nullptr);
+  if (need_T) {
+    if (on(PH_T) || on(PH_OPEN)) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
+    cur = &lane_t; cur->njobs = 0;
+    commit(PH_T, t, t_lo, t_len, d, 1);                                                // T            Protocol.hs:73
+    open(PH_OPEN, t, t_lo, t_len, pZ, -1, 4);                                          // W_t          :81
+    flush_group(true);
+  }
   for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   Fr* frstd = p->frstd.as<Fr>();
   HIP_OK(hipMemcpyAsync(frstd, frout, sizeof(Fr) * (3 + 2 * Q), hipMemcpyDeviceToDevice, ms));
@@ -549,6 +615,113 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   if (replay || capturing) HIP_OK(hipGraphLaunch(p->graph, st));
   p->t_enq = std::chrono::steady_clock::now();
   API_END
+}
+
+// canonical proof bytes from the 7 + 4Q points (slot order) and the 3 + 2Q evaluations: record order of `Proof` (Protocol.hs:28-38)
+// then `HscProof` (Signature.hs:22-29)
+static void proof_layout(long Q, const uint8_t* pts, const uint8_t* frs, const uint8_t* transcript, uint8_t* out_proof) {
+  auto G = [&](long i) { return pts + 96 * (size_t)i; };
+  auto F = [&](long i) { return frs + 32 * (size_t)i; };
+  uint8_t* o = out_proof;
+  auto putG = [&](long i) { memcpy(o, G(i), 96); o += 96; };
+  auto putF = [&](const uint8_t* s) { memcpy(o, s, 32); o += 32; };
+  putG(0); putG(1); putF(F(0)); putG(2); putF(F(1)); putG(3); putG(4); putF(F(2));      // R T a Wa b Wb Wt s
+  for (long j = 0; j < Q; j++) { putG(5 + 2 * j); putF(F(3 + j)); putG(6 + 2 * j); }     // hscS
+  for (long j = 0; j < Q; j++) { putF(F(3 + Q + j)); putG(5 + 2 * Q + 2 * j); putG(6 + 2 * Q + 2 * j); }   // hscW
+  putG(5 + 4 * Q); putG(6 + 4 * Q);                                                      // Qv, C
+  putF(transcript + 32 * (6 + 2 * Q)); putF(transcript + 32 * (7 + 2 * Q));              // u, v
+}
+
+// ---- one proof over several GPUs: the share a rank reports and how the shares become the proof ---------------------------------
+// share = header (32 B) | K x {lo, hi} pieces (8 B each) | K x 192-B un-normalised partial sums (infinity where the rank has no
+// piece) | (3 + 2Q) x 32-B evaluations a, b, s, s_j, s'_j (standard form; zeros unless reported) | (3 + 2Q) x int32 reported
+namespace {
+struct ShareHeader { uint32_t magic, version; int32_t rank, world; int64_t Q; int32_t flags, pad; };
+constexpr uint32_t SHARE_MAGIC = 0x48534e53u;      // "SNSH"
+}
+extern "C" size_t sonic_proof_share_size(int64_t Q) {
+  const size_t K = (size_t)(7 + 4 * Q), F = (size_t)(3 + 2 * Q);
+  return sizeof(ShareHeader) + K * 8 + K * 192 + F * 32 + F * 4;
+}
+
+static int prove_finish_share(sonic_prover_t* p, uint8_t* out_share) {
+  API_BEGIN
+  const long Q = p->Q;
+  const int K = (int)(7 + 4 * Q), F = (int)(3 + 2 * Q);
+  HIP_OK(hipStreamSynchronize(p->st));
+  p->proofs_done++;
+  const MsmSlot* hs = p->h_slots;
+  memset(out_share, 0, sonic_proof_share_size(Q));
+  ShareHeader h{SHARE_MAGIC, 1, p->share_rank, p->share_world > 1 ? p->share_world : 1, Q, *p->h_flags, 0};
+  memcpy(out_share, &h, sizeof h);
+  uint8_t* o = out_share + sizeof h;
+  for (int i = 0; i < K; i++) {
+    SlotShare s; s.lo = 0; s.hi = SHARE_ONE;
+    if (p->share_world > 1) s = p->share.row(p->share_rank)[i];
+    memcpy(o, &s.lo, 4); memcpy(o + 4, &s.hi, 4); o += 8;
+  }
+  for (int i = 0; i < K; i++, o += 192) {
+    G1XYZZ sum = G1XYZZ::inf();
+    if (p->slot_ran[(size_t)i]) sum = msm_finish_host(hs[i]);
+    const int j = (i - 5) / 2;
+    if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0 && p->slot_ran[(size_t)(K + j)]) sum = g1_add(sum, msm_finish_host(hs[K + j]));
+    memcpy(o, &sum, 192);
+  }
+  for (int i = 0; i < F; i++, o += 32) if (p->fr_valid[(size_t)i]) memcpy(o, p->h_fr + 32 * i, 32);
+  for (int i = 0; i < F; i++, o += 4) { const int32_t v = p->fr_valid[(size_t)i]; memcpy(o, &v, 4); }
+  API_END
+}
+
+// the shares of all ranks -> proof bytes.  Checks that the pieces of every MSM partition its term range and that every evaluation
+// was reported; a rank's error flags (non-canonical input, SRS index, unsatisfied circuit) become the status, as in sonic_prove.
+extern "C" int sonic_proof_from_shares(int64_t Q, int world, const uint8_t* shares, const uint8_t* transcript, uint8_t* out_proof) {
+  try {
+  if (Q < 1 || world < 1 || !shares || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
+  const int K = (int)(7 + 4 * Q), F = (int)(3 + 2 * Q);
+  const size_t sz = sonic_proof_share_size(Q);
+  std::vector<const uint8_t*> by_rank((size_t)world, nullptr);
+  int flags = 0;
+  for (int r = 0; r < world; r++) {
+    ShareHeader h;
+    memcpy(&h, shares + sz * r, sizeof h);
+    if (h.magic != SHARE_MAGIC || h.version != 1 || h.Q != Q || h.world != world || h.rank < 0 || h.rank >= world || by_rank[(size_t)h.rank]) {
+      set_error("sonic_proof_from_shares: share %d is not one of %d distinct shares of a Q = %ld proof", r, world, (long)Q); return SONIC_ERR_INVALID_ARG; }
+    by_rank[(size_t)h.rank] = shares + sz * r;
+    flags |= h.flags;
+  }
+  if (flags) return flags_to_status(flags, "prove");
+  std::vector<G1XYZZ> sums((size_t)K, G1XYZZ::inf());
+  for (int i = 0; i < K; i++) {
+    std::vector<std::pair<uint32_t, uint32_t>> pieces;
+    for (int r = 0; r < world; r++) {
+      const uint8_t* b = by_rank[(size_t)r] + sizeof(ShareHeader);
+      uint32_t lo, hi;
+      memcpy(&lo, b + 8 * i, 4); memcpy(&hi, b + 8 * i + 4, 4);
+      if (hi <= lo) continue;
+      pieces.push_back({lo, hi});
+      G1XYZZ part;
+      memcpy(&part, b + 8 * K + 192 * (size_t)i, 192);
+      sums[(size_t)i] = g1_add(sums[(size_t)i], part);
+    }
+    std::sort(pieces.begin(), pieces.end());
+    uint32_t at = 0;
+    for (auto& pc : pieces) { if (pc.first != at) break; at = pc.second; }
+    if (at != SHARE_ONE) { set_error("sonic_proof_from_shares: the pieces of MSM %d do not cover its terms exactly once", i); return SONIC_ERR_INVALID_ARG; }
+  }
+  std::vector<uint8_t> pts(96 * (size_t)K), frs(32 * (size_t)F);
+  g1_canonical_bytes_host_batch(sums.data(), K, pts.data());
+  for (int i = 0; i < F; i++) {
+    bool got = false;
+    for (int r = 0; r < world && !got; r++) {
+      const uint8_t* b = by_rank[(size_t)r] + sizeof(ShareHeader) + 8 * (size_t)K + 192 * (size_t)K;
+      int32_t v; memcpy(&v, b + 32 * (size_t)F + 4 * (size_t)i, 4);
+      if (v) { memcpy(&frs[32 * (size_t)i], b + 32 * (size_t)i, 32); got = true; }
+    }
+    if (!got) { set_error("sonic_proof_from_shares: no share reports evaluation %d", i); return SONIC_ERR_INVALID_ARG; }
+  }
+  proof_layout(Q, pts.data(), frs.data(), transcript, out_proof);
+  } catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
+  return SONIC_OK;
 }
 
 static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
@@ -594,20 +767,16 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
     g1_canonical_bytes_host_batch(sums.data(), K, pts.data());
     if (timing) fprintf(stderr, "[sonic] host tails of %d MSMs: %.3f ms\n", K, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
-  auto G = [&](long i) { return &pts[96 * (size_t)i]; };
-  auto F = [&](long i) { return &hfr_p[32 * (size_t)i]; };
-  uint8_t* o = out_proof;
-  auto putG = [&](long i) { memcpy(o, G(i), 96); o += 96; };
-  auto putF = [&](const uint8_t* s) { memcpy(o, s, 32); o += 32; };
-  putG(0); putG(1); putF(F(0)); putG(2); putF(F(1)); putG(3); putG(4); putF(F(2));      // R T a Wa b Wb Wt s
-  for (long j = 0; j < Q; j++) { putG(5 + 2 * j); putF(F(3 + j)); putG(6 + 2 * j); }     // hscS
-  for (long j = 0; j < Q; j++) { putF(F(3 + Q + j)); putG(5 + 2 * Q + 2 * j); putG(6 + 2 * Q + 2 * j); }   // hscW
-  putG(5 + 4 * Q); putG(6 + 4 * Q);                                                      // Qv, C
-  putF(transcript + 32 * (6 + 2 * Q)); putF(transcript + 32 * (7 + 2 * Q));              // u, v
+  proof_layout(Q, pts.data(), hfr_p, transcript, out_proof);
   API_END
 }
 
 extern "C" {
+
+static int whole_proof_only(sonic_prover_t* p, const char* who) {
+  if (p->share_world > 1) { set_error("%s: the handle runs one rank's share of a proof (sonic_prover_set_share): use collect_share / prove_share", who); return SONIC_ERR_INVALID_ARG; }
+  return SONIC_OK;
+}
 
 static int prove_args_ok(sonic_prover_t* p, const char* who) {
   if (!p->have_assignment) { set_error("%s: no assignment set", who); return SONIC_ERR_INVALID_ARG; }
@@ -619,6 +788,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   if (!p || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   int rc = prove_args_ok(p, "sonic_prover_prove");
+  if (!rc) rc = whole_proof_only(p, "sonic_prover_prove");
   if (!rc) rc = prove_enqueue(p, transcript);
   if (!rc) rc = prove_finish(p, out_proof);
   else if (p->st) (void)hipStreamSynchronize(p->st);      // an enqueue that failed half way: let what was queued drain
@@ -639,8 +809,59 @@ int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof) {
   if (!p || !out_proof) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   if (!p->in_flight) { set_error("sonic_prover_collect: nothing was submitted"); return SONIC_ERR_INVALID_ARG; }
+  if (whole_proof_only(p, "sonic_prover_collect")) return SONIC_ERR_INVALID_ARG;
   p->in_flight = false;
   return prove_finish(p, out_proof);
+}
+
+// ONE proof over `world` GPUs (SURVEY 8e "MSM-level parallelism"; BASELINE configs[3] as one n = 2^20 instance on 8 GPUs): every rank
+// makes a handle for the same circuit and assignment, calls set_share(rank, world), and then submit + collect_share (or
+// prove_share) with the same transcript; the shares are all-gathered (a few KB) and sonic_proof_from_shares turns them into the
+// proof on every rank.  world <= 1 restores the whole proof.
+int sonic_prover_set_share(sonic_prover_t* p, int rank, int world) {
+  API_BEGIN
+  if (!p || (world > 1 && (rank < 0 || rank >= world))) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  if (p->in_flight) { set_error("sonic_prover_set_share: a submitted proof has not been collected yet"); return SONIC_ERR_INVALID_ARG; }
+  if (p->graph) { (void)hipGraphExecDestroy(p->graph); p->graph = nullptr; }
+  p->graph_tried = false;
+  p->share_rank = world > 1 ? rank : 0;
+  p->share_world = world > 1 ? world : 0;
+  p->share_planned = false;
+  // slots and evaluations of pieces this rank no longer runs must not survive from an earlier proof
+  HIP_OK(hipMemsetAsync(p->slots.p, 0, sizeof(MsmSlot) * (7 + 5 * p->Q), p->st));
+  HIP_OK(hipMemsetAsync(p->frout.p, 0, sizeof(Fr) * (3 + 2 * p->Q), p->st));
+  HIP_OK(hipStreamSynchronize(p->st));
+  API_END
+}
+
+int sonic_prover_collect_share(sonic_prover_t* p, uint8_t* out_share) {
+  if (!p || !out_share) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  if (!p->in_flight) { set_error("sonic_prover_collect_share: nothing was submitted"); return SONIC_ERR_INVALID_ARG; }
+  p->in_flight = false;
+  return prove_finish_share(p, out_share);
+}
+
+int sonic_prover_prove_share(sonic_prover_t* p, const uint8_t* transcript, uint8_t* out_share) {
+  if (!p || !transcript || !out_share) return SONIC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(p->mu);
+  int rc = prove_args_ok(p, "sonic_prover_prove_share");
+  if (!rc) rc = prove_enqueue(p, transcript);
+  if (!rc) rc = prove_finish_share(p, out_share);
+  else if (p->st) (void)hipStreamSynchronize(p->st);
+  return rc;
+}
+
+// what the plan gives a rank (host only): K = 7 + 4Q pieces {lo, hi} in units of 1 / 2^20 of each MSM's terms (slot order R, T,
+// W_a, W_b, W_t, [S_j, W_j]_j, [W'_j, Q_j]_j, Q_v, C) and the modelled cost in MSM terms.  nb, w: buckets per set and windows of
+// the MSM plan (sonic_msm_plan; 0, 0: the defaults of an SRS with window tables, 2^19 and 13).
+int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int rank, int64_t nb, int w, uint32_t* out_lo_hi, double* out_cost) {
+  if (n < 1 || Q < 1 || world < 1 || rank < 0 || rank >= world || !out_lo_hi) return SONIC_ERR_INVALID_ARG;
+  const SharePlan pl = share_plan(n, Q, prepared != 0, world, nb > 0 ? nb : (1L << 19), w > 0 ? w : 13, ShareCosts::from_env());
+  for (int i = 0; i < pl.K; i++) { out_lo_hi[2 * i] = pl.row(rank)[i].lo; out_lo_hi[2 * i + 1] = pl.row(rank)[i].hi; }
+  if (out_cost) *out_cost = pl.cost[(size_t)rank];
+  return SONIC_OK;
 }
 
 // ---- opt-in Fiat-Shamir transcript (fs.hpp) ----------------------------------------------------------------------
@@ -670,6 +891,7 @@ int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], c
   if (!p || !circuit_digest || !blinder_seed || !out_proof) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   int rc = prove_args_ok(p, "sonic_prover_prove_fs");
+  if (!rc) rc = whole_proof_only(p, "sonic_prover_prove_fs");
   if (rc) return rc;
   const long n = p->n, Q = p->Q, d = srs_d(p->srs);
   std::vector<uint8_t> tr(32 * (size_t)(8 + 2 * Q), 0), pf(sonic_proof_size(Q));

@@ -13,8 +13,13 @@ SRS replicated, and two ways of splitting ONE MSM over the ranks:
 RCCL has no elliptic-curve reduction op, so both end in a gather + local curve additions, never an all-reduce.  The collectives
 run on device tensors ordered on one HIP stream with the lane's kernels (sonic_msm_lane_new_on_stream): nothing visits the host
 between the scalars in HBM and the gathered partials, which come back in ONE device-to-host copy.  With the gloo backend (tests:
-several ranks on one GPU, or no GPU at all) the same exchanges are staged through host tensors.  prove() itself shards by proof
-and needs no collective.
+several ranks on one GPU, or no GPU at all) the same exchanges are staged through host tensors.
+
+prove() shards two ways: by proof (every rank its own proofs, no collective: bench.py's `value`), and -- `ShardedProver` -- ONE
+proof over all ranks: the 7 + 4Q commitments and openings of prove + hscProve (src/Sonic/Protocol.hs:63,73,79-81,
+src/Sonic/Signature.hs:40-45,51-57,63) are independent sums once the transcript is known, so every rank builds the polynomials
+its pieces read, runs a contiguous, cost-balanced piece of those MSMs (sonic_prover_set_share) and the ranks all-gather their
+shares (a few KB: 192-byte partial sums, evaluations, error flags).
 """
 from __future__ import annotations
 
@@ -205,3 +210,77 @@ class ShardedMsm:
             self.close()
         except Exception:
             pass
+
+
+def allgather_shares(share: bytes, world: int, device=None):
+    """all-gather of one proof share per rank over the default process group: device tensors over RCCL (backend nccl), host
+    tensors over gloo; returns the `world` shares in rank order"""
+    import torch
+    import torch.distributed as dist
+    staged = dist.get_backend() != "nccl"
+    mine = torch.frombuffer(bytearray(share), dtype=torch.uint8)
+    if not staged:
+        mine = mine.to(device)
+    gathered = torch.empty(world * len(share), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine)
+    host = gathered.cpu().numpy().tobytes()
+    return [host[i * len(share):(i + 1) * len(share)] for i in range(world)]
+
+
+class ShardedProver:
+    """ONE proof over the ranks of the default process group (BASELINE configs[3] read as "a single n = 2^20 instance on 8 GPUs").
+
+    Every rank constructs it with the same circuit over its replica of the SRS and calls set_assignment / prove_bytes with the same
+    assignment and transcript; prove_bytes returns the same proof bytes on every rank, byte-identical to Prover.prove_bytes on one
+    GPU.  The only collective is one all-gather of sonic_proof_share_size(Q) bytes per rank (device tensors over RCCL, host tensors
+    over gloo).  Without a process group (world == 1) it is a plain Prover.
+
+    emulate=(rank, world): no collective -- this process runs the share of `rank` of `world` (timing one rank's work on one GPU,
+    and the tests that run every rank's share in turn and combine them)."""
+
+    def __init__(self, srs, circuit, rank: int = 0, world: int = 1, device=None, prepare: bool = True, emulate=None):
+        from .protocol import Prover
+        self.rank, self.world, self.device = rank, world, device
+        self.emulate = emulate
+        self.pg = _pg_active()
+        if world > 1 and not self.pg and emulate is None:
+            raise RuntimeError("ShardedProver: world > 1 needs an initialised process group")
+        self.prover = Prover(srs, circuit, prepare=prepare)
+        self.Q = self.prover.Q
+        if emulate is not None:
+            self.prover.set_share(*emulate)
+        elif world > 1:
+            self.prover.set_share(rank, world)
+        self.share_bytes = _lib.lib().sonic_proof_share_size(self.Q)
+
+    def set_assignment(self, assignment):
+        self.prover.set_assignment(assignment)
+
+    def set_emulated_rank(self, rank: int, world: int):
+        self.emulate = (rank, world)
+        self.prover.set_share(rank, world)
+
+    def prove_share(self, transcript) -> bytes:
+        """this rank's share only (no collective)"""
+        return self.prover.prove_share(transcript)
+
+    def prove_bytes(self, transcript) -> bytes:
+        from .protocol import proof_from_shares
+        if self.emulate is not None:
+            raise RuntimeError("ShardedProver: an emulated rank has only a share (prove_share)")
+        if self.world <= 1:
+            return self.prover.prove_bytes(transcript)
+        # a rank whose share fails must still enter the all-gather (the others would hang in it): it reports through the flags
+        # of its share when the library got that far, else re-raises after the collective
+        err = None
+        try:
+            share = self.prover.prove_share(transcript)
+        except Exception as e:      # noqa: BLE001
+            err, share = e, bytes(self.share_bytes)
+        shares = allgather_shares(share, self.world, self.device)
+        if err is not None:
+            raise err
+        return proof_from_shares(self.Q, shares, transcript)
+
+    def close(self):
+        self.prover.close()

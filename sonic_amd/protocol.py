@@ -179,6 +179,23 @@ class Prover:
         _lib.check(_lib.lib().sonic_prover_collect(self._h, out))
         return out.raw
 
+    # ---- ONE proof over several GPUs (sonic_prover_set_share): this handle runs rank's pieces of the proof's MSMs ----
+    def set_share(self, rank: int, world: int) -> None:
+        _lib.check(_lib.lib().sonic_prover_set_share(self._h, rank, world))
+
+    def prove_share(self, transcript) -> bytes:
+        tr = fr_array(transcript)
+        assert tr.shape[0] == transcript_len(self.Q)
+        out = C.create_string_buffer(_lib.lib().sonic_proof_share_size(self.Q))
+        _lib.check(_lib.lib().sonic_prover_prove_share(self._h, tr.ctypes.data, out))
+        return out.raw
+
+    def collect_share(self) -> bytes:
+        """wait for the submitted share (submit() queues it like a whole proof) and return its bytes"""
+        out = C.create_string_buffer(_lib.lib().sonic_proof_share_size(self.Q))
+        _lib.check(_lib.lib().sonic_prover_collect_share(self._h, out))
+        return out.raw
+
     def prove_fs(self, circuit_digest: bytes, blinder_seed: bytes):
         """prove with the opt-in Fiat-Shamir transcript (sonic_prover_prove_fs): returns (proof bytes, the 8 + 2Q transcript values
         the proof was made with); six waits for the GPU instead of one"""
@@ -205,6 +222,29 @@ class Prover:
             self.close()
         except Exception:
             pass
+
+
+def proof_from_shares(Q: int, shares, transcript) -> bytes:
+    """the shares of all ranks (any order) -> canonical proof bytes (sonic_proof_from_shares; host only)"""
+    shares = list(shares)
+    blob = b"".join(bytes(s) for s in shares)
+    tr = fr_array(transcript)
+    out = C.create_string_buffer(_lib.lib().sonic_proof_size(Q))
+    _lib.check(_lib.lib().sonic_proof_from_shares(Q, len(shares), blob, tr.ctypes.data, out))
+    return out.raw
+
+
+def share_plan(n: int, Q: int, prepared: bool, world: int, nb: int = 0, w: int = 0):
+    """the plan of one proof over `world` ranks: per rank (pieces, cost) with pieces = 7 + 4Q pairs (lo, hi) in units of 1 / 2^20 of
+    each MSM's terms (slot order R, T, W_a, W_b, W_t, [S_j, W_j]_j, [W'_j, Q_j]_j, Q_v, C)"""
+    K = 7 + 4 * Q
+    out = []
+    for r in range(world):
+        buf = (C.c_uint32 * (2 * K))()
+        cost = C.c_double()
+        _lib.check(_lib.lib().sonic_prove_share_plan(n, Q, int(prepared), world, r, nb, w, buf, C.byref(cost)))
+        out.append(([(buf[2 * i], buf[2 * i + 1]) for i in range(K)], cost.value))
+    return out
 
 
 class ProverPipeline:
