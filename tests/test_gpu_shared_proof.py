@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _setup(sonic, orc, ref, n, Q, seed, d=None):
     pyr = random.Random(seed)
-    d = d or 8 * n
+    d = d or max(8 * n, 12)          # n = 1 needs d >= 4n + 8 (t(X,y) reaches X^{-4n-8})
     x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
     srs = sonic.SRS.new(d, x, alpha)
     osrs = orc.SRS(d, x, alpha, threads=os.cpu_count() or 1)
@@ -57,8 +57,11 @@ def test_all_shares_of_a_proof_combine_to_the_oracle_proof(sonic, orc, ref, n, Q
     p.close()
 
 
-def test_shares_with_cut_msms_at_2p14(sonic, orc, ref):
-    """n = 2^14 on an SRS with window tables (d = 2^17): the plan cuts inside MSMs, the pieces run over the tables"""
+def test_shares_with_cut_msms_at_2p14(sonic, orc, ref, monkeypatch):
+    """n = 2^14 on an SRS with window tables (d = 2^17): the plan cuts inside MSMs, the pieces run over the tables.  With the fixed
+    parts of the cost model set to zero the line is cut into equal term counts, so every world size cuts some MSM."""
+    for k in ("JOB", "R1", "SY", "SU", "T"):
+        monkeypatch.setenv("SONIC_SHARE_COST_" + k, "0.0001")
     n, Q = 1 << 14, 2
     circ = big_circuit(7, n, Q)
     x, alpha = 0x1234567891, 0x9876543211
