@@ -45,7 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-ROUND = "r03"
+ROUND = "r04"
 
 
 def log(*a):
@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pipelined-throughput leg (timelines of one solo proof)")
     ap.add_argument("--msm-lanes", type=int, default=3, help="lanes the standalone MSMs are streamed over (0: skip the streamed leg, e.g. for rocprofv3 / PMC passes over the solo kernels)")
     ap.add_argument("--msm-only", action="store_true", help="skip prove() (PMC counter passes over the MSM kernels)")
+    ap.add_argument("--strong-log2n", type=int, default=20, help="n = 2^this of the ONE proof that all ranks share (north_star: n = 2^20, d = 2^23; BASELINE configs[3] "
+                                                                 "as a single instance); 0: skip the leg")
+    ap.add_argument("--strong-emulate", type=int, default=8, help="(1 GPU) also time every rank's share of that proof as if there were this many ranks (0: off)")
+    ap.add_argument("--north-star-cpu", action="store_true", help="also time the CPU port on the SAME n = 2^strong-log2n proof (minutes; one-off runs for profiles/)")
     ap.add_argument("--prove-only", action="store_true", help="nothing but the proofs (PMC pass for the per-kernel instruction budget of a proof)")
     args = ap.parse_args()
 
@@ -401,6 +405,87 @@ def main():
         sh.close()
     L.sonic_dev_free(dsc)
 
+    # ---------------- timed: ONE proof at the north_star size shared by all ranks (strong scaling of prove()) ----------------
+    # Every rank holds the same circuit, assignment and transcript over its replica of the SRS, runs its cost-balanced piece of the
+    # proof's 7 + 4Q MSMs (sonic_prover_set_share) and the ranks all-gather their shares (a few KB).  One rank: the plain sequential
+    # prove() -- the north_star's "prove() wall-clock at n = 2^20 on 1 MI355X".
+    prove_strong = north_star = None
+    if do_prove and not args.prove_only and args.strong_log2n > 0:
+        ns_lg = args.strong_log2n
+        ns_n, ns_d = 1 << ns_lg, 8 << ns_lg
+        t0 = time.time()
+        srs_ns = srs if ns_d == d else sonic_amd.SRS.new(ns_d, x, alpha)
+        t_srs_ns = time.time() - t0
+        c_ns = circ if (ns_n == n and world == 1) else big_circuit(2000, ns_n, Q)           # the same statement on every rank
+        circuit_ns = sonic_amd.ArithCircuit(sonic_amd.GateWeights(c_ns["wL"], c_ns["wR"], c_ns["wO"]), c_ns["cs"])
+        asg_ns = sonic_amd.Assignment(c_ns["aL"], c_ns["aR"], c_ns["aO"])
+        sp = sd.ShardedProver(srs_ns, circuit_ns, rank, world, device)
+        sp.set_assignment(asg_ns)
+        ns_rng = np.random.default_rng(4242)
+        ns_tr = [rand_fr_array(ns_rng, 8 + 2 * Q) for _ in range(K + max(1, W))]
+        for t in ns_tr:
+            t[:, 0] |= 1
+        for i in range(max(1, W)):
+            sp.prove_bytes(ns_tr[i])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            ns_proof = sp.prove_bytes(ns_tr[max(1, W) + i])
+        barrier()
+        dt_ns = max_over_ranks([time.perf_counter() - t0])[0]
+        same_ns = None
+        if rank == 0 and world > 1:       # the same proof made by this GPU alone (untimed): the bytes must not depend on the sharing
+            alone = sonic_amd.Prover(srs_ns, circuit_ns, prepare=False)
+            alone.set_assignment(asg_ns)
+            same_ns = alone.prove_bytes(ns_tr[max(1, W) + K - 1]) == ns_proof
+            alone.close()
+        prove_strong = {"metric": "ONE prove() shared by all ranks", "n": ns_n, "Q": Q, "d": ns_d, "scaling": "strong", "n_gpus": world,
+                        "ms_per_proof": round(1e3 * dt_ns / K, 3), "value": round(K / dt_ns, 4), "unit": "proofs/s",
+                        "method": ("every rank builds the polynomials its pieces read and runs a contiguous, cost-balanced piece of the proof's 7+4Q MSMs "
+                                   "(cuts inside an MSM split its term range); one all-gather of %d-byte shares; sonic_proof_from_shares on every rank"
+                                   % L.sonic_proof_share_size(Q)) if world > 1 else "single rank: the plain sequential prove() (baseline of the curve)",
+                        "same_bytes_as_one_gpu_alone": same_ns, "proof_bytes": len(ns_proof), "srs_new_s": round(t_srs_ns, 2)}
+        if world == 1 and args.strong_emulate > 1:
+            E = args.strong_emulate
+            tr_e = ns_tr[max(1, W) + K - 1]
+            ms_e, shares_e = [], []
+            for r in range(E):
+                sp.set_emulated_rank(r, E)
+                sp.prove_share(tr_e)
+                L.sonic_device_sync()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    sh_e = sp.prove_share(tr_e)
+                ms_e.append(1e3 * (time.perf_counter() - t0) / 3)
+                shares_e.append(sh_e)
+            t0 = time.perf_counter()
+            comb = sonic_amd.proof_from_shares(Q, shares_e, tr_e)
+            t_comb = 1e3 * (time.perf_counter() - t0)
+            prove_strong["emulated_shares"] = {"world": E, "ms_per_share": [round(v, 2) for v in ms_e], "slowest_ms": round(max(ms_e), 2),
+                                               "combine_ms_host": round(t_comb, 3), "combined_equals_whole_proof": comb == ns_proof,
+                                               "speedup_vs_one_gpu": round((1e3 * dt_ns / K) / (max(ms_e) + t_comb), 2),
+                                               "note": "UNMEASURED ON MULTI-GPU HARDWARE: this one GPU ran every rank's share in turn; "
+                                                       "the all-gather of %d bytes per rank over xGMI is not included" % L.sonic_proof_share_size(Q)}
+        if rank == 0 and world == 1:
+            north_star = {"target": "prove() wall-clock at n=2^20 (d = 8n = 2^23; BASELINE states d=2^22, which Protocol.hs:54-55 rejects) on 1 MI355X, "
+                                    ">= 10x the CPU prove(), bit-exact", "n": ns_n, "d": ns_d, "Q": Q,
+                          "ms_per_proof": round(1e3 * dt_ns / K, 3), "how": f"{K} sequential prove() calls, each finished before the next begins"}
+            if args.north_star_cpu and not args.no_cpu:
+                from oracle import orc
+                cores_ns = effective_cores()
+                orc.set_mode(1, cores_ns)
+                o_ns = orc.SRS.from_points(ns_d, srs_ns.points(0, -ns_d, 2 * ns_d + 1), srs_ns.points(1, -ns_d, 2 * ns_d + 1))
+                t0 = time.perf_counter()
+                cp_ns = orc.prove(o_ns, ns_n, Q, c_ns["wL"], c_ns["wR"], c_ns["wO"], c_ns["cs"], c_ns["aL"], c_ns["aR"], c_ns["aO"], ns_tr[max(1, W) + K - 1], True)
+                cdt_ns = time.perf_counter() - t0
+                north_star["cpu"] = {"kind": "port", "what": "oracle/sonic_oracle.c, the repo's plain-C port (Pippenger + NTT)", "cores": cores_ns, "n": ns_n,
+                                     "s_per_proof": round(cdt_ns, 2), "same_bytes_as_gpu_proof": cp_ns == ns_proof,
+                                     "gpu_over_cpu": round(cdt_ns / (dt_ns / K), 1)}
+                del o_ns
+        sp.close()
+        if srs_ns is not srs:
+            del srs_ns
+
     if rank != 0:
         if pg:
             dist.destroy_process_group()
@@ -549,6 +634,8 @@ def main():
         "roofline_ntt": ntt,
         "roofline_prove": roofline_prove,
         "cpu_baseline": cpu_baseline,
+        "prove_strong": prove_strong,
+        "north_star": north_star,
         "proof_bytes": len(proof),
         "sequential": sequential,
     }

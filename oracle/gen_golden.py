@@ -92,6 +92,7 @@ def gen_fs():
         proof, _o, tr = ref.prove_fs(srs, asg, circ, seed)
         assert ref.verify_exponent(srs, circ, asg, tr, proof)
         cases.append({"name": c["name"], "seed": seed.hex(), "circuit_digest": ref.fs_circuit_digest(circ).hex(),
+                      "srs_id": ref.fs_srs_id(srs).hex(), "witness_digest": ref.fs_witness_digest(asg).hex(),
                       "transcript": [hx(v) for v in tr], "proof": ref.proof_to_bytes(proof).hex()})
     json.dump({"generator": "oracle/gen_golden.py (gen_fs): inputs are the cases of the same name in prove_small.json", "cases": cases},
               open(os.path.join(OUT, "fs_small.json"), "w"), indent=1)

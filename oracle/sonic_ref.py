@@ -559,17 +559,36 @@ def fs_circuit_digest(circuit) -> bytes:
     return h.digest()
 
 
-def fs_blinders(seed: bytes):
+def fs_srs_id(srs: SRS) -> bytes:
+    """what ties a transcript to ONE structured reference string of a given d: g^x, g^{alpha x}, g^{1/x}, g^{alpha/x}
+    (gPositiveX[1], gPositiveAlphaX[0], gNegativeX[0], gNegativeAlphaX[0]; SRS.hs:33-39) determine x and alpha"""
+    pts = [srs.gPositiveX(1), srs.gPositiveAlphaX(0), srs.gNegativeX(0), srs.gNegativeAlphaX(0)]
+    return _hashlib.sha256(b"sonic-hip/srs/v1" + _le64(srs.d) + b"".join(g1_to_bytes(p) for p in pts)).digest()
+
+
+def fs_witness_digest(assignment) -> bytes:
+    aL, aR, aO = assignment
+    h = _hashlib.sha256(b"sonic-hip/witness/v1")
+    for vec in (aL, aR, aO):
+        for v in vec:
+            h.update(fr_to_bytes(v))
+    return h.digest()
+
+
+def fs_blinders(seed: bytes, digest: bytes, srs_id: bytes, witness_digest: bytes):
+    """the four blinders (Protocol.hs:58) from the prover's secret seed AND the statement, the SRS and the witness (in the manner of
+    RFC 6979): the same seed on another assignment gives unrelated blinders, so R1 - R2 never is an unblinded commitment"""
     out = []
     for i in range(4):
-        d = [_hashlib.sha256(b"sonic-hip/blinder/v1" + seed + i.to_bytes(4, "little") + bytes([half])).digest() for half in (0, 1)]
+        d = [_hashlib.sha256(b"sonic-hip/blinder/v2" + seed + digest + srs_id + witness_digest + i.to_bytes(4, "little") + bytes([half])).digest()
+             for half in (0, 1)]
         out.append(fs_wide(d[0], d[1]))
     return out
 
 
 class FsTranscript:
-    def __init__(self, n: int, m: int, d: int, digest: bytes):
-        self.st = _hashlib.sha256(b"sonic-hip/fs/v1" + _le64(n) + _le64(m) + _le64(d) + digest).digest()
+    def __init__(self, n: int, m: int, d: int, digest: bytes, srs_id: bytes):
+        self.st = _hashlib.sha256(b"sonic-hip/fs/v2" + _le64(n) + _le64(m) + _le64(d) + digest + srs_id).digest()
 
     def absorb(self, label: bytes, data: bytes):
         self.st = _hashlib.sha256(self.st + label + data).digest()
@@ -579,9 +598,9 @@ class FsTranscript:
         return fs_wide(d[0], d[1]) or 1
 
 
-def fs_challenges_of_proof(n: int, m: int, d: int, digest: bytes, pb: bytes):
+def fs_challenges_of_proof(n: int, m: int, d: int, digest: bytes, srs_id: bytes, pb: bytes):
     """y, z, [y_j], [z_j], u, v as a proof's canonical bytes determine them"""
-    t = FsTranscript(n, m, d, digest)
+    t = FsTranscript(n, m, d, digest, srs_id)
     t.absorb(b"R", pb[0:96])
     y = t.challenge(b"y", 0)
     t.absorb(b"T", pb[96:192])
@@ -604,14 +623,14 @@ def prove_fs(srs: SRS, assignment, circuit, seed: bytes):
     one from the bytes reaches the fixed point after one round per draw site; the literal `prove` above does the proving."""
     aL = assignment[0]
     n, m = len(aL), len(circuit[0])
-    digest = fs_circuit_digest(circuit)
-    tr = fs_blinders(seed) + [1] * (4 + 2 * m)
+    digest, sid = fs_circuit_digest(circuit), fs_srs_id(srs)
+    tr = fs_blinders(seed, digest, sid, fs_witness_digest(assignment)) + [1] * (4 + 2 * m)
     for _ in range(6):
         proof, _o = prove(srs, assignment, circuit, tr)
-        y, z, ys, zs, u, v = fs_challenges_of_proof(n, m, srs.d, digest, proof_to_bytes(proof))
+        y, z, ys, zs, u, v = fs_challenges_of_proof(n, m, srs.d, digest, sid, proof_to_bytes(proof))
         tr = tr[:4] + [y, z] + ys + zs + [u, v]
     proof, oracle = prove(srs, assignment, circuit, tr)
-    assert fs_challenges_of_proof(n, m, srs.d, digest, proof_to_bytes(proof)) == (y, z, ys, zs, u, v)
+    assert fs_challenges_of_proof(n, m, srs.d, digest, sid, proof_to_bytes(proof)) == (y, z, ys, zs, u, v)
     return proof, oracle, tr
 
 def arith_circuit_example1():

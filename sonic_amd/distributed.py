@@ -233,7 +233,7 @@ class ShardedProver:
     Every rank constructs it with the same circuit over its replica of the SRS and calls set_assignment / prove_bytes with the same
     assignment and transcript; prove_bytes returns the same proof bytes on every rank, byte-identical to Prover.prove_bytes on one
     GPU.  The only collective is one all-gather of sonic_proof_share_size(Q) bytes per rank (device tensors over RCCL, host tensors
-    over gloo).  Without a process group (world == 1) it is a plain Prover.
+    over gloo).  Without a process group it is a plain Prover.
 
     emulate=(rank, world): no collective -- this process runs the share of `rank` of `world` (timing one rank's work on one GPU,
     and the tests that run every rank's share in turn and combine them)."""
@@ -268,8 +268,9 @@ class ShardedProver:
         from .protocol import proof_from_shares
         if self.emulate is not None:
             raise RuntimeError("ShardedProver: an emulated rank has only a share (prove_share)")
-        if self.world <= 1:
+        if not self.pg:
             return self.prover.prove_bytes(transcript)
+        # (a group of ONE rank still goes through the share and the all-gather: the collective runs wherever a group exists)
         # a rank whose share fails must still enter the all-gather (the others would hang in it): it reports through the flags
         # of its share when the library got that far, else re-raises after the collective
         err = None

@@ -368,6 +368,29 @@ def hsc_prove(srs: SRS, circuit: ArithCircuit, yzs, u: Optional[int] = None, v: 
         p.close()
 
 
+def from_x(p) -> dict:
+    """fromX :: VLaurent f -> BiVLaurent f (Utils.hs:23-24): the univariate polynomial {exponent: coeff} in X as a bivariate one,
+    constant in Y -- in the nested form hsc_prove_poly takes.  The prover itself never lifts: evaluating Y := y is a ring
+    homomorphism, so tPoly's product (Constraints.hs:56-65) is formed in the univariate ring."""
+    return {int(ex): {0: int(c)} for ex, c in (p.items() if isinstance(p, dict) else p) if int(c) % R_MODULUS}
+
+
+def from_y(p) -> dict:
+    """fromY :: VLaurent f -> BiVLaurent f (Utils.hs:26-27): `monomial 0` -- a polynomial in Y as the X^0 coefficient"""
+    inner = {int(ey): int(c) for ey, c in (p.items() if isinstance(p, dict) else p) if int(c) % R_MODULUS}
+    return {0: inner} if inner else {}
+
+
+def biv_add(a: dict, b: dict) -> dict:
+    """sum of two BiVLaurent polynomials in the nested form (coefficients mod r, zero terms dropped)"""
+    out = {ex: dict(inner) for ex, inner in a.items()}
+    for ex, inner in b.items():
+        row = out.setdefault(ex, {})
+        for ey, c in inner.items():
+            row[ey] = (row.get(ey, 0) + c) % R_MODULUS
+    return {ex: {ey: c for ey, c in inner.items() if c} for ex, inner in out.items() if any(inner.values())}
+
+
 def _biv_terms(sXY):
     """BiVLaurent Fr as {x_exp: {y_exp: coeff}} (X outside, Y inside, like poly's nested sparse form) or [(x_exp, y_exp, coeff)]"""
     if isinstance(sXY, dict):

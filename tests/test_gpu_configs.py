@@ -300,7 +300,7 @@ def test_bench_under_the_driver_launch_line_one_rank_rccl():
     all-gathered over RCCL on device tensors and the strong-scaling leg runs"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--log2n", "12", "--msm-log2", "14", "--no-cpu"]
+           "--log2n", "12", "--msm-log2", "14", "--no-cpu", "--strong-log2n", "13"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -309,3 +309,8 @@ def test_bench_under_the_driver_launch_line_one_rank_rccl():
     assert j["n_gpus"] == 1 and j["config"]["process_group"].startswith("nccl") and j["value"] > 0
     assert j["msm"]["sequential"]["same_result_as_streamed"] and j["msm_strong"]["same_result_as_term_range_sharding"]
     assert j["roofline"]["bound"] == "hbm" and j["roofline_ntt"]["hbm_passes_per_transform"] >= 1 and j["roofline_prove"]["frac"] > 0
+    # ONE proof shared by the (one) rank: the share went through the RCCL all-gather; the emulated 8-rank shares recombine to it
+    ps = j["prove_strong"]
+    assert ps["n"] == 1 << 13 and ps["n_gpus"] == 1 and ps["ms_per_proof"] > 0
+    assert ps["emulated_shares"]["world"] == 8 and ps["emulated_shares"]["combined_equals_whole_proof"] is True
+    assert j["north_star"]["n"] == 1 << 13 and j["north_star"]["ms_per_proof"] == ps["ms_per_proof"]

@@ -147,7 +147,7 @@ def test_bench_two_ranks_one_gpu():
     """the driver's N = 2 launch line, small sizes, gloo: one JSON line from rank 0 with whole-job values"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
-           "--warmup", "1", "--log2n", "10", "--msm-log2", "12", "--no-cpu"]
+           "--warmup", "1", "--log2n", "10", "--msm-log2", "12", "--no-cpu", "--strong-log2n", "12"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -157,3 +157,7 @@ def test_bench_two_ranks_one_gpu():
     assert j["roofline"]["bound"] == "hbm" and j["cpu_baseline"] is None
     assert j["msm_strong"]["scaling"] == "strong" and j["msm_strong"]["n_gpus"] == 2 and j["msm_strong"]["same_result_as_term_range_sharding"]
     assert "all-to-all" in j["msm_strong"]["method"]
+    # ONE proof shared by the two ranks, byte-equal to the proof rank 0 makes alone
+    ps = j["prove_strong"]
+    assert ps["scaling"] == "strong" and ps["n_gpus"] == 2 and ps["n"] == 1 << 12 and ps["same_bytes_as_one_gpu_alone"] is True and ps["ms_per_proof"] > 0
+    assert j["north_star"] is None

@@ -142,8 +142,9 @@ def test_prove_bytes_vs_oracle_mid_sizes(sonic, orc, log2n):
 def test_prove_bytes_vs_oracle_at_the_bench_size(sonic, orc):
     """BASELINE.json configs[2] exactly as bench.py runs it (n = 2^18, Q = 2, d = 8n = 2^21): the complete proof, byte for byte, against
     the C oracle's prove() on the host cores (~20-40 s).  The oracle takes the SRS points from the GPU-made SRS (set-up is not part of
-    prove(); generating 8 M points on the host would take minutes), so sampled SRS elements are first checked against the oracle's own
-    fixed-base multiples g^{x^e}, g^{alpha x^e}."""
+    prove(); generating 8 M points on the host would take minutes), so the GPU-made SRS is checked first: sampled elements against the
+    oracle's own fixed-base multiples g^{x^e}, g^{alpha x^e}, then ALL of them through random linear combinations against the closed
+    form in the exponent."""
     n, Q = 1 << 18, 2
     d = 8 * n
     pyr = random.Random(1818)
@@ -163,6 +164,22 @@ def test_prove_bytes_vs_oracle_at_the_bench_size(sonic, orc):
     except Exception:
         pass
     osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1), threads=cores)
+    # ALL 2 (2d + 1) GPU-made points, not a sample: two random linear combinations per basis, summed by the ORACLE's Pippenger over
+    # the bytes it was handed, against the closed form in the exponent.  rho_e = lambda^(e + d) for a random lambda: the two sides are
+    # polynomials of degree 2d in lambda that agree at a random point only if every coefficient (every point) agrees (Schwartz-Zippel,
+    # error 2d / r ~ 2^-233):  sum_e lambda^(e+d) g^{x^e} = g^{x^-d ((lambda x)^(2d+1) - 1) / (lambda x - 1)};  basis 1 has alpha and no e = 0.
+    orc.set_mode(1, cores)
+    gen = orc.g1_gen()
+    for _ in range(2):
+        lam = pyr.randrange(2, R)
+        rho, v = [], 1
+        for _i in range(2 * d + 1):
+            rho.append(v)
+            v = v * lam % R
+        rho_b = fr_bytes(rho)
+        total = pow(x, -d, R) * geom(lam * x % R, 0, 2 * d) % R
+        assert orc.msm_srs(osrs, 0, -d, rho_b, 1, cores) == orc.g1_mul(gen, total)
+        assert orc.msm_srs(osrs, 1, -d, rho_b, 1, cores) == orc.g1_mul(gen, alpha * (total - pow(lam, d, R)) % R)
     circ = big_circuit(1818, n, Q)
     tr = fr_bytes([pyr.randrange(2, R) for _ in range(8 + 2 * Q)])
     orc.set_mode(1, cores)

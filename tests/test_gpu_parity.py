@@ -970,3 +970,59 @@ def test_c99_abi_harness(sonic, tmp_path):
     from test_abi import _build_harness
     out = subprocess.run([_build_harness(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "abi_harness: OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_from_x_from_y_lifts(sonic, ref):
+    """fromX / fromY (Utils.hs:23-27) lift a univariate polynomial into the bivariate ring; the reference uses them inside tPoly
+    (Constraints.hs:56-65).  Here: the lifts of the product's mirror equal the restatement's; hscProve on a lifted polynomial
+    fails exactly as the reference does (evalX u / evalY y_j of a lift has a constant term, and commitPoly with max = d needs the
+    omitted g^alpha for it: CommitmentScheme.hs:70-73 via SRS.hs:38); hscProve on fromX p + fromY q with the constant terms
+    arranged to cancel equals the restatement's element by element and verifies; and tPoly built the reference's way -- fromX (evalY 1 r)
+    * (r + s) + fromY (-k) in the bivariate ring, then evalY y -- commits to the T of the GPU's univariate prover."""
+    pyr = random.Random(1212)
+    d = 64
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    g, s = sonic.SRS.new(d, x, alpha), ref.SRS(d, x, alpha)
+    p = {e: pyr.randrange(1, R) for e in (-7, -3, -1, 2, 5, 9)}
+    q = {e: pyr.randrange(1, R) for e in (-6, -2, 1, 3, 4)}
+    assert sonic.from_x(p) == ref.from_x(p) and sonic.from_y(q) == ref.from_y(q)
+    assert sonic.from_x({3: 0, 4: 5}) == {4: {0: 5}} and sonic.from_y({}) == {} and sonic.from_y({2: 0}) == {}
+    yz, u, v = [(pyr.randrange(1, R), pyr.randrange(1, R))], pyr.randrange(1, R), pyr.randrange(1, R)
+    # a bare lift: the reference's `index` panics on the hole of the alpha basis; both sides refuse
+    for lifted in (sonic.from_x(p), sonic.from_y(q)):
+        with pytest.raises(sonic.SonicError) as e:
+            sonic.hsc_prove_poly(g, lifted, yz, u, v)
+        assert e.value.code == 2
+        with pytest.raises(Exception):
+            ref.hsc_prove(s, lifted, yz, u, v)
+    # fromX p + fromY q with p_0, q_0 such that s(X, y_1) and s(u, Y) have no constant term:
+    #   p_0 + q(y_1) = 0 and q_0 + p(u) = 0  <=>  p'(u) = q'(y_1) (primes: without the constant terms) and p_0 + q_0 = -p'(u)
+    ev = lambda f, t: sum(c * pow(t, e, R) for e, c in f.items()) % R        # noqa: E731
+    (y1, _z1), = yz
+    scale = ev(p, u) * pow(ev(q, y1), -1, R) % R
+    q = {e: c * scale % R for e, c in q.items()}
+    assert ev(p, u) == ev(q, y1)
+    p0 = pyr.randrange(1, R)
+    p[0] = p0
+    q[0] = (-ev({e: c for e, c in p.items() if e}, u) - p0) % R
+    sXY = sonic.biv_add(sonic.from_x(p), sonic.from_y(q))
+    assert sXY == ref.biv_add(ref.from_x(p), ref.from_y(q))
+    got = sonic.hsc_prove_poly(g, sXY, yz, u, v)
+    want = ref.hsc_prove(s, sXY, yz, u, v)
+    assert (got.hscS, got.hscW, got.hscQv, got.hscC, got.hscU, got.hscV) == \
+        (want["hscS"], want["hscW"], want["hscQv"], want["hscC"], want["hscU"], want["hscV"])
+    assert sonic.hsc_verify_poly(g, sXY, yz, got)
+    # tPoly the reference's way (lifts and a bivariate product), against the T of the GPU prover
+    n, Q = 3, 2
+    circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+    tr = [pyr.randrange(1, R) for _ in range(8 + 2 * Q)]
+    proof, _ = sonic.prove(g, sonic.Assignment(*asg), sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), circ[3]), transcript=tr)
+    rXY = ref.r_poly(*asg)
+    for i, c in enumerate(tr[:4], start=1):                                    # the blinders, Protocol.hs:58-62
+        rXY = ref.biv_add(rXY, {-2 * n - i: {-2 * n - i: c}})
+    sXY_c = ref.s_poly(circ[0], circ[1], circ[2])
+    kY = ref.k_poly(circ[3], n)
+    rX1 = ref.from_x(ref.eval_y(1, rXY))
+    tXY = ref.biv_add(ref.biv_mul(rX1, ref.biv_add(rXY, sXY_c)), ref.from_y(ref.lp_neg(kY)))
+    assert tXY == ref.t_poly(rXY, sXY_c, kY)
+    assert sonic.commit_poly(g, d, ref.eval_y(tr[4], tXY)) == proof.prT
