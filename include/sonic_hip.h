@@ -63,6 +63,10 @@ typedef struct sonic_prover sonic_prover_t;
 int sonic_init(int device_ordinal);                 /* select the GPU; idempotent */
 int sonic_last_error(char* buf, size_t cap);        /* copies the calling thread's last message */
 int sonic_device_sync(void);
+/* HIP_VERSION the library was compiled against / hipRuntimeGetVersion of the runtime mapped into this process (major * 10^7 +
+ * minor * 10^5 + patch).  A process holds ONE HIP runtime; when another component loaded its own first (a PyTorch-ROCm wheel), the
+ * two differ and the caller may want to know.  No device needed. */
+int sonic_hip_versions(int* build, int* runtime);
 
 /* ---- Sonic.SRS ---- */
 /* SRS.new :: Int -> Fr -> Fr -> SRS  (SRS.hs:27-43).  Generates, on the GPU, the G1 halves the
@@ -220,7 +224,11 @@ int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int ra
  * definition: sonic_amd/csrc/fs.hpp): the proof carries its own challenges.  It serialises the
  * proof (R -> y -> T -> z -> ...: six waits for the GPU instead of one), so the explicit transcript above stays the default.
  *   circuit_digest  SHA-256 of (n, Q, wL, wR, wO, cs): computed once per circuit
- *   prove_fs        blinder_seed: the prover's secret randomness (32 bytes) the four blinders are derived from;
+ *   srs_id          SHA-256 of d and the four G1 elements g^x, g^{alpha x}, g^{1/x}, g^{alpha/x}: binds the transcript to ONE reference
+ *                   string (round 4; the round-3 transcript bound only d)
+ *   prove_fs        blinder_seed: the prover's secret randomness (32 bytes).  The four blinders are derived from the seed AND the
+ *                   circuit digest, the srs id and a digest of the assignment (RFC 6979 style, round 4), so one seed may serve
+ *                   several statements; a seed must still never be disclosed;
  *                   out_transcript (may be NULL): the 8 + 2Q values the proof was made with, in sonic_prove's transcript order --
  *                   sonic_prover_prove on them reproduces the proof byte for byte
  *   fs_challenges   what a proof determines: y, z, y_1..y_Q, z_1..z_Q, u, v (32 bytes each)
@@ -228,7 +236,8 @@ int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int ra
 int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO, const uint8_t* cs, uint8_t out[32]);
 int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], const uint8_t blinder_seed[32], uint8_t* out_proof,
                           uint8_t* out_transcript);
-int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t* proof, uint8_t* out);
+int sonic_fs_srs_id(const sonic_srs_t* srs, uint8_t out[32]);
+int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t srs_id[32], const uint8_t* proof, uint8_t* out);
 int sonic_verify_fs(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                     const uint8_t* cs, const uint8_t* proof, int* accepted);
 

@@ -23,7 +23,7 @@ from .encoding import R_MODULUS, Q_MODULUS, fr_to_bytes, fr_from_bytes, g1_to_by
 from .srs import SRS  # noqa: F401,E402
 from .commitment import commit_poly, open_poly, pc_v, msm_g1, MsmLane  # noqa: F401,E402
 from .protocol import hsc_prove_poly, hsc_verify_poly  # noqa: F401,E402
-from .protocol import prove_fs, verify_fs, fs_challenges, fs_circuit_digest  # noqa: F401,E402
+from .protocol import prove_fs, verify_fs, fs_challenges, fs_circuit_digest, fs_srs_id  # noqa: F401,E402
 from .protocol import proof_from_shares, share_plan, from_x, from_y, biv_add  # noqa: F401,E402
 from .protocol import prove, verify, hsc_prove, hsc_verify, Proof, HscProof, RndOracle, Prover, ProverPipeline, ArithCircuit, Assignment, GateWeights  # noqa: F401,E402
 

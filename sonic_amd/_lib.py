@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
+import warnings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SONIC_HIP_LIB") or os.path.join(_HERE, "csrc", "libsonic_hip.so")   # SONIC_HIP_LIB: another build of the same library (tuning experiments)
@@ -39,13 +41,21 @@ def lib() -> C.CDLL:
             "sonic_amd has no CPU fallback.")
     # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; loaded AFTER this library
     # has pulled in /opt/rocm's, torch finds "No HIP GPUs" (two HSA runtimes cannot share the device).  Loaded first, torch's copy
-    # also serves this library (same SONAME).  torch is only plumbing here (device tensors and RCCL for the multi-GPU exchange), so
-    # it is imported when it is installed and ignored when it is not (the C harness and a Haskell host never see it).
-    if os.environ.get("SONIC_NO_TORCH_PRELOAD") is None:
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+    # also serves this library (same SONAME).  So: if torch is already imported, nothing to do; if it is installed but not yet
+    # imported, it is imported here first -- unless SONIC_TORCH_PRELOAD=0 (or the older SONIC_NO_TORCH_PRELOAD) says the process
+    # will never use torch (the C harness and a Haskell host never see any of this).  What got mapped is checked below.
+    preload = os.environ.get("SONIC_TORCH_PRELOAD", "1") != "0" and os.environ.get("SONIC_NO_TORCH_PRELOAD") is None
+    preloaded = None
+    if preload and "torch" not in sys.modules:
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            try:
+                import torch  # noqa: F401
+                preloaded = True
+            except Exception as e:      # noqa: BLE001
+                warnings.warn(f"sonic_amd: importing torch before libsonic_hip.so failed ({e!r}); torch imported later in this process "
+                              "will not find the GPU")
+                preloaded = False
     L = C.CDLL(LIB_PATH)
     vp, cp, i64, i32 = C.c_void_p, C.c_char_p, C.c_int64, C.c_int
     sig = {
@@ -96,7 +106,8 @@ def lib() -> C.CDLL:
         "sonic_prove_share_plan": [i64, i64, i32, i32, i32, i64, i32, vp, C.POINTER(C.c_double)],
         "sonic_fs_circuit_digest": [i64, i64, vp, vp, vp, vp, vp],
         "sonic_prover_prove_fs": [vp, cp, cp, vp, vp],
-        "sonic_fs_challenges": [i64, i64, i64, cp, vp, vp],
+        "sonic_fs_srs_id": [vp, vp],
+        "sonic_fs_challenges": [i64, i64, i64, cp, cp, vp, vp],
         "sonic_verify_fs": [vp, i64, i64, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "sonic_prover_hsc_prove": [vp, i64, vp, cp, cp, vp],
         "sonic_hsc_prove_poly": [vp, i64, vp, vp, vp, i64, vp, cp, cp, vp],
@@ -134,19 +145,38 @@ def lib() -> C.CDLL:
     L.sonic_hsc_proof_size.restype = C.c_size_t
     L.sonic_proof_share_size.argtypes = [i64]
     L.sonic_proof_share_size.restype = C.c_size_t
+    L.sonic_hip_versions.argtypes = [C.POINTER(i32), C.POINTER(i32)]
+    L.sonic_hip_versions.restype = i32
+    bv, rv = i32(), i32()
+    L.sonic_hip_versions(C.byref(bv), C.byref(rv))
+    if rv.value and bv.value // 10**5 != rv.value // 10**5:
+        # not an error (the ABI this library uses is stable across these), but never silent
+        msg = (f"sonic_amd: libsonic_hip.so was built against HIP {_hipver(bv.value)} and runs on the HIP runtime {_hipver(rv.value)} "
+               f"that was mapped first{' (torch, imported by sonic_amd._lib)' if preloaded else ''}")
+        if os.environ.get("SONIC_DEBUG"):
+            print(msg, file=sys.stderr)
+        global HIP_RUNTIME_NOTE
+        HIP_RUNTIME_NOTE = msg
     _lib = L
     return L
 
 
+HIP_RUNTIME_NOTE = None
+
+
+def _hipver(v: int) -> str:
+    return f"{v // 10**7}.{v // 10**5 % 100}.{v % 10**5}"
+
+
 EXPORTED = [
-    "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_srs_new", "sonic_srs_from_points",
+    "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_hip_versions", "sonic_srs_new", "sonic_srs_from_points",
     "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_has_g2", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
     "sonic_g1_sum_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_msm_lane_new_on_stream", "sonic_msm_submit_dev", "sonic_msm_exchange_layout",
     "sonic_msm_accumulate_dev", "sonic_msm_reduce_slices_dev", "sonic_msm_lane_sync", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_poly_mul_fr_dev", "sonic_msm_set_window", "sonic_srs_point_bytes", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
     "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare",
-    "sonic_prover_set_share", "sonic_proof_share_size", "sonic_prover_prove_share", "sonic_prover_collect_share", "sonic_proof_from_shares", "sonic_prove_share_plan", "sonic_fs_circuit_digest", "sonic_prover_prove_fs", "sonic_fs_challenges", "sonic_verify_fs", "sonic_prover_hsc_prove", "sonic_hsc_prove_poly", "sonic_hsc_verify_poly", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
+    "sonic_prover_set_share", "sonic_proof_share_size", "sonic_prover_prove_share", "sonic_prover_collect_share", "sonic_proof_from_shares", "sonic_prove_share_plan", "sonic_fs_circuit_digest", "sonic_fs_srs_id", "sonic_prover_prove_fs", "sonic_fs_challenges", "sonic_verify_fs", "sonic_prover_hsc_prove", "sonic_hsc_prove_poly", "sonic_hsc_verify_poly", "sonic_hsc_proof_size", "sonic_hsc_verify", "sonic_prover_free", "sonic_pc_v", "sonic_verify", "sonic_dev_alloc", "sonic_dev_free", "sonic_dev_upload",
     "sonic_dev_download", "sonic_profile_enable", "sonic_profile_reset", "sonic_profile_get",
     "sonic_profile_names",
 ]

@@ -243,6 +243,14 @@ int sonic_init(int device_ordinal) {
   return SONIC_OK;
 }
 
+// the HIP the library was built against and the HIP runtime that got mapped into this process (they differ when another
+// component, e.g. a PyTorch-ROCm wheel, brought its own libamdhip64 first); no device needed
+int sonic_hip_versions(int* build, int* runtime) {
+  if (build) *build = HIP_VERSION;
+  if (runtime) { int v = 0; if (hipRuntimeGetVersion(&v) != hipSuccess) v = 0; *runtime = v; }
+  return SONIC_OK;
+}
+
 int sonic_last_error(char* buf, size_t cap) {
   if (!buf || cap == 0) return SONIC_ERR_INVALID_ARG;
   strncpy(buf, g_err, cap - 1);

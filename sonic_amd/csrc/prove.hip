@@ -207,6 +207,8 @@ struct sonic_prover {
   bool share_planned_prepared = false, share_planned = false;
   std::vector<uint8_t> slot_ran;             // per slot (7 + 5Q): the last enqueue queued an MSM for it
   std::vector<uint8_t> fr_valid;             // per evaluation (3 + 2Q): the last enqueue computed it
+  uint8_t witness_digest[32] = {0};          // SHA-256 of the assignment (Fiat-Shamir blinders, fs.hpp), made on first use
+  bool have_witness_digest = false;
   // Lane N_LANES-1 carries the t(X,y) group (the largest, ready last); the other groups alternate over the rest, which
   // balances the point additions per lane (Q = 2: 55M / 51M / 48M) while one lane's sort and reduction phases run under
   // another lane's accumulation.  Streams beyond the 4 hardware queues would serialise behind each other.
@@ -355,6 +357,7 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
   int f = read_flags(st, p->flags);
   if (f) return flags_to_status(f, "sonic_prover_set_assignment");
   p->have_assignment = true;
+  p->have_witness_digest = false;
   API_END
 }
 
@@ -880,9 +883,9 @@ int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8
   return SONIC_OK;
 }
 
-int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t* proof, uint8_t* out) {
-  if (n < 1 || Q < 1 || d < 1 || !circuit_digest || !proof || !out) return SONIC_ERR_INVALID_ARG;
-  fs_challenges_of_proof(n, Q, d, circuit_digest, proof, out);
+int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t srs_id[32], const uint8_t* proof, uint8_t* out) {
+  if (n < 1 || Q < 1 || d < 1 || !circuit_digest || !srs_id || !proof || !out) return SONIC_ERR_INVALID_ARG;
+  fs_challenges_of_proof(n, Q, d, circuit_digest, srs_id, proof, out);
   return SONIC_OK;
 }
 
@@ -895,10 +898,32 @@ int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], c
   if (rc) return rc;
   const long n = p->n, Q = p->Q, d = srs_d(p->srs);
   std::vector<uint8_t> tr(32 * (size_t)(8 + 2 * Q), 0), pf(sonic_proof_size(Q));
-  for (long k = 0; k < 4; k++) fs_blinder(blinder_seed, (uint32_t)k, &tr[32 * k]);
+  uint8_t srs_id[32];
+  if ((rc = sonic_fs_srs_id(p->srs, srs_id))) return rc;
+  if (!p->have_witness_digest) {
+    // SHA-256 of the assignment's canonical bytes, once per set_assignment: the device copy is Montgomery, so a scratch copy is
+    // converted back and brought to the host
+    try {
+      DevBuf tmp(sizeof(Fr) * 3 * n);
+      Fr* t3 = tmp.as<Fr>();
+      HIP_OK(hipMemcpyAsync(t3, p->aL.p, sizeof(Fr) * n, hipMemcpyDeviceToDevice, p->st));
+      HIP_OK(hipMemcpyAsync(t3 + n, p->aR.p, sizeof(Fr) * n, hipMemcpyDeviceToDevice, p->st));
+      HIP_OK(hipMemcpyAsync(t3 + 2 * n, p->aO.p, sizeof(Fr) * n, hipMemcpyDeviceToDevice, p->st));
+      fr_from_mont_enqueue(p->st, t3, 3 * n);
+      std::vector<uint8_t> host(96 * (size_t)n);
+      HIP_OK(hipMemcpyAsync(host.data(), t3, host.size(), hipMemcpyDeviceToHost, p->st));
+      HIP_OK(hipStreamSynchronize(p->st));
+      Sha256 h;
+      h.update("sonic-hip/witness/v1", 20);
+      h.update(host.data(), host.size());
+      h.finish(p->witness_digest);
+      p->have_witness_digest = true;
+    } catch (const HipFail& f) { return f.code; }
+  }
+  for (long k = 0; k < 4; k++) fs_blinder(blinder_seed, circuit_digest, srs_id, p->witness_digest, (uint32_t)k, &tr[32 * k]);
   for (long k = 4; k < 8 + 2 * Q; k++) tr[32 * k] = 1;               // not drawn yet: any invertible value (results that use it are not read)
   FsTranscript t;
-  t.init(n, Q, d, circuit_digest);
+  t.init(n, Q, d, circuit_digest, srs_id);
   auto pass = [&](int ph) {
     p->phases = 1u << ph;
     int r = prove_enqueue(p, tr.data());

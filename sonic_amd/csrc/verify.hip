@@ -242,6 +242,22 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
   catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
 }
 
+// what ties a Fiat-Shamir transcript to ONE reference string (fs.hpp): four G1 elements that determine x and alpha
+int sonic_fs_srs_id(const sonic_srs_t* srs, uint8_t out[32]) {
+  try {
+    if (!srs || !out) return SONIC_ERR_INVALID_ARG;
+    uint8_t pts[4 * 96];
+    int rc = sonic_srs_get_points(srs, 0, 1, 1, pts);                 // g^x            gPositiveX[1]
+    if (!rc) rc = sonic_srs_get_points(srs, 1, 1, 1, pts + 96);       // g^{alpha x}    gPositiveAlphaX[0]
+    if (!rc) rc = sonic_srs_get_points(srs, 0, -1, 1, pts + 192);     // g^{1/x}        gNegativeX[0]
+    if (!rc) rc = sonic_srs_get_points(srs, 1, -1, 1, pts + 288);     // g^{alpha/x}    gNegativeAlphaX[0]
+    if (rc) return rc;
+    fs_srs_id_of_points(srs_d(srs), pts, out);
+    return SONIC_OK;
+  } catch (const HipFail& f) { return f.code; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
+}
+
 // verify for a proof made by sonic_prover_prove_fs: the challenges y, z, (y_j, z_j) are not handed over (RndOracle) but recomputed from
 // the statement and the proof (fs.hpp), and the proof's u, v must be the ones its own transcript yields
 int sonic_verify_fs(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
@@ -252,8 +268,11 @@ int sonic_verify_fs(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t*
     uint8_t digest[32];
     int rc = sonic_fs_circuit_digest(n, Q, wL, wR, wO, cs, digest);
     if (rc) return rc;
+    uint8_t srs_id[32];
+    rc = sonic_fs_srs_id(srs, srs_id);
+    if (rc) return rc;
     std::vector<uint8_t> ch(32 * (size_t)(4 + 2 * Q));
-    fs_challenges_of_proof(n, Q, srs_d(srs), digest, proof, ch.data());
+    fs_challenges_of_proof(n, Q, srs_d(srs), digest, srs_id, proof, ch.data());
     const uint8_t* uv = proof + sonic_proof_size(Q) - 64;
     if (memcmp(uv, &ch[32 * (2 + 2 * Q)], 64) != 0) return SONIC_OK;          // u, v are not this transcript's: rejected
     std::vector<uint8_t> yzs(64 * (size_t)Q);

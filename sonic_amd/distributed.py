@@ -135,9 +135,11 @@ class ShardedMsm:
         L = _lib.lib()
         sets = C.c_int()
         _lib.check(L.sonic_msm_plan(self.srs._h, n, None, None, C.byref(sets)))
+        submitted = False
         with self.torch.cuda.stream(self.stream):
             if n > 0 and sets.value == 1:
                 _lib.check(L.sonic_msm_submit_dev(self._lane, self.srs._h, basis, e0, d_scalars, n, C.c_void_p(self.part.data_ptr())))
+                submitted = True
             elif n > 0:
                 # no single window sum on the device (no window tables, or a slice too small for them): the host folds the
                 # window sums (sonic_msm_collect) and the partial goes back up for the gather
@@ -147,9 +149,13 @@ class ShardedMsm:
                 self.part.copy_(self.torch.frombuffer(bytearray(h.raw), dtype=self.torch.uint8))
             else:
                 self.part.zero_()
-            res = self._gather_and_sum()
-        if n > 0 and sets.value == 1:
-            _lib.check(L.sonic_msm_collect(self._lane, None, None))       # closes the submit (stream already drained)
+            try:
+                res = self._gather_and_sum()
+            finally:
+                # closes the submit whatever the gather reported (a non-canonical scalar raises out of lane_sync): a lane left
+                # in flight would hand the NEXT run_terms the result of this one
+                if submitted:
+                    L.sonic_msm_collect(self._lane, None, None)
         return res
 
     def _ensure_exchange(self, world: int):
@@ -168,8 +174,17 @@ class ShardedMsm:
         self._ensure_exchange(self.world)
         S = self.slice_len
         with torch.cuda.stream(self.stream):
-            _lib.check(L.sonic_msm_accumulate_dev(self._lane, self.srs._h, basis, e0, d_scalars, n,
-                                                  C.c_void_p(self.buckets.data_ptr()), self.world * S))
+            rc = L.sonic_msm_accumulate_dev(self._lane, self.srs._h, basis, e0, d_scalars, n, C.c_void_p(self.buckets.data_ptr()), self.world * S)
+            err = _lib.last_error() if rc else ""
+            if self.pg:
+                # a rank that cannot take part (bad arguments, a slice too large) must not leave the others waiting in the
+                # all-to-all: agree first, on the host (one 4-byte all-reduce; the exchange that follows moves megabytes)
+                ok = torch.tensor([0 if rc else 1], dtype=torch.int32, device=self.part.device if not self.staged else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    raise _lib.SonicError(rc or 7, err or "run_buckets: another rank could not accumulate its slice")
+            elif rc:
+                raise _lib.SonicError(rc, err)
             if self.pg and not self.staged:
                 dist.all_to_all_single(self.recv, self.buckets)           # equal splits: S x 192 B per pair
             elif self.pg:

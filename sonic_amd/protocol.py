@@ -199,6 +199,9 @@ class Prover:
     def prove_fs(self, circuit_digest: bytes, blinder_seed: bytes):
         """prove with the opt-in Fiat-Shamir transcript (sonic_prover_prove_fs): returns (proof bytes, the 8 + 2Q transcript values
         the proof was made with); six waits for the GPU instead of one"""
+        circuit_digest, blinder_seed = bytes(circuit_digest), bytes(blinder_seed)
+        if len(circuit_digest) != 32 or len(blinder_seed) != 32:      # the C side reads 32 bytes of each
+            raise ValueError("prove_fs: circuit_digest and blinder_seed must be 32 bytes each")
         out = C.create_string_buffer(_lib.lib().sonic_proof_size(self.Q))
         tr = C.create_string_buffer(32 * transcript_len(self.Q))
         _lib.check(_lib.lib().sonic_prover_prove_fs(self._h, bytes(circuit_digest), bytes(blinder_seed), out, tr))
@@ -322,11 +325,21 @@ def fs_circuit_digest(circuit: ArithCircuit) -> bytes:
     return out.raw
 
 
+def fs_srs_id(srs: SRS) -> bytes:
+    """SHA-256 of d, g^x, g^{alpha x}, g^{1/x}, g^{alpha/x}: what binds a Fiat-Shamir transcript to one reference string"""
+    out = C.create_string_buffer(32)
+    _lib.check(_lib.lib().sonic_fs_srs_id(srs._h, out))
+    return out.raw
+
+
 def fs_challenges(srs: SRS, circuit: ArithCircuit, proof: Proof) -> RndOracle:
     """the RndOracle a Fiat-Shamir proof determines (sonic_fs_challenges)"""
     wL, wR, wO, cs, n, Q = _circuit_arrays(circuit)
+    raw = proof.to_bytes()
+    if len(raw) != _lib.lib().sonic_proof_size(Q):
+        raise ValueError("fs_challenges: the proof does not have Q entries in its hsc lists")
     out = C.create_string_buffer(32 * (4 + 2 * Q))
-    _lib.check(_lib.lib().sonic_fs_challenges(n, Q, srs.srsD, fs_circuit_digest(circuit), proof.to_bytes(), out))
+    _lib.check(_lib.lib().sonic_fs_challenges(n, Q, srs.srsD, fs_circuit_digest(circuit), fs_srs_id(srs), raw, out))
     v = [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(4 + 2 * Q)]
     return RndOracle(v[0], v[1], list(zip(v[2:2 + Q], v[2 + Q:2 + 2 * Q])))
 

@@ -86,10 +86,13 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> proof((7 + 4 * Q) * 96 + (5 + 2 * Q) * 32), ch(32 * (4 + 2 * Q));
     for (auto& c : proof) c = (uint8_t)rnd64();
     uint8_t dg[32] = {1, 2, 3};
-    fs_challenges_of_proof(8, Q, 61, dg, proof.data(), ch.data());
+    uint8_t sid[32], pts[4 * 96];
+    for (auto& c : pts) c = (uint8_t)rnd64();
+    fs_srs_id_of_points(61, pts, sid);
+    fs_challenges_of_proof(8, Q, 61, dg, sid, proof.data(), ch.data());
     for (int i = 0; i < 4 + 2 * Q; i++) { Fr c; memcpy(c.l, &ch[32 * i], 32); CHECK(fp_is_canonical(c) && !c.is_zero(), "challenge canonical and non-zero"); }
     uint8_t bl[32];
-    for (uint32_t i = 0; i < 4; i++) fs_blinder(dg, i, bl);
+    for (uint32_t i = 0; i < 4; i++) { fs_blinder(dg, dg, sid, sid, i, bl); Fr c; memcpy(c.l, bl, 32); CHECK(fp_is_canonical(c), "blinder canonical"); }
   }
   // ---- SRS file parser: a valid file (with and without the G2 half), every truncation class, trailing bytes, hostile headers ----
   {

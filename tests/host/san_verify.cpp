@@ -44,6 +44,24 @@ int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8
   h.finish(out);
   return 0;
 }
+// g^{alpha^basis x^e} from the trapdoor, canonical bytes (the Fiat-Shamir verifier reads four of them for the srs id, fs.hpp)
+int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out) {
+  constexpr uint32_t gx[12] = G1_GEN_X_MONT, gy[12] = G1_GEN_Y_MONT;
+  G1Affine g;
+  for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t e = e0 + i;
+    if (e < -srs->d || e > srs->d) return SONIC_ERR_SRS_INDEX;
+    if (basis && e == 0) { memset(out + 96 * i, 0, 96); continue; }
+    Fr k = pow_signed(srs->x, e);
+    if (basis) k = fp_mul(k, srs->alpha);
+    const Fr ks = fp_from_mont(k);
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int b = 254; b >= 0; b--) { acc = g1_dbl(acc); if ((ks.l[b >> 5] >> (b & 31)) & 1) acc = g1_add_mixed(acc, g); }
+    g1_canonical_bytes_host(acc, out + 96 * i);
+  }
+  return 0;
+}
 // h^{alpha^basis x^e} from the trapdoor, canonical bytes (what the device-side SRS serves)
 int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out) {
   sonic_srs* s = const_cast<sonic_srs*>(srs);

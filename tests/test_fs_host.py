@@ -28,6 +28,7 @@ def test_python_fs_matches_fixture(ref):
     b, circ, asg = _case(c)
     assert ref.fs_circuit_digest(circ).hex() == c["circuit_digest"]
     srs = ref.SRS(b["d"], int(b["x"], 16), int(b["alpha"], 16))
+    assert ref.fs_srs_id(srs).hex() == c["srs_id"] and ref.fs_witness_digest(asg).hex() == c["witness_digest"]
     proof, _o, tr = ref.prove_fs(srs, asg, circ, bytes.fromhex(c["seed"]))
     assert ref.proof_to_bytes(proof).hex() == c["proof"] and ["%x" % v for v in tr] == c["transcript"]
 
@@ -37,10 +38,20 @@ def test_fixture_is_a_fixed_point(ref):
     for c in FS:
         b, circ, asg = _case(c)
         pb = bytes.fromhex(c["proof"])
-        y, z, ys, zs, u, v = ref.fs_challenges_of_proof(b["n"], b["Q"], b["d"], bytes.fromhex(c["circuit_digest"]), pb)
+        dg, sid, wd = (bytes.fromhex(c[k]) for k in ("circuit_digest", "srs_id", "witness_digest"))
+        y, z, ys, zs, u, v = ref.fs_challenges_of_proof(b["n"], b["Q"], b["d"], dg, sid, pb)
         tr = [int(t, 16) for t in c["transcript"]]
         assert tr[4:] == [y, z] + ys + zs + [u, v]
-        assert tr[:4] == ref.fs_blinders(bytes.fromhex(c["seed"]))
+        assert tr[:4] == ref.fs_blinders(bytes.fromhex(c["seed"]), dg, sid, wd)
+        assert wd == ref.fs_witness_digest(asg)
+        # the blinders depend on the statement, the reference string and the witness, not on the seed alone: one seed on
+        # another assignment / circuit / SRS gives unrelated blinders
+        other = ref.fs_witness_digest((asg[0], asg[1], [(v_ + 1) % R for v_ in asg[2]]))
+        for alt in (ref.fs_blinders(bytes.fromhex(c["seed"]), dg, sid, other), ref.fs_blinders(bytes.fromhex(c["seed"]), bytes(32), sid, wd),
+                    ref.fs_blinders(bytes.fromhex(c["seed"]), dg, bytes(32), wd)):
+            assert not set(alt) & set(tr[:4])
+        # ... and the challenges on the reference string, not only on its degree
+        assert ref.fs_challenges_of_proof(b["n"], b["Q"], b["d"], dg, bytes(32), pb)[0] != y
         assert pb[-64:-32] == ref.fr_to_bytes(u) and pb[-32:] == ref.fr_to_bytes(v)
 
 
@@ -56,7 +67,7 @@ def test_product_transcript_code_matches_python(ref):
         assert L.sonic_fs_circuit_digest(b["n"], b["Q"], aL.ctypes.data, aR.ctypes.data, aO.ctypes.data, acs.ctypes.data, out) == 0
         assert out.raw.hex() == c["circuit_digest"]
         ch = C.create_string_buffer(32 * (4 + 2 * b["Q"]))
-        assert L.sonic_fs_challenges(b["n"], b["Q"], b["d"], out.raw, bytes.fromhex(c["proof"]), ch) == 0
+        assert L.sonic_fs_challenges(b["n"], b["Q"], b["d"], out.raw, bytes.fromhex(c["srs_id"]), bytes.fromhex(c["proof"]), ch) == 0
         got = [int.from_bytes(ch.raw[32 * i:32 * i + 32], "little") for i in range(4 + 2 * b["Q"])]
         assert got == [int(t, 16) for t in c["transcript"]][4:]
 

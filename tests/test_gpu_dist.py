@@ -27,6 +27,21 @@ def _free_port():
     return port
 
 
+def _reports(fn):
+    """a worker that fails puts its exception on the queue, so that the parent fails at once instead of waiting out its timeout"""
+    import functools
+
+    @functools.wraps(fn)
+    def run(rank, *args):
+        try:
+            fn(rank, *args)
+        except BaseException as e:      # noqa: BLE001
+            args[-1].put((rank, False, repr(e)))
+            raise
+    return run
+
+
+@_reports
 def _worker_big(rank, world, port, q):
     """N = 2^22 over two ranks: 2^21 terms each, SRS d = 2^21 on both (replicated), scalars 1, x0, x0^2, ..."""
     sys.path.insert(0, ROOT)
@@ -79,9 +94,10 @@ def test_msm_2p22_two_ranks_one_gpu():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert all(ok for _, ok in res), res
+    assert all(r[1] for r in res), res
 
 
+@_reports
 def _worker(rank, world, port, n_terms, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -140,7 +156,7 @@ def test_range_sharded_msm_ranks_share_one_gpu(n_terms, world):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert all(ok for _, ok in res), res
+    assert all(r[1] for r in res), res
 
 
 def test_bench_two_ranks_one_gpu():
@@ -161,3 +177,87 @@ def test_bench_two_ranks_one_gpu():
     ps = j["prove_strong"]
     assert ps["scaling"] == "strong" and ps["n_gpus"] == 2 and ps["n"] == 1 << 12 and ps["same_bytes_as_one_gpu_alone"] is True and ps["ms_per_proof"] > 0
     assert j["north_star"] is None
+
+
+@_reports
+def _worker_rccl(rank, world, port, q):
+    """one rank per GPU over RCCL: the device-tensor collectives of ShardedMsm (all_gather_into_tensor, all_to_all_single ordered on
+    the lane's stream) and the share all-gather of ShardedProver, against closed forms / the single-GPU proof"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    device = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    try:
+        import sonic_amd
+        from oracle import orc
+        from sonic_amd import _lib, distributed as sd
+        from util import R, big_circuit, rand_fr_array
+        L = _lib.lib()
+        _lib.check(L.sonic_init(rank))
+        d, x, alpha, x0 = 1 << 17, 0x123456789abcdef, 0xfedcba987654321, 0x1000000000000007
+        N = 1 << 18
+        srs = sonic_amd.SRS.new(d, x, alpha)
+        lo, hi = sd.split_range(N, world, rank)
+        buf = bytearray(32 * (hi - lo))
+        v = pow(x0, lo, R)
+        for i in range(hi - lo):
+            buf[32 * i:32 * i + 32] = v.to_bytes(32, "little")
+            v = v * x0 % R
+        mine = np.frombuffer(bytes(buf), np.uint8)
+        dsc = C.c_void_p()
+        _lib.check(L.sonic_dev_alloc(mine.size, C.byref(dsc)))
+        _lib.check(L.sonic_dev_upload(dsc, mine.ctypes.data, mine.size))
+        xx = x0 * x % R
+        want = orc.g1_mul(orc.g1_gen(), pow(x, -d, R) * (pow(xx, N, R) - 1) % R * pow(xx - 1, -1, R) % R)
+        sh = sd.ShardedMsm(srs, rank, world, device)
+        assert not sh.staged
+        ok = sh.run_terms(0, -d + lo, dsc, hi - lo) == want
+        ok = ok and sh.run_buckets(0, -d + lo, dsc, hi - lo) == want
+        ok = ok and sh.run_terms(0, -d + lo, dsc, hi - lo) == want          # and again after an exchange (buffers reused)
+        sh.close()
+        L.sonic_dev_free(dsc)
+        # one proof over the ranks
+        n, Q = 1 << 12, 2
+        circ = big_circuit(21, n, Q)
+        circuit = sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"])
+        asg = sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"])
+        tr = rand_fr_array(np.random.default_rng(8), 8 + 2 * Q)
+        tr[:, 0] |= 1
+        sp = sd.ShardedProver(srs, circuit, rank, world, device)
+        sp.set_assignment(asg)
+        got = sp.prove_bytes(tr)
+        sp.close()
+        one = sonic_amd.Prover(srs, circuit, prepare=False)
+        one.set_assignment(asg)
+        ok = ok and one.prove_bytes(tr) == got
+        one.close()
+        q.put((rank, ok, got[:16].hex()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # counting does not initialise the GPU in this process
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL cannot put two ranks on one device (the pool's test boxes have one; "
+                                             "the same paths run there over gloo and over a one-rank RCCL group)")
+def test_rccl_ranks_on_their_own_gpus():
+    world = min(_gpu_count(), 8)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rccl, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(120)
+    assert all(r[1] for r in res), res
+    assert len({r[2] for r in res}) == 1

@@ -29,7 +29,7 @@ def test_prove_fs_matches_fixture(sonic, case):
     b = BASE[case["name"]]
     srs = sonic.SRS.new(b["d"], int(b["x"], 16), int(b["alpha"], 16))
     circuit, asg = _circuit(sonic, b)
-    assert sonic.fs_circuit_digest(circuit).hex() == case["circuit_digest"]
+    assert sonic.fs_circuit_digest(circuit).hex() == case["circuit_digest"] and sonic.fs_srs_id(srs).hex() == case["srs_id"]
     for prepare in (False, True):
         p = sonic.Prover(srs, circuit, prepare=prepare)
         p.set_assignment(asg)
@@ -55,10 +55,12 @@ def test_prove_fs_random_circuits_and_rejections(sonic, orc, ref):
         proof, oracle = sonic.prove_fs(srs, sonic.Assignment(*asg), circuit, seed)
         raw = proof.to_bytes()
         # the C oracle proves the same bytes from the transcript the hashes yield; python re-derives that transcript from the bytes
-        y, z, ys, zs, u, v = ref.fs_challenges_of_proof(n, Q, d, ref.fs_circuit_digest(circ), raw)
+        rsrs = ref.SRS(d, x, alpha)
+        assert sonic.fs_srs_id(srs) == ref.fs_srs_id(rsrs)
+        y, z, ys, zs, u, v = ref.fs_challenges_of_proof(n, Q, d, ref.fs_circuit_digest(circ), ref.fs_srs_id(rsrs), raw)
         assert (oracle.rndOracleY, oracle.rndOracleZ, oracle.rndOracleYZs) == (y, z, list(zip(ys, zs)))
         assert (proof.prHscProof.hscU, proof.prHscProof.hscV) == (u, v)
-        tr = ref.fs_blinders(seed) + [y, z] + ys + zs + [u, v]
+        tr = ref.fs_blinders(seed, ref.fs_circuit_digest(circ), ref.fs_srs_id(rsrs), ref.fs_witness_digest(asg)) + [y, z] + ys + zs + [u, v]
         want = orc.prove(orc.SRS(d, x, alpha, threads=NCPU), n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], fr_bytes(tr))
         assert raw == want
         assert sonic.verify_fs(srs, circuit, proof)
@@ -77,6 +79,9 @@ def test_prove_fs_random_circuits_and_rejections(sonic, orc, ref):
         cs2 = list(circ[3])
         cs2[0] = (cs2[0] + 1) % R
         assert not sonic.verify_fs(srs, sonic.ArithCircuit(sonic.GateWeights(circ[0], circ[1], circ[2]), cs2), proof)
+        # another reference string of the same d: other challenges (the srs id opens the transcript), rejected
+        srs2 = sonic.SRS.new(d, (x + 1) % R or 1, alpha)
+        assert sonic.fs_challenges(srs2, circuit, proof).rndOracleY != oracle.rndOracleY and not sonic.verify_fs(srs2, circuit, proof)
 
 
 def test_prove_fs_mid_size_and_error_contract(sonic):
@@ -101,4 +106,16 @@ def test_prove_fs_mid_size_and_error_contract(sonic):
     assert e.value.code == 2
     p.set_assignment(asg)
     assert p.prove_fs(digest, b"\x07" * 32)[0] == raw       # the handle is usable afterwards
+    # one seed, two witnesses of the same circuit: the blinders must not repeat (with seed-only blinders R_1 - R_2 was an
+    # unblinded commitment to the difference of the witnesses)
+    aL2, aR2 = circ["aR"].copy(), circ["aL"].copy()          # aL and aR swapped: satisfies the same constraints when wL and wR carry the same row
+    if circ["rows"][0] == circ["rows"][1]:
+        p.set_assignment(sonic.Assignment(aL2, aR2, circ["aO"]))
+        raw2, tr2 = p.prove_fs(digest, b"\x07" * 32)
+        assert not set(tr2[:4]) & set(tr[:4]) and raw2 != raw
+        assert sonic.verify_fs(srs, circuit, sonic.Proof.from_bytes(raw2, Q))
+    with pytest.raises(ValueError):
+        p.prove_fs(digest[:31], b"\x07" * 32)               # short inputs never reach the C side (it reads 32 bytes of each)
+    with pytest.raises(ValueError):
+        p.prove_fs(digest, b"\x07" * 5)
     p.close()
