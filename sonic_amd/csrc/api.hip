@@ -2,6 +2,7 @@
 // the SRS handle and the standalone MSM / NTT entry points.  prove lives in prove.hip.
 #include <stdarg.h>
 #include <string.h>
+#include <vector>
 #include <memory>
 #include "internal.hpp"
 #include "g2.hpp"
@@ -59,6 +60,25 @@ void require_device() {
 hipStream_t default_stream() { return g_stream; }
 MsmWorkspace& shared_msm_ws() { if (!g_msm_ws) g_msm_ws = new MsmWorkspace(); return *g_msm_ws; }
 std::mutex& call_mutex() { return g_call_mu; }
+
+static std::mutex g_pool_mu;
+static std::vector<CallCtx*> g_pool;
+CallLease::CallLease() : c_(nullptr) {
+  {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (!g_pool.empty()) { c_ = g_pool.back(); g_pool.pop_back(); }
+  }
+  if (!c_) {
+    std::unique_ptr<CallCtx> c(new CallCtx());
+    HIP_OK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    c_ = c.release();
+  }
+}
+CallLease::~CallLease() {
+  (void)hipStreamSynchronize(c_->st);        // nothing of this call may still be running when the context is handed on
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  g_pool.push_back(c_);
+}
 
 // ---- encodings ------------------------------------------------------------------------------
 // inf_ok: index at which the point at infinity is accepted (-1: everywhere, as for the operands of sonic_msm_g1; -2: nowhere; an SRS has
@@ -296,8 +316,8 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
   if (!srs || !out || n < 0) return SONIC_ERR_INVALID_ARG;
   if (e0 < -srs->d || e0 + n - 1 > srs->d) { set_error("sonic_srs_get_points: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
   if (n == 0) return SONIC_OK;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
+  CallLease lease;
+  hipStream_t st = lease.st();
   DevBuf raw(96 * n);
   // diagnostic: basis = b + 2 w reads window table w (2^(c w) multiples) of basis b
   const int w = basis >> 1;
@@ -442,8 +462,8 @@ int sonic_msm_plan(const sonic_srs_t* srs, int64_t n, int* window_bits, int* win
 int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]) {
   API_BEGIN
   if (n < 0 || !out_g1 || (n > 0 && (!points || !scalars))) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
+  CallLease lease;
+  hipStream_t st = lease.st();
   const long m = n > 0 ? n : 1;
   DevBuf raw(96 * m), pts(sizeof(G1Affine) * m), sc(32 * m), err(4);
   HIP_OK(hipMemsetAsync(err.p, 0, 4, st));
@@ -458,7 +478,7 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
   HIP_OK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (herr) { set_error("sonic_msm_g1: non-canonical input or point not on curve"); return SONIC_ERR_BAD_ENCODING; }
-  msm_blocking(st, shared_msm_ws(), msm_plan(n > 0 ? n : 1, /*fold=*/false), PointArray::packed(pts.as<G1Affine>()), sc.as<Fr>(), n, false, out_g1, nullptr);
+  msm_blocking(st, lease.ws(), msm_plan(n > 0 ? n : 1, /*fold=*/false), PointArray::packed(pts.as<G1Affine>()), sc.as<Fr>(), n, false, out_g1, nullptr);
   API_END
 }
 
@@ -571,9 +591,16 @@ static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const v
                           int64_t n, uint8_t* out96, uint8_t* out192) {
   try { require_device(); } catch (const HipFail& f) { return f.code; }
   if (!srs || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  static sonic_msm_lane_t* lane = nullptr;
+  // a lane per call from a pool (the blocking MSMs of different host threads run side by side)
+  static std::mutex lanes_mu;
+  static std::vector<sonic_msm_lane_t*> lanes;
+  sonic_msm_lane_t* lane = nullptr;
+  {
+    std::lock_guard<std::mutex> g(lanes_mu);
+    if (!lanes.empty()) { lane = lanes.back(); lanes.pop_back(); }
+  }
   if (!lane) { int rc = sonic_msm_lane_new(&lane); if (rc) return rc; lane->segment = 8; }     // one MSM at a time: shortest chain
+  struct Back { sonic_msm_lane_t* l; std::mutex& mu; std::vector<sonic_msm_lane_t*>& v; ~Back() { std::lock_guard<std::mutex> g(mu); v.push_back(l); } } back{lane, lanes_mu, lanes};
   DevBuf sc;
   const void* dsc = d_scalars;
   try {
@@ -585,7 +612,7 @@ static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const v
   } catch (const HipFail& f) { return f.code; }
   if (n > 0 && !dsc) return SONIC_ERR_INVALID_ARG;
   int rc = sonic_msm_submit(lane, srs, basis, e0, dsc, n);
-  if (rc) return rc;
+  if (rc) { (void)hipStreamSynchronize(lane->st); return rc; }       // (the upload of `sc` may still be in flight)
   return sonic_msm_collect(lane, out96, out192);       // waits for the stream: `sc` may go out of scope afterwards
 }
 

@@ -10,7 +10,23 @@ namespace sonic {
 
 hipStream_t default_stream();
 MsmWorkspace& shared_msm_ws();
+// serialises the calls that CHANGE shared state (SRS construction, the lazy G2 half, the shared NTT tables); the read-only
+// entry points over an SRS (commitPoly, openPoly, hscProve, the blocking MSMs, srs_get_points) run on a leased context instead
 std::mutex& call_mutex();
+// A stream + MSM workspace of its own for the duration of one call: read-only calls on a shared SRS are re-entrant.
+// Contexts are pooled and grow with the number of host threads that are inside the library at once.
+struct CallCtx { hipStream_t st = nullptr; MsmWorkspace ws; };
+class CallLease {
+ public:
+  CallLease();
+  ~CallLease();
+  CallLease(const CallLease&) = delete;
+  CallLease& operator=(const CallLease&) = delete;
+  hipStream_t st() const { return c_->st; }
+  MsmWorkspace& ws() const { return c_->ws; }
+ private:
+  CallCtx* c_;
+};
 
 // SRS handle internals (api.hip)
 PointArray srs_basis(const sonic_srs* s, int b);            // table 0 of a basis, slot e + d; window table w follows at + w (2d+1)

@@ -510,16 +510,19 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   Fr* sy = p->sy0.as<Fr>();
   // ---- all polynomials first (small kernels; queued behind a bucket accumulation they would each wait ~0.5 ms for CUs) ----
   // zkP_1: r'(X,1)                                                                   Protocol.hs:58-63
-  if (need_g0 || need_T) build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
+  // (a polynomial is built in the pass that first knows its challenge -- every pass when phases == PH_ALL -- and stays in the
+  // handle's buffers for the later passes of sonic_prover_prove_fs: r(X,1) from the blinders, s(X,y) and t(X,y) from y, s(X,y_j)
+  // from y_j, s(u,Y) from u)
+  if ((need_g0 || need_T) && on(PH_R)) build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
   ready(p->ev_r1);
   // s(X,y)                                                                           Protocol.hs:69-70
-  if (need_T) {
+  if (need_T && on(PH_T)) {
     poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
     s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, sy);
     HIP_OK(hipMemcpyAsync(p->kpow.p, pw + (2 * n + 1), sizeof(Fr) * Q, hipMemcpyDeviceToDevice, ms));   // y^{n+1..n+Q} for k(y); pw is reused below
   }
   ready(p->ev_sy0);
-  if (need_T && (on(PH_T) || on(PH_OPEN))) {
+  if (need_T && on(PH_T)) {
     // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y), on its own stream          Protocol.hs:69-73, Constraints.hs:56-68
     hipStream_t ts = p->ts;
     HIP_OK(hipStreamWaitEvent(ts, p->ev_sy0, 0));          // ev_sy0 follows ev_r1 on the main stream
@@ -538,7 +541,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   Fr* t = fa;                                                                         // exponents [t_lo, t_lo + t_len)
   // hscProve: s(X, y_j), s(u, Y)                                                     Signature.hs:41,51
   for (long j = 0; j < Q; j++) {
-    if (need_j[(size_t)j]) {
+    if (need_j[(size_t)j] && on(PH_HSCS)) {
       poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pYj(j), pYj(j) + 1);
       // a prepared handle that has only a piece of S_j's diagonal part does not read s(X, y_j) itself
       if (!p->prepared || own(6 + 2 * j) || own(5 + 2 * Q + 2 * j)) s_of_y_enqueue(ms, wL, wR, wO, pw, n, Q, p->syj[j].as<Fr>());
@@ -547,7 +550,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     ready(p->ev_syj[j]);
   }
   const long u_lo = -n, u_len = 2 * n + Q + 1;
-  if (need_su) {
+  if (need_su && on(PH_HSCW)) {
     poly_scale_powers_enqueue(ms, nullptr, pw, 3 * n + 1, -n, pU, pU + 1);           // u^e, e in [-n, 2n]
     s_of_u_enqueue(ms, wL, wR, wO, pw, n, Q, su, p->tmp);
   }
@@ -593,7 +596,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   }
   flush_now(last_group == 2 && sh != nullptr);
   if (need_T) {
-    if (on(PH_T) || on(PH_OPEN)) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
+    if (on(PH_T)) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
     cur = &lane_t; cur->njobs = 0;
     commit(PH_T, t, t_lo, t_len, d, 1);                                                // T            Protocol.hs:73
     open(PH_OPEN, t, t_lo, t_len, pZ, -1, 4);                                          // W_t          :81
@@ -871,8 +874,8 @@ int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int ra
 // The challenges of the reference are `rnd` draws made AFTER certain proof elements exist; as hashes of those elements they
 // serialise the proof: R -> y -> T -> z -> openings -> y_j, z_j -> S_j.. -> u -> C.. -> v -> Q_v.  sonic_prover_prove_fs walks
 // that chain in six passes over the same enqueue (prove_enqueue with one phase bit each): every MSM of the proof still runs
-// exactly once, the polynomial building before it is repeated per pass (cheap), and between passes the host waits, reads the new
-// elements' canonical bytes and hashes.  The caller-supplied transcript stays the default and fast path (one pass, no waits).
+// exactly once and every polynomial is built once, in the pass that first knows its challenge (round 4; it was rebuilt in every pass
+// before); between passes the host waits, reads the new elements' canonical bytes and hashes.  The caller-supplied transcript stays the default and fast path (one pass, no waits).
 int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO, const uint8_t* cs, uint8_t out[32]) {
   if (n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !out) return SONIC_ERR_INVALID_ARG;
   Sha256 h;
@@ -1171,8 +1174,8 @@ int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t*
                          int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out) {
   API_BEGIN
   if (!srs || n_terms < 0 || (n_terms > 0 && (!x_exps || !y_exps || !coeffs)) || m < 0 || (m > 0 && !yzs) || !u || !v || !out) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
+  CallLease lease;
+  hipStream_t st = lease.st();
   const long d = srs_d(srs);
   bool neg_x = false, neg_y = false;
   for (int64_t i = 0; i < n_terms; i++) {
@@ -1212,7 +1215,7 @@ int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t*
   Fr* fo = frout.as<Fr>();
   DevBuf sy(sizeof(Fr) * byx.len), su(sizeof(Fr) * byy.len);
   Scratch sc[MSM_MAX_JOBS];
-  MsmWorkspace& ws = shared_msm_ws();
+  MsmWorkspace& ws = lease.ws();
   // an opening at 0 is only defined without negative exponents (checked above), where it is a shift (open_job_at_zero)
   auto open_any = [&](Scratch& s_, const Fr* poly, long lo, long len, const Fr* zp, bool zero, Fr* fz, MsmSlot* slot) {
     return zero ? open_job_at_zero(st, srs, poly, len, fz ? fz : s_.fz_discard.as<Fr>(), slot, fl)
@@ -1309,15 +1312,15 @@ static int densify(hipStream_t st, const sonic_srs* srs, int64_t nt, const int64
 int sonic_commit_poly(const sonic_srs_t* srs, int64_t max, int64_t n_terms, const int64_t* exps, const uint8_t* coeffs, uint8_t out_g1[96]) {
   API_BEGIN
   if (!srs || n_terms < 0 || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
+  CallLease lease;
+  hipStream_t st = lease.st();
   DevBuf flags(4), slot(sizeof(MsmSlot));
   HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
   DensePoly f;
   int rc = densify(st, srs, n_terms, exps, coeffs, false, f, flags.as<int>());
   if (rc) return rc;
   MsmJob job = commit_job(st, srs, f.c.as<Fr>(), f.lo, f.len, max, slot.as<MsmSlot>(), flags.as<int>());
-  run_jobs(st, srs, shared_msm_ws(), &job, 1);
+  run_jobs(st, srs, lease.ws(), &job, 1);
   MsmSlot h;
   HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));
   int fl = read_flags(st, flags);
@@ -1330,8 +1333,8 @@ int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms
                     uint8_t out_fz[32], uint8_t out_g1[96]) {
   API_BEGIN
   if (!srs || !z || n_terms < 0 || !out_fz || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
+  CallLease lease;
+  hipStream_t st = lease.st();
   DevBuf flags(4), slot(sizeof(MsmSlot)), zin(sizeof(Fr)), zpair(2 * sizeof(Fr)), fz(sizeof(Fr));
   HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
   DensePoly f;
@@ -1345,7 +1348,7 @@ int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms
   MsmJob job = bytes_are_zero(z, 32)
                    ? open_job_at_zero(st, srs, f.c.as<Fr>(), f.len, fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>())
                    : open_job(st, srs, sc, f.c.as<Fr>(), f.lo, f.len, zpair.as<Fr>(), fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>());
-  run_jobs(st, srs, shared_msm_ws(), &job, 1);
+  run_jobs(st, srs, lease.ws(), &job, 1);
   fr_from_mont_enqueue(st, fz.as<Fr>(), 1);
   MsmSlot h;
   HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));

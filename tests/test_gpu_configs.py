@@ -250,6 +250,54 @@ def test_host_threads_share_one_srs(sonic):
     seq.close()
 
 
+def test_readonly_calls_on_one_srs_from_many_threads(sonic, orc):
+    """commitPoly / openPoly / the blocking MSM / hscProve on ONE SRS handle from 6 host threads at once (re-entrant calls on a
+    shared SRS; round 4: each call leases its own stream + workspace instead of queueing behind a process-wide mutex): every result
+    equals the one a single thread got, and the oracle's"""
+    from sonic_amd.commitment import msm_g1_srs
+    pyr = random.Random(4040)
+    d = 1 << 12
+    x, alpha = pyr.randrange(2, R), pyr.randrange(2, R)
+    srs = sonic.SRS.new(d, x, alpha)
+    osrs = orc.SRS(d, x, alpha, threads=NCPU)
+    polys = []
+    for k in range(6):
+        exps = sorted(pyr.sample(range(-1500, 1500), 400 + 50 * k))
+        exps = [e for e in exps if e != 0]
+        polys.append(([(e, pyr.randrange(1, R)) for e in exps], pyr.randrange(1, R), 2000 + k))
+    sc = rand_fr_array(np.random.default_rng(12), 3000)
+    biv = {ex: {ey: pyr.randrange(1, R) for ey in range(-5, 6) if ey} for ex in range(-20, 21) if ex}
+    yz = [(pyr.randrange(1, R), pyr.randrange(1, R))]
+
+    def one(k):
+        poly, z, mx = polys[k]
+        return (sonic.commit_poly(srs, mx, poly), sonic.open_poly(srs, z, poly), msm_g1_srs(srs, k & 1, -1000 + k, sc),
+                sonic.srs_points_bytes(srs, 0, -5 + k, 3) if hasattr(sonic, "srs_points_bytes") else srs.points(0, -5 + k, 3).tobytes(),
+                sonic.hsc_prove_poly(srs, biv, yz, 17 + k, 19 + k))
+    serial = [one(k) for k in range(6)]
+    for k in range(6):                                       # the single-thread results against the oracle
+        poly, z, mx = polys[k]
+        exps = np.array([e for e, _ in poly], np.int64)
+        co = fr_bytes([c for _, c in poly])
+        assert sonic.g1_to_bytes(serial[k][0]) == orc.commit_poly(osrs, mx, exps, co)
+        fz, W = orc.open_poly(osrs, z, exps, co)
+        assert serial[k][1][0] == fz and sonic.g1_to_bytes(serial[k][1][1]) == W
+        assert serial[k][2] == orc.msm_srs(osrs, k & 1, -1000 + k, sc, 1, NCPU)
+    res, errs = {}, []
+
+    def work(k):
+        try:
+            res[k] = [one(k) for _ in range(5)]
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k in range(6):
+        assert res[k] == [serial[k]] * 5, k
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
