@@ -55,6 +55,10 @@ enum {
 #define SONIC_FR_BYTES 32
 #define SONIC_G1_BYTES 96
 #define SONIC_G1_PARTIAL_BYTES 192   /* un-normalised XYZZ accumulator exchanged between ranks */
+/* what the bulk kernels leave of an MSM in DEVICE memory: a header and up to 64 points that the host folds in microseconds (window sums
+ * of a Horner walk, or the bit sums of the round-4 bucket reduction) -- the operand of the cross-rank all-gather that never visits the
+ * host (sonic_msm_submit_dev, sonic_msm_reduce_slices_dev), summed by sonic_g1_sum_dev_partials */
+#define SONIC_G1_DEV_PARTIAL_BYTES 12304
 
 typedef struct sonic_srs sonic_srs_t;
 typedef struct sonic_prover sonic_prover_t;
@@ -135,8 +139,8 @@ int sonic_msm_submit(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, 
 int sonic_msm_collect(sonic_msm_lane_t* lane, uint8_t* out_g1, uint8_t* out_partial);
 /* a lane on a stream the caller owns (e.g. the stream its RCCL collectives are ordered on); the stream must outlive the lane */
 int sonic_msm_lane_new_on_stream(void* hip_stream, sonic_msm_lane_t** out);
-/* sonic_msm_submit that also leaves the un-normalised 192-byte sum in device memory, queued on the lane's stream: the operand
- * of a cross-rank all-gather that never visits the host.  Needs a plan with one window sum (window tables). */
+/* sonic_msm_submit that also leaves the un-normalised result (SONIC_G1_DEV_PARTIAL_BYTES) in device memory, queued on the lane's stream:
+ * the operand of a cross-rank all-gather that never visits the host (ABI note: 192 bytes and window-table plans only up to round 3). */
 int sonic_msm_submit_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
                          void* d_partial_out);
 /* ONE MSM strong-scaled over `world` GPUs by sharding its BUCKETS (the fold of CommitmentScheme.hs:25-29 / 45-48 split twice: by term
@@ -145,7 +149,7 @@ int sonic_msm_submit_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int bas
  *   accumulate  sort + bucket accumulation of this rank's terms into d_buckets (capacity >= world * S entries of 192 B; the
  *               padding is cleared), queued on the lane's stream
  *   -- the caller exchanges slices: all-to-all, rank r receives entries [r S, (r+1) S) of every rank, laid out [world][S] --
- *   reduce      element-wise curve addition of the k slices, then sum_i (bucket_base + i + 1) * slice[i]: 192-byte partial in
+ *   reduce      element-wise curve addition of the k slices, then sum_i (bucket_base + i + 1) * slice[i]: SONIC_G1_DEV_PARTIAL_BYTES in
  *               device memory (gathered and added like the term-range partials), queued on the lane's stream
  *   sync        waits for the lane, reports a non-canonical scalar */
 int sonic_msm_exchange_layout(const sonic_srs_t* srs, int world, int64_t* n_buckets, int64_t* slice_len);
@@ -156,6 +160,8 @@ int sonic_msm_reduce_slices_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, 
 int sonic_msm_lane_sync(sonic_msm_lane_t* lane);
 /* curve addition of k partials (RCCL has no such reduction op) + normalisation */
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]);
+/* the same for k device-side results of SONIC_G1_DEV_PARTIAL_BYTES each (host only) */
+int sonic_g1_sum_dev_partials(const uint8_t* blobs, int k, uint8_t out_g1[96]);
 /* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n) */
 int sonic_ntt_fr(uint8_t* data, int log2n, int inverse);
 /* dense product of two coefficient arrays (the `*` at Constraints.hs:61): out has na+nb-1 Fr */

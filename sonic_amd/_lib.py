@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         "sonic_msm_g1_srs_dev": [vp, i32, i64, vp, i64, vp],
         "sonic_msm_g1_srs_partial_dev": [vp, i32, i64, vp, i64, vp],
         "sonic_g1_sum_partials": [vp, i32, vp],
+        "sonic_g1_sum_dev_partials": [vp, i32, vp],
         "sonic_msm_lane_new": [C.POINTER(vp)],
         "sonic_msm_submit": [vp, vp, i32, i64, vp, i64],
         "sonic_msm_collect": [vp, vp, vp],
@@ -172,7 +173,7 @@ EXPORTED = [
     "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_hip_versions", "sonic_srs_new", "sonic_srs_from_points",
     "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_has_g2", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",
-    "sonic_g1_sum_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_msm_lane_new_on_stream", "sonic_msm_submit_dev", "sonic_msm_exchange_layout",
+    "sonic_g1_sum_partials", "sonic_g1_sum_dev_partials", "sonic_msm_lane_new", "sonic_msm_lane_free", "sonic_msm_submit", "sonic_msm_collect", "sonic_msm_lane_new_on_stream", "sonic_msm_submit_dev", "sonic_msm_exchange_layout",
     "sonic_msm_accumulate_dev", "sonic_msm_reduce_slices_dev", "sonic_msm_lane_sync", "sonic_ntt_fr", "sonic_poly_mul_fr", "sonic_poly_mul_fr_dev", "sonic_msm_set_window", "sonic_srs_point_bytes", "sonic_msm_plan",
     "sonic_proof_size", "sonic_prove", "sonic_prover_new", "sonic_prover_set_assignment",
     "sonic_prover_prove", "sonic_prover_submit", "sonic_prover_collect", "sonic_prover_prepare",

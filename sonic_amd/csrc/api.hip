@@ -154,7 +154,7 @@ void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArra
   DevBuf slot(sizeof(MsmSlot));
   msm_enqueue(st, ws, pl, d_pts, d_sc, n, mont, slot.as<MsmSlot>());
   MsmSlot h;
-  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof(int) * 4 + sizeof(G1XYZZ) * pl.Wb, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof(MsmSlot), hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   G1XYZZ sum = msm_finish_host(h);
   if (out96) g1_canonical_bytes_host(sum, out96);
@@ -559,14 +559,13 @@ static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
   HIP_OK(hipMemsetAsync(l->err.p, 0, 4, st));
   fr_check_enqueue(st, dsc, n, l->err.as<int>());
   MsmPlan pl = srs_msm_plan(srs, n);
-  if (d_partial_out && pl.Wb != 1) { set_error("sonic_msm_submit_dev: this MSM leaves %d window sums for the host to fold (no window tables, or too few terms for them)", pl.Wb); return SONIC_ERR_INVALID_ARG; }
-  static const int seg_env = getenv("SONIC_MSM_SEGMENT") ? atoi(getenv("SONIC_MSM_SEGMENT")) : 0;      // tuning knob: buckets per running-sum segment
+    static const int seg_env = getenv("SONIC_MSM_SEGMENT") ? atoi(getenv("SONIC_MSM_SEGMENT")) : 0;      // tuning knob: buckets per running-sum segment
   if (pl.Wb == 1 && pl.NB >= (1 << 16)) msm_plan_set_segment(pl, seg_env > 0 ? seg_env : l->segment);
   pl.accum_block = 64;           // a lane's MSM runs alone or beside other lanes' MSMs, not inside a proof (msm.hpp)
   msm_enqueue(st, l->ws, pl, srs->basis(basis) + (e0 + srs->d), dsc, n, false, l->slot.as<MsmSlot>());
   l->Wb = pl.Wb;
-  if (d_partial_out) HIP_OK(hipMemcpyAsync(d_partial_out, &l->slot.as<MsmSlot>()->win[0], sizeof(G1XYZZ), hipMemcpyDeviceToDevice, st));
-  HIP_OK(hipMemcpyAsync(l->h_slot, l->slot.p, sizeof(int) * 4 + sizeof(G1XYZZ) * pl.Wb, hipMemcpyDeviceToHost, st));
+  if (d_partial_out) HIP_OK(hipMemcpyAsync(d_partial_out, l->slot.p, sizeof(MsmSlot), hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(l->h_slot, l->slot.p, sizeof(MsmSlot), hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(l->h_err, l->err.p, 4, hipMemcpyDeviceToHost, st));
   l->in_flight = true;
   API_END
@@ -673,7 +672,7 @@ int sonic_msm_reduce_slices_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, con
   std::lock_guard<std::mutex> g(l->mu);
   hipStream_t st = l->st;
   msm_reduce_slices_enqueue(st, l->ws, static_cast<const G1XYZZ*>(d_slices), k, slice_len, bucket_base, srs->tab_c, l->slot.as<MsmSlot>());
-  HIP_OK(hipMemcpyAsync(d_partial_out, &l->slot.as<MsmSlot>()->win[0], sizeof(G1XYZZ), hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(d_partial_out, l->slot.p, sizeof(MsmSlot), hipMemcpyDeviceToDevice, st));
   API_END
 }
 
@@ -685,6 +684,22 @@ int sonic_msm_lane_sync(sonic_msm_lane_t* l) {
   HIP_OK(hipStreamSynchronize(l->st));
   if (*l->h_err) { *l->h_err = 0; set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
   API_END
+}
+
+// the device-side partials of sonic_msm_submit_dev / sonic_msm_reduce_slices_dev (SONIC_G1_DEV_PARTIAL_BYTES each: what the bulk kernels
+// leave of an MSM, a handful of points the host folds) -> their sum, normalised
+static_assert(sizeof(MsmSlot) == SONIC_G1_DEV_PARTIAL_BYTES, "SONIC_G1_DEV_PARTIAL_BYTES is the size of a device-side MSM result");
+int sonic_g1_sum_dev_partials(const uint8_t* blobs, int k, uint8_t out_g1[96]) {
+  if (!blobs || k < 1 || !out_g1) return SONIC_ERR_INVALID_ARG;
+  G1XYZZ acc = G1XYZZ::inf();
+  std::unique_ptr<MsmSlot> s(new MsmSlot());
+  for (int i = 0; i < k; i++) {
+    memcpy(s.get(), blobs + sizeof(MsmSlot) * (size_t)i, sizeof(MsmSlot));
+    if (s->W < 0 || s->W >= MSM_MAX_WINDOWS || s->c < 0 || s->c > 32) { set_error("sonic_g1_sum_dev_partials: blob %d is not a device-side MSM result", i); return SONIC_ERR_INVALID_ARG; }
+    acc = g1_add(acc, msm_finish_host(*s));
+  }
+  g1_canonical_bytes_host(acc, out_g1);
+  return SONIC_OK;
 }
 
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]) {

@@ -681,6 +681,92 @@ __global__ __launch_bounds__(256, 2) void k_group_sum(const G1XYZZ* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
+// ---- bucket reduction as an in-place bit-sum butterfly (round 4; shared bucket sets) ---------------------------------------------
+// sum_i (i + 1) B_i over a set of 2^L buckets  =  tot + sum_j 2^j bs_j   with  tot = sum_i B_i,  bs_j = sum_{i : bit j of i} B_i.
+// The L + 1 sums come out of ONE log-depth tree with no scalar multiplication in it: for a block of 2^m buckets starting at s keep
+// Z[s] = the block's total and Z[s + 2^j] = the block's sum over local indices with bit j set (j < m).  Two neighbouring blocks
+// (s and s + h, h = 2^(m-1)) combine IN PLACE with m additions that touch disjoint elements:
+//     Z[s] += Z[s + h]              Z[s + 2^j] += Z[s + h + 2^j]  (j < m - 1)
+// and the new bs_(m-1) is the right block's total, which already sits at Z[s + h] = Z[s + 2^(m-1)].  Level m costs (NB / 2^m) m
+// additions, all independent: ~2 NB additions in total -- fewer than the running sums over K-bucket segments, which paid 2 NB + a
+// ~30-step multiple per segment (2.5 NB at K = 64, 5.8 NB at K = 8) -- and the dependent chain is L additions deep instead of
+// 2K + ~30 + 16.  What is left for the host is Horner over L + 1 points (msm_finish_host: ~20 us), next to the normalisation it
+// does anyway.  Measured: profiles/r04_bucket_tree.txt.
+constexpr int TREE_BLOCK_LOG = 10;          // buckets per workgroup of the first launch: 1024 (4 per thread)
+constexpr int TREE_MID_LOG = 14;            // second launch: one workgroup per 2^14 buckets, levels 11..14; third: one per set
+
+// item `it` of level m inside the span that starts at s0: pair = it / m, component = it % m (0: total, j: bit j - 1)
+__device__ __forceinline__ void tree_item(G1XYZZ* __restrict__ Z, size_t s0, int m, uint32_t it) {
+  const uint32_t pair = it / (uint32_t)m, comp = it % (uint32_t)m;
+  const size_t s = s0 + ((size_t)pair << m);
+  const size_t pos = comp == 0 ? 0 : (size_t)1 << (comp - 1);
+  const size_t h = (size_t)1 << (m - 1);
+  Z[s + pos] = g1_add(Z[s + pos], Z[s + h + pos]);
+}
+
+// first launch: levels 1, 2 in registers (4 buckets per thread: 4 additions), then levels 3 .. LB through memory, one workgroup per
+// block of 2^LB buckets (the block's lines stay in this CU's cache; __syncthreads orders the levels)
+__global__ __launch_bounds__(256, 2) void k_bucket_tree_block(G1XYZZ* __restrict__ Z, int LB) {
+  const size_t s0 = (size_t)blockIdx.x << LB;
+  const uint32_t nthreads = 1u << (LB - 2);
+  if (threadIdx.x < nthreads) {
+    G1XYZZ* b = Z + s0 + 4 * (size_t)threadIdx.x;
+    const G1XYZZ b1 = b[1], b3 = b[3];
+    const G1XYZZ p01 = g1_add(b[0], b1);
+    const G1XYZZ p23 = g1_add(b[2], b3);
+    b[0] = g1_add(p01, p23);       // total
+    b[1] = g1_add(b1, b3);         // bit 0
+    b[2] = p23;                    // bit 1
+  }
+  for (int m = 3; m <= LB; m++) {
+    __syncthreads();
+    const uint32_t items = (uint32_t)m << (LB - m);
+    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) tree_item(Z, s0, m, it);
+  }
+}
+
+// later launches: levels m_lo .. m_hi over spans of 2^span_log buckets, one workgroup per span.  final_L > 0 (then span_log == final_L:
+// one workgroup per bucket set): the set's sums go to its job's slot -- win[j] = bs_j (j < L), win[L] = total, W = L, c = 1,
+// pad0 = the total's weight (1, or base + 1 for a bucket range that starts at `base`), pad1 = 1 marks the form (msm_finish_host)
+__global__ __launch_bounds__(256, 2) void k_bucket_tree_levels(G1XYZZ* __restrict__ Z, int span_log, int m_lo, int m_hi, int final_L,
+                                                               uint32_t tot_mul, const MsmBatchDev batch) {
+  const size_t s0 = (size_t)blockIdx.x << span_log;
+  for (int m = m_lo; m <= m_hi; m++) {
+    if (m > m_lo) __syncthreads();
+    const uint32_t items = (uint32_t)m << (span_log - m);
+    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) tree_item(Z, s0, m, it);
+  }
+  if (final_L > 0) {
+    __syncthreads();
+    MsmSlot* slot = batch.slot[blockIdx.x];
+    if ((int)threadIdx.x <= final_L) {
+      G1XYZZ r = Z[s0 + ((int)threadIdx.x == final_L ? 0 : (size_t)1 << threadIdx.x)];
+      r.x = fp_canonical(r.x); r.y = fp_canonical(r.y); r.zz = fp_canonical(r.zz); r.zzz = fp_canonical(r.zzz);   // leaves the device (lazy range)
+      slot->win[threadIdx.x] = r;
+    }
+    if (threadIdx.x == 0) { slot->W = final_L; slot->c = 1; slot->pad0 = (int)tot_mul; slot->pad1 = 1; }
+  }
+}
+
+static const bool g_use_tree = !(getenv("SONIC_MSM_TREE") && atoi(getenv("SONIC_MSM_TREE")) == 0);      // knob: 0 = the running-sum segments of rounds 1-3
+bool msm_tree_reduction() { return g_use_tree; }
+
+// reduces `sets` bucket sets of 2^L buckets each (consecutive in Z) into the jobs' slots
+static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint32_t tot_mul, const MsmBatchDev& batch) {
+  const int LB = L < TREE_BLOCK_LOG ? L : TREE_BLOCK_LOG;
+  LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB);
+  int done = LB;
+  if (L > done) {
+    const int mid = L < TREE_MID_LOG ? L : TREE_MID_LOG;
+    if (mid < L) {
+      LAUNCH(k_bucket_tree_levels, (uint32_t)sets << (L - mid), 256, 0, st, Z, mid, done + 1, mid, 0, 0u, batch);
+      done = mid;
+    }
+  }
+  // last launch: one workgroup per set finishes the levels that are left (none when L <= TREE_BLOCK_LOG) and fills the slot
+  LAUNCH(k_bucket_tree_levels, (uint32_t)sets, 256, 0, st, Z, L, done + 1, L, L, tot_mul, batch);
+}
+
 // ---- tail (host) -----------------------------------------------------------------------------
 // What is left of an MSM after the bulk kernels is W <= 64 window sums: Horner over the windows
 // (255 dependent doublings) and one Fq inversion for the canonical affine form.  That is ~2600
@@ -691,6 +777,18 @@ G1XYZZ msm_finish_host(const MsmSlot& s) {
   // ~20 us per window sum (0.3 ms per proof), so every window sum is copied out once before it is used
   const int W = s.W, c = s.c;
   G1XYZZ acc = G1XYZZ::inf();
+  if (s.pad1 == 1) {
+    // bit-sum form (k_bucket_tree_levels): sum_j 2^j win[j] + pad0 * win[W]
+    for (int w = W - 1; w >= 0; w--) {
+      G1XYZZ win;
+      memcpy(&win, &s.win[w], sizeof win);
+      acc = g1_add(g1_dbl(acc), win);
+    }
+    G1XYZZ tot;
+    memcpy(&tot, &s.win[W], sizeof tot);
+    const uint32_t mul = (uint32_t)s.pad0;
+    return g1_add(acc, mul == 1 ? tot : g1_mul_small(tot, mul));
+  }
   for (int w = W - 1; w >= 0; w--) {
     G1XYZZ win;
     memcpy(&win, &s.win[w], sizeof win);
@@ -771,6 +869,12 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
   if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)
   const int sets = k * pl.Wb;
+  if (g_use_tree && pl.Wb == 1 && pl.NB >= 4) {
+    int L = 0;
+    while ((1 << L) < pl.NB) L++;
+    bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), sets, L, 1u, batch);
+    return;
+  }
   LAUNCH(k_bucket_segments, ceil_div((long)sets * pl.nseg, 256), 256, 0, st, (const G1XYZZ*)ws.buckets.as<G1XYZZ>(), sets,
          pl.NB, pl.K, pl.nseg, 0, ws.segres.as<G1XYZZ>());
   if (pl.nseg > 4096) {
@@ -809,6 +913,21 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
   if (k < 1 || len < K || len % MSM_SLICE_QUANTUM || base % MSM_SLICE_QUANTUM || base + len >= (1L << 31))
     throw std::runtime_error("msm_reduce_slices_enqueue: slice length and base must be multiples of MSM_SLICE_QUANTUM");
   const int nseg = (int)(len / K);
+  if (g_use_tree) {
+    // the butterfly wants a power of two: the sum of the slices goes into a zero-padded (= infinity) copy; bucket i weighs base + i + 1
+    int L = 2;
+    while (((long)1 << L) < len) L++;
+    const long P = (long)1 << L;
+    ws.buckets.ensure((size_t)P * sizeof(G1XYZZ));
+    if (P > len) HIP_OK(hipMemsetAsync(ws.buckets.as<G1XYZZ>() + len, 0, (size_t)(P - len) * sizeof(G1XYZZ), st));
+    LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+    MsmBatchDev b1;
+    memset(&b1, 0, sizeof b1);
+    b1.k = 1;
+    b1.slot[0] = d_slot;
+    bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), 1, L, (uint32_t)(base + 1), b1);
+    return;
+  }
   ws.buckets.ensure((size_t)len * sizeof(G1XYZZ));
   ws.segres.ensure(((size_t)nseg + nseg / 256 + 2) * sizeof(G1XYZZ));
   const G1XYZZ* B = d_slices;

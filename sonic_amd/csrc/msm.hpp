@@ -48,10 +48,14 @@ constexpr int MSM_TABLE_MAX_WINDOWS = 32;
 constexpr long MSM_MAX_TERMS = 1L << 31;
 
 // Per-MSM hand-off between the bulk kernels and the (deferred, batched) tail: the per-window sums.
+// Two forms: W window sums of a c-bit Horner walk (per-window bucket sets; pad1 == 0), or -- shared bucket sets reduced by the
+// bit-sum butterfly, pad1 == 1 -- win[j] = sum of the buckets whose index has bit j set (j < W), win[W] = the sum of all buckets
+// and pad0 = its weight: the MSM is sum_j 2^j win[j] + pad0 win[W].  msm_finish_host folds either.
 struct MsmSlot {
   int W, c, pad0, pad1;
   G1XYZZ win[MSM_MAX_WINDOWS];
 };
+bool msm_tree_reduction();
 
 struct MsmWorkspace {
   DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, heavy_meta, heavy_items, heavy_partial;

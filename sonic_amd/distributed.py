@@ -31,6 +31,21 @@ import numpy as np
 from . import _lib
 
 PARTIAL_BYTES = 192
+DEV_PARTIAL_BYTES = 12304       # SONIC_G1_DEV_PARTIAL_BYTES: a device-side MSM result (header + up to 64 points the host folds)
+
+
+def dev_partial_from_sum(partial192: bytes) -> bytes:
+    """a finished 192-byte XYZZ sum in the device-partial form: one window sum (W = 1, c = 1)"""
+    import struct
+    return struct.pack("<iiii", 1, 1, 0, 0) + bytes(partial192) + bytes(DEV_PARTIAL_BYTES - 16 - PARTIAL_BYTES)
+
+
+def sum_dev_partials(blobs: np.ndarray, k: int) -> bytes:
+    """the sum of k device-side MSM results (DEV_PARTIAL_BYTES each), normalised -> 96 canonical bytes"""
+    p = np.ascontiguousarray(blobs, np.uint8)
+    out = C.create_string_buffer(96)
+    _lib.check(_lib.lib().sonic_g1_sum_dev_partials(p.ctypes.data, k, out))
+    return out.raw
 
 
 def msm_shard(rank: int, world: int, d: int, terms_per_rank: int) -> Tuple[int, int]:
@@ -109,8 +124,8 @@ class ShardedMsm:
         self._lane = C.c_void_p()
         _lib.check(_lib.lib().sonic_msm_lane_new_on_stream(C.c_void_p(self.stream.cuda_stream), C.byref(self._lane)))
         with torch.cuda.stream(self.stream):          # allocated and cleared on the stream everything else here is ordered on
-            self.part = torch.zeros(PARTIAL_BYTES, dtype=torch.uint8, device=device)
-            self.gathered = torch.zeros(world * PARTIAL_BYTES, dtype=torch.uint8, device=device)
+            self.part = torch.zeros(DEV_PARTIAL_BYTES, dtype=torch.uint8, device=device)
+            self.gathered = torch.zeros(world * DEV_PARTIAL_BYTES, dtype=torch.uint8, device=device)
         self.buckets = self.recv = None
         self.n_buckets = self.slice_len = 0
         self._layout_world = 0
@@ -123,32 +138,23 @@ class ShardedMsm:
             host = self.gathered.cpu()                                   # the one device-to-host copy (waits for the stream)
         elif self.pg:
             mine = self.part.cpu()
-            host = torch.empty(self.world * PARTIAL_BYTES, dtype=torch.uint8)
+            host = torch.empty(self.world * DEV_PARTIAL_BYTES, dtype=torch.uint8)
             dist.all_gather_into_tensor(host, mine)
         else:
             host = self.part.cpu()
         _lib.check(_lib.lib().sonic_msm_lane_sync(self._lane))            # the stream has drained: reports non-canonical scalars
-        return sum_partials(host.numpy(), self.world)
+        return sum_dev_partials(host.numpy(), self.world)
 
     def run_terms(self, basis: int, e0: int, d_scalars, n: int) -> bytes:
         """this rank's term slice [e0, e0 + n) through the whole bucket method; partials gathered on the device"""
         L = _lib.lib()
-        sets = C.c_int()
-        _lib.check(L.sonic_msm_plan(self.srs._h, n, None, None, C.byref(sets)))
         submitted = False
         with self.torch.cuda.stream(self.stream):
-            if n > 0 and sets.value == 1:
+            if n > 0:
                 _lib.check(L.sonic_msm_submit_dev(self._lane, self.srs._h, basis, e0, d_scalars, n, C.c_void_p(self.part.data_ptr())))
                 submitted = True
-            elif n > 0:
-                # no single window sum on the device (no window tables, or a slice too small for them): the host folds the
-                # window sums (sonic_msm_collect) and the partial goes back up for the gather
-                _lib.check(L.sonic_msm_submit(self._lane, self.srs._h, basis, e0, d_scalars, n))
-                h = C.create_string_buffer(PARTIAL_BYTES)
-                _lib.check(L.sonic_msm_collect(self._lane, None, h))
-                self.part.copy_(self.torch.frombuffer(bytearray(h.raw), dtype=self.torch.uint8))
             else:
-                self.part.zero_()
+                self.part.zero_()               # W = 0: the empty sum
             try:
                 res = self._gather_and_sum()
             finally:

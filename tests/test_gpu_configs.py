@@ -97,16 +97,16 @@ def test_msm_2p22_sharded_on_one_gpu(sonic, orc, big_srs, kind, world):
             lo, hi = sd.split_range(N, world, r)
             _lib.check(L.sonic_msm_accumulate_dev(sh._lane, srs._h, 0, -d + lo, C.c_void_p(dsc.value + 32 * lo), hi - lo,
                                                   C.c_void_p(full[r].data_ptr()), world * S))
-        parts2 = torch.zeros(world * 192, dtype=torch.uint8, device=dev)
+        parts2 = torch.zeros(world * sd.DEV_PARTIAL_BYTES, dtype=torch.uint8, device=dev)
         for r in range(world):
             # what rank r's all-to-all would deliver: slice r of every rank's bucket set, laid out [world][S]
             recv = torch.cat([full[s][r * S * 192:(r + 1) * S * 192] for s in range(world)])
             _lib.check(L.sonic_msm_reduce_slices_dev(sh._lane, srs._h, C.c_void_p(recv.data_ptr()), world, S, r * S,
-                                                     C.c_void_p(parts2.data_ptr() + 192 * r)))
+                                                     C.c_void_p(parts2.data_ptr() + sd.DEV_PARTIAL_BYTES * r)))
             torch.cuda.current_stream().synchronize()
         host = parts2.cpu().numpy()
     _lib.check(L.sonic_msm_lane_sync(sh._lane))
-    assert sd.sum_partials(host, world) == whole.raw
+    assert sd.sum_dev_partials(host, world) == whole.raw
     # the single-process forms of the two schemes (no process group: world 1)
     assert sh.run_terms(0, -d, dsc, N) == whole.raw
     assert sh.run_buckets(0, -d, dsc, N) == whole.raw
@@ -130,7 +130,7 @@ def test_bucket_exchange_uneven_world_and_errors(sonic, orc):
     dev = torch.device("cuda", 0)
     sh = sd.ShardedMsm(srs, 0, 1, dev)
     full = [torch.zeros(world * S * 192, dtype=torch.uint8, device=dev) for _ in range(world)]
-    parts = torch.zeros(world * 192, dtype=torch.uint8, device=dev)
+    parts = torch.zeros(world * sd.DEV_PARTIAL_BYTES, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     with torch.cuda.stream(sh.stream):
         for r in range(world):
@@ -140,10 +140,10 @@ def test_bucket_exchange_uneven_world_and_errors(sonic, orc):
         for r in range(world):
             recv = torch.cat([full[s][r * S * 192:(r + 1) * S * 192] for s in range(world)])
             _lib.check(L.sonic_msm_reduce_slices_dev(sh._lane, srs._h, C.c_void_p(recv.data_ptr()), world, S, r * S,
-                                                     C.c_void_p(parts.data_ptr() + 192 * r)))
+                                                     C.c_void_p(parts.data_ptr() + sd.DEV_PARTIAL_BYTES * r)))
             torch.cuda.current_stream().synchronize()
         host = parts.cpu().numpy()
-    assert sd.sum_partials(host, world) == want
+    assert sd.sum_dev_partials(host, world) == want
     # contract: capacity, quantum, SRS range, non-canonical scalars
     assert L.sonic_msm_accumulate_dev(sh._lane, srs._h, 1, -d, dsc, N, C.c_void_p(full[0].data_ptr()), NB - 1) == 7
     assert L.sonic_msm_reduce_slices_dev(sh._lane, srs._h, C.c_void_p(full[0].data_ptr()), 1, S - 1, 0, C.c_void_p(parts.data_ptr())) == 7
