@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void k_window_sum(const G1XYZZ* __restrict_
     G1XYZZ r = sh[0];                 // leaves the device for the host tail: representatives below q (field.hpp, lazy range)
     r.x = fp_canonical(r.x); r.y = fp_canonical(r.y); r.zz = fp_canonical(r.zz); r.zzz = fp_canonical(r.zzz);
     slot->win[w] = r;
-    if (w == 0) { slot->W = W; slot->c = c; }
+    if (w == 0) { slot->W = W; slot->c = c; slot->pad0 = 0; slot->pad1 = 0; }
   }
 }
 
@@ -869,7 +869,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
   if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)
   const int sets = k * pl.Wb;
-  if (g_use_tree && pl.Wb == 1 && pl.NB >= 4) {
+  if (g_use_tree && pl.tree && pl.Wb == 1 && pl.NB >= 4) {
     int L = 0;
     while ((1 << L) < pl.NB) L++;
     bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), sets, L, 1u, batch);

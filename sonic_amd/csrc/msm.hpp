@@ -28,6 +28,11 @@ struct MsmPlan {
   // wave slot without waiting for three more (k_bucket_accum 2.31-2.40 against 2.42-2.45 ms, MSM 2^20 streamed 3.22-3.24 against
   // 3.33-3.59 ms).  SONIC_ACCUM_BLOCK overrides both.
   int accum_block = 256;
+  // reduce the shared bucket set by the bit-sum butterfly (log-depth, least work, ~4x the memory traffic) instead of running sums over
+  // K-bucket segments (one pass over the buckets, a long dependent chain per segment).  The tree wins wherever the reduction is
+  // exposed -- a stand-alone MSM, the last group of a proof, a rank's few pieces of a shared proof -- the segments where it hides under
+  // other groups' accumulation (profiles/r04_bucket_tree.txt).
+  bool tree = true;
   // fold scalars s > (r-1)/2 into r - s on the negated point: valid iff r P = O.  Every SRS element is in the r-torsion;
   // caller-supplied points of sonic_msm_g1 only have to be on the curve (E(Fq) has cofactor points, e.g. (0, 2) of order 3),
   // and s P then means the literal multiple the reference's `mul` computes, so that entry point does not fold.

@@ -78,20 +78,26 @@ static MsmJob commit_job(hipStream_t st, const sonic_srs* srs, const Fr* poly, l
 
 // The MSMs that become ready together run as one batched kernel chain when the SRS has window tables (msm.hpp);
 // otherwise one after the other.
-static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const MsmJob* jobs, int k, bool last = false) {
+static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const MsmJob* jobs, int k, bool last = false, bool exposed = true) {
   if (k <= 0) return;
   long nmax = 0;
   for (int j = 0; j < k; j++) nmax = std::max(nmax, jobs[j].n);
   MsmPlan pl = srs_msm_plan(srs, nmax);
+  // SONIC_PROVE_TREE: which groups reduce their buckets by the bit-sum butterfly: 0 none, 1 the group that finishes last (default),
+  // 2 all.  `exposed`: the caller knows that little else runs beside this group (a rank's share of a proof split over many GPUs).
+  static const int tree_mode = getenv("SONIC_PROVE_TREE") ? atoi(getenv("SONIC_PROVE_TREE")) : 1;
+  const bool tree = tree_mode >= 2 || (tree_mode == 1 && (last || exposed));
   if (k > 1 && msm_can_batch(pl)) {
     // the group that finishes last reduces with nothing left to hide under: shortest chain instead of least work
     msm_plan_set_segment(pl, prove_segment(pl, k, last));
+    pl.tree = tree;
     msm_enqueue_batch(st, ws, pl, jobs, k, true);
     return;
   }
   for (int j = 0; j < k; j++) {
     MsmPlan p1 = srs_msm_plan(srs, jobs[j].n);
     msm_plan_set_segment(p1, prove_segment(p1, 1, false));
+    p1.tree = tree;
     msm_enqueue_batch(st, ws, p1, &jobs[j], 1, true);
   }
 }
@@ -480,7 +486,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   std::vector<std::function<void()>> after_flush;       // small MSMs that use the lane's workspace after the batch (stream order)
   auto flush_now = [&](bool last = false) {
     if (!cur) return;
-    run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last);
+    run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last, /*exposed=*/p->share_world >= 4);
     cur->njobs = 0;
     for (auto& f : after_flush) f();
     after_flush.clear();
