@@ -695,7 +695,7 @@ int sonic_g1_sum_dev_partials(const uint8_t* blobs, int k, uint8_t out_g1[96]) {
   std::unique_ptr<MsmSlot> s(new MsmSlot());
   for (int i = 0; i < k; i++) {
     memcpy(s.get(), blobs + sizeof(MsmSlot) * (size_t)i, sizeof(MsmSlot));
-    if (s->W < 0 || s->W >= MSM_MAX_WINDOWS || s->c < 0 || s->c > 32) { set_error("sonic_g1_sum_dev_partials: blob %d is not a device-side MSM result", i); return SONIC_ERR_INVALID_ARG; }
+    if (s->W < 0 || s->W > MSM_MAX_WINDOWS || (s->pad1 == 1 && s->W >= MSM_MAX_WINDOWS) || s->c < 0 || s->c > 32) { set_error("sonic_g1_sum_dev_partials: blob %d is not a device-side MSM result", i); return SONIC_ERR_INVALID_ARG; }
     acc = g1_add(acc, msm_finish_host(*s));
   }
   g1_canonical_bytes_host(acc, out_g1);

@@ -34,7 +34,10 @@ namespace sonic {
 #define SONIC_PART_LOW_BITS 8
 #endif
 constexpr int PART_LOW_BITS = SONIC_PART_LOW_BITS;   // buckets per sort partition = 2^PART_LOW_BITS (8..10)
-constexpr int PART_TILE = 1024;            // scalars per tile in pass 1
+#ifndef SONIC_PART_TILE
+#define SONIC_PART_TILE 1024
+#endif
+constexpr int PART_TILE = SONIC_PART_TILE;            // scalars per tile in pass 1
 constexpr uint32_t PASS1_GRID = 1024;      // workgroups of pass 1 (grid-stride over the tiles)
 // workgroups of pass 2 (grid-stride over the (job, partition) pairs): one MSM over 2^19 buckets has 2048 partitions and keeps one
 // workgroup each; a batched group of three or four would otherwise queue 6144-8192 short workgroups behind the wave slots that other
@@ -754,6 +757,8 @@ bool msm_tree_reduction() { return g_use_tree; }
 // reduces `sets` bucket sets of 2^L buckets each (consecutive in Z) into the jobs' slots
 static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint32_t tot_mul, const MsmBatchDev& batch) {
   const int LB = L < TREE_BLOCK_LOG ? L : TREE_BLOCK_LOG;
+  // (a first launch with 8 buckets per thread -- 11 additions in registers, blocks of 2048, one wave per SIMD -- measured the same:
+  // 0.51 + 2 x 0.09 ms against 0.52 + 2 x 0.10 ms at 2^19 buckets)
   LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB);
   int done = LB;
   if (L > done) {
