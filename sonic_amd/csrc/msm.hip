@@ -27,6 +27,7 @@
 #include <string.h>
 #include <stdexcept>
 #include "msm.hpp"
+#include "g1_quad.hpp"
 
 namespace sonic {
 
@@ -707,9 +708,31 @@ __device__ __forceinline__ void tree_item(G1XYZZ* __restrict__ Z, size_t s0, int
   Z[s + pos] = g1_add(Z[s + pos], Z[s + h + pos]);
 }
 
+// the same item shared by the four lanes of a quad (g1_quad.hpp): lane r moves coordinate r.  Every lane of the quad calls it with
+// the same `it`.
+__device__ __forceinline__ void tree_item_quad(G1XYZZ* __restrict__ Z, size_t s0, int m, uint32_t it, int r) {
+  const uint32_t pair = it / (uint32_t)m, comp = it % (uint32_t)m;
+  const size_t s = s0 + ((size_t)pair << m);
+  const size_t pos = comp == 0 ? 0 : (size_t)1 << (comp - 1);
+  const size_t h = (size_t)1 << (m - 1);
+  Fq* pa = reinterpret_cast<Fq*>(&Z[s + pos]) + r;
+  const Fq* pb = reinterpret_cast<const Fq*>(&Z[s + h + pos]) + r;
+  *pa = g1q_add(*pa, *pb, r);
+}
+// one level inside a workgroup: whole additions per lane while there are more additions than lanes, a quad per addition once at most
+// two rounds of quads cover the level (the chain, not the issue slots, is what the late levels wait for)
+__device__ __forceinline__ void tree_level(G1XYZZ* __restrict__ Z, size_t s0, int m, uint32_t items, bool quads_ok) {
+  if (quads_ok && items * 4 <= 2 * blockDim.x) {
+    const int r = threadIdx.x & 3;
+    for (uint32_t it = threadIdx.x >> 2; it < items; it += blockDim.x >> 2) tree_item_quad(Z, s0, m, it, r);
+  } else {
+    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) tree_item(Z, s0, m, it);
+  }
+}
+
 // first launch: levels 1, 2 in registers (4 buckets per thread: 4 additions), then levels 3 .. LB through memory, one workgroup per
 // block of 2^LB buckets (the block's lines stay in this CU's cache; __syncthreads orders the levels)
-__global__ __launch_bounds__(256, 2) void k_bucket_tree_block(G1XYZZ* __restrict__ Z, int LB) {
+__global__ __launch_bounds__(256, 2) void k_bucket_tree_block(G1XYZZ* __restrict__ Z, int LB, int quads) {
   const size_t s0 = (size_t)blockIdx.x << LB;
   const uint32_t nthreads = 1u << (LB - 2);
   if (threadIdx.x < nthreads) {
@@ -723,8 +746,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_tree_block(G1XYZZ* __restrict
   }
   for (int m = 3; m <= LB; m++) {
     __syncthreads();
-    const uint32_t items = (uint32_t)m << (LB - m);
-    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) tree_item(Z, s0, m, it);
+    tree_level(Z, s0, m, (uint32_t)m << (LB - m), quads != 0);
   }
 }
 
@@ -732,12 +754,11 @@ __global__ __launch_bounds__(256, 2) void k_bucket_tree_block(G1XYZZ* __restrict
 // one workgroup per bucket set): the set's sums go to its job's slot -- win[j] = bs_j (j < L), win[L] = total, W = L, c = 1,
 // pad0 = the total's weight (1, or base + 1 for a bucket range that starts at `base`), pad1 = 1 marks the form (msm_finish_host)
 __global__ __launch_bounds__(256, 2) void k_bucket_tree_levels(G1XYZZ* __restrict__ Z, int span_log, int m_lo, int m_hi, int final_L,
-                                                               uint32_t tot_mul, const MsmBatchDev batch) {
+                                                               uint32_t tot_mul, int quads, const MsmBatchDev batch) {
   const size_t s0 = (size_t)blockIdx.x << span_log;
   for (int m = m_lo; m <= m_hi; m++) {
     if (m > m_lo) __syncthreads();
-    const uint32_t items = (uint32_t)m << (span_log - m);
-    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) tree_item(Z, s0, m, it);
+    tree_level(Z, s0, m, (uint32_t)m << (span_log - m), quads != 0);
   }
   if (final_L > 0) {
     __syncthreads();
@@ -759,17 +780,18 @@ static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint
   const int LB = L < TREE_BLOCK_LOG ? L : TREE_BLOCK_LOG;
   // (a first launch with 8 buckets per thread -- 11 additions in registers, blocks of 2048, one wave per SIMD -- measured the same:
   // 0.51 + 2 x 0.09 ms against 0.52 + 2 x 0.10 ms at 2^19 buckets)
-  LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB);
+  static const int quads = getenv("SONIC_TREE_QUADS") ? atoi(getenv("SONIC_TREE_QUADS")) : 1;      // knob: 0 = whole additions per lane on every level
+  LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB, quads);
   int done = LB;
   if (L > done) {
     const int mid = L < TREE_MID_LOG ? L : TREE_MID_LOG;
     if (mid < L) {
-      LAUNCH(k_bucket_tree_levels, (uint32_t)sets << (L - mid), 256, 0, st, Z, mid, done + 1, mid, 0, 0u, batch);
+      LAUNCH(k_bucket_tree_levels, (uint32_t)sets << (L - mid), 256, 0, st, Z, mid, done + 1, mid, 0, 0u, quads, batch);
       done = mid;
     }
   }
   // last launch: one workgroup per set finishes the levels that are left (none when L <= TREE_BLOCK_LOG) and fills the slot
-  LAUNCH(k_bucket_tree_levels, (uint32_t)sets, 256, 0, st, Z, L, done + 1, L, L, tot_mul, batch);
+  LAUNCH(k_bucket_tree_levels, (uint32_t)sets, 256, 0, st, Z, L, done + 1, L, L, tot_mul, quads, batch);
 }
 
 // ---- tail (host) -----------------------------------------------------------------------------
@@ -906,6 +928,24 @@ __global__ __launch_bounds__(256, 1) void k_sum_slices(const G1XYZZ* __restrict_
   out[i] = acc;
 }
 
+// the same for k = 4, 8, 12, ...: four threads per bucket sum k / 4 slices each, then two levels through LDS -- a chain of k / 4 + 1
+// additions instead of k - 1 (65536 buckets x 8 slices: 0.16 -> ~0.09 ms on the nearly empty chip of a strong-scaled MSM)
+__global__ __launch_bounds__(256, 2) void k_sum_slices4(const G1XYZZ* __restrict__ slices, int k, long len, G1XYZZ* __restrict__ out) {
+  __shared__ G1XYZZ sh[256];
+  const long i = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int part = threadIdx.x & 3, per = k >> 2;
+  G1XYZZ acc = G1XYZZ::inf();
+  if (i < len) {
+    acc = slices[(size_t)(part * per) * len + i];
+    for (int s = 1; s < per; s++) acc = g1_add(acc, slices[(size_t)(part * per + s) * len + i]);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if ((part & 1) == 0) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + 1]);
+  __syncthreads();
+  if (part == 0 && i < len) out[i] = g1_add(sh[threadIdx.x], sh[threadIdx.x + 2]);
+}
+
 void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot) {
   // buckets per running-sum segment of a slice: a rank's 1/world of the buckets leaves most of the chip idle, so the chain, not the
   // work, is what counts -- shorter segments, more threads (tuning knob SONIC_SLICE_SEGMENT: 1, 2, 4 or 8)
@@ -925,7 +965,8 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
     const long P = (long)1 << L;
     ws.buckets.ensure((size_t)P * sizeof(G1XYZZ));
     if (P > len) HIP_OK(hipMemsetAsync(ws.buckets.as<G1XYZZ>() + len, 0, (size_t)(P - len) * sizeof(G1XYZZ), st));
-    LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+    if (k >= 4 && k % 4 == 0) LAUNCH(k_sum_slices4, ceil_div(len, 64), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+    else LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
     MsmBatchDev b1;
     memset(&b1, 0, sizeof b1);
     b1.k = 1;

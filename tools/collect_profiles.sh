@@ -2,7 +2,7 @@
 # Collects the measurements DESIGN.md section 5 quotes, on one MI355X box:  bash tools/collect_profiles.sh r03
 # Writes gpurun_out/<tag>/...; tools/publish_profiles.sh <tag> copies the summaries into profiles/ afterwards.
 # PMC passes are separate runs with one counter group each and no tracing, as MI355X_MICROARCH.md's HBM section prescribes.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -38,7 +38,7 @@ python3 tools/valu_budget.py $(find $OUT/pmc_valu -name "*counter_collection.csv
 {
   echo "# python bench.py --msm-strong --emulate-world E --no-cpu --steps 10: one GPU doing ONE rank's share of an N = 2^22 MSM split over E ranks (UNMEASURED ON MULTI-GPU HARDWARE: device copy instead of the xGMI all-to-all)"
   for E in 2 4 8; do
-    python3 bench.py --msm-strong --emulate-world $E --no-cpu --steps 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['msm_strong']; e=d['emulated_share']; print('E=$E  whole MSM on one GPU %.3f ms   one share %.3f ms   ratio %.2f   kernels %s' % (d['ms_per_msm'], e['ms_per_share'], e['speedup_vs_single'], {k: v for k, v in e['kernel_ms'].items() if v >= 0.02}))"
+    python3 bench.py --msm-strong --emulate-world $E --no-cpu --steps 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['msm_strong']; e=d['emulated_share']; print('E=$E  whole MSM on one GPU %.3f ms   one share %.3f ms   ratio %.2f   + modelled xGMI exchange %.3f ms -> %.3f ms, ratio %.2f   kernels %s' % (d['ms_per_msm'], e['ms_per_share'], e['speedup_vs_single'], e['exchange_model']['ms'], e['ms_per_share_with_modelled_exchange'], e['speedup_with_modelled_exchange'], {k: v for k, v in e['kernel_ms'].items() if v >= 0.02}))"
   done
 } > $OUT/msm_strong_emulated.txt
 python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1

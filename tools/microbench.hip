@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "g1.hpp"
+#include "g1_quad.hpp"
 using namespace sonic;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -209,6 +210,58 @@ __global__ __launch_bounds__(256) void k_check_dbl(const G1Affine* pts, int n, i
   same(g1_add_affine_walk(p, qm, (t & 2) != 0), (t & 2) ? G1XYZZ::from_affine(p) : g1_add_mixed(G1XYZZ::from_affine(p), qm));
 }
 
+// the lane-cooperative addition / doubling (g1_quad.hpp) against the general ones: every quad takes its own case, so a wave mixes
+// general position, P + P (doubling), P + (-P), either operand at infinity, both at infinity, and non-trivial ZZ on both sides
+__global__ __launch_bounds__(256) void k_check_quad(const G1Affine* pts, int n, int* bad) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t >> 2, r = t & 3;
+  const G1Affine p = pts[q % n], o = pts[(q * 7 + 3) % n];
+  G1XYZZ A = g1_dbl(g1_add_mixed(G1XYZZ::from_affine(p), o));         // some point with ZZ != 1
+  G1XYZZ B = g1_add_mixed(g1_dbl_affine(o), p);
+  switch (q % 8) {
+    case 0: break;
+    case 1: B = A; break;                                             // P + P
+    case 2: B = g1_neg(A); break;                                     // P + (-P)
+    case 3: A = G1XYZZ::inf(); break;
+    case 4: B = G1XYZZ::inf(); break;
+    case 5: A = G1XYZZ::inf(); B = G1XYZZ::inf(); break;
+    case 6: B = g1_dbl(g1_dbl(A)); B = g1_add(B, g1_neg(g1_add(g1_dbl(A), A))); break;    // 4A - 3A: the SAME point as A in other coordinates
+    default: A = G1XYZZ::from_affine(p); B = G1XYZZ::from_affine(o); break;             // ZZ = 1 on both sides
+  }
+  const Fq* ca = reinterpret_cast<const Fq*>(&A);
+  const Fq* cb = reinterpret_cast<const Fq*>(&B);
+  const Fq got = g1q_add(ca[r], cb[r], r);
+  const G1XYZZ want = g1_add(A, B);
+  // compare as group elements: gather the quad's four coordinates (every lane rebuilds the point)
+  G1XYZZ G;
+  Fq* cg = reinterpret_cast<Fq*>(&G);
+  cg[0] = fq_quad<QP_B0>(got); cg[1] = fq_quad<QP_B1>(got); cg[2] = fq_quad<QP_B2>(got); cg[3] = fq_quad<0xFF>(got);
+  const G1Affine x = g1_to_affine(G), y = g1_to_affine(want);
+  if (G.is_inf() != want.is_inf() || x.x != y.x || x.y != y.y) atomicAdd(bad, 1);
+  const Fq gd = g1q_dbl(ca[r], r);
+  G1XYZZ D;
+  Fq* cd = reinterpret_cast<Fq*>(&D);
+  cd[0] = fq_quad<QP_B0>(gd); cd[1] = fq_quad<QP_B1>(gd); cd[2] = fq_quad<QP_B2>(gd); cd[3] = fq_quad<0xFF>(gd);
+  const G1XYZZ wd = g1_dbl(A);
+  const G1Affine u = g1_to_affine(D), v = g1_to_affine(wd);
+  if (D.is_inf() != wd.is_inf() || u.x != v.x || u.y != v.y) atomicAdd(bad + 1, 1);
+}
+// dependent chains of additions: one lane per chain (general addition) and one quad per chain -- the latency the reduction tree pays
+__global__ __launch_bounds__(256) void k_chain_full(G1XYZZ* out, const G1Affine* pts, int iters) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  G1XYZZ acc = g1_dbl_affine(pts[t & 4095]);
+  const G1XYZZ inc = g1_dbl_affine(pts[(t * 3 + 1) & 4095]);
+  for (int i = 0; i < iters; i++) acc = g1_add(acc, inc);
+  out[t] = acc;
+}
+__global__ __launch_bounds__(256) void k_chain_quad(G1XYZZ* out, const G1Affine* pts, int iters) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t >> 2, r = t & 3;
+  const G1XYZZ a0 = g1_dbl_affine(pts[q & 4095]), i0 = g1_dbl_affine(pts[(q * 3 + 1) & 4095]);
+  Fq acc = reinterpret_cast<const Fq*>(&a0)[r];
+  const Fq inc = reinterpret_cast<const Fq*>(&i0)[r];
+  for (int i = 0; i < iters; i++) acc = g1q_add(acc, inc, r);
+  reinterpret_cast<Fq*>(&out[q])[r] = acc;
+}
+
 template <class F> float time_ms(F f, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -230,6 +283,10 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_check_dbl, 16, 256, 0, 0, (const G1Affine*)pts, 4096, bad, 11); hipMemcpy(hb, bad, 12, hipMemcpyDeviceToHost);
     printf("dbl_affine^11 vs mul_small(2^11): %d mismatches; add_mixed(P,P) vs dbl: %d mismatches; fused walk addition vs general (incl. exceptional lanes): %d mismatches\n", hb[0], hb[1], hb[2]);
     if (hb[0] | hb[1] | hb[2]) return 3; }
+  { int* bad; int hb[2] = {0, 0}; hipMalloc(&bad, 8); hipMemset(bad, 0, 8);
+    hipLaunchKernelGGL(k_check_quad, 64, 256, 0, 0, (const G1Affine*)pts, 4096, bad); hipMemcpy(hb, bad, 8, hipMemcpyDeviceToHost);
+    printf("quad addition vs general (8 cases per wave, exceptional ones included): %d mismatches; quad doubling: %d mismatches\n", hb[0], hb[1]);
+    if (hb[0] | hb[1]) return 4; }
   if (check_only) { printf("self-checks ok\n"); return 0; }
   const double lanes = (double)blocks * threads;
   { int it = 32768; float ms = time_ms([&] { hipLaunchKernelGGL(k_mad, blocks, threads, 0, 0, (uint64_t*)buf, 12345u, 67891u, it); }, 10);
@@ -248,5 +305,10 @@ int main(int argc, char** argv) {
     printf("g1_add_mixed:  %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
   { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd_walk, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
     printf("g1_add_mixed_walk (fused asm): %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
+  // latency of a dependent addition: ONE wave per SIMD (the late levels of the bucket-reduction tree), whole addition per lane vs per quad
+  { int it = 32; const int bl = pr.multiProcessorCount, th = 256;
+    float m1 = time_ms([&] { hipLaunchKernelGGL(k_chain_full, bl, th, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
+    float m2 = time_ms([&] { hipLaunchKernelGGL(k_chain_quad, bl, th, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
+    printf("dependent XYZZ addition, one wave per SIMD: %.2f us per addition on a lane, %.2f us on a quad (%.2fx)\n", 1e3 * m1 / it, 1e3 * m2 / it, m1 / m2); }
   return 0;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copies the summaries of gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/ under the round's prefix, and derives
 # the two JSON files bench.py reads (kernel model, HBM traffic per kernel).   bash tools/publish_profiles.sh r03
-TAG=${1:-r03}
+TAG=${1:-r04}
 IN=gpurun_out/$TAG
 P=profiles
 for f in bench.json microbench.txt ba_bench.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt; do
