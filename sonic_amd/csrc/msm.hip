@@ -928,24 +928,6 @@ __global__ __launch_bounds__(256, 1) void k_sum_slices(const G1XYZZ* __restrict_
   out[i] = acc;
 }
 
-// the same for k = 4, 8, 12, ...: four threads per bucket sum k / 4 slices each, then two levels through LDS -- a chain of k / 4 + 1
-// additions instead of k - 1 (65536 buckets x 8 slices: 0.16 -> ~0.09 ms on the nearly empty chip of a strong-scaled MSM)
-__global__ __launch_bounds__(256, 2) void k_sum_slices4(const G1XYZZ* __restrict__ slices, int k, long len, G1XYZZ* __restrict__ out) {
-  __shared__ G1XYZZ sh[256];
-  const long i = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
-  const int part = threadIdx.x & 3, per = k >> 2;
-  G1XYZZ acc = G1XYZZ::inf();
-  if (i < len) {
-    acc = slices[(size_t)(part * per) * len + i];
-    for (int s = 1; s < per; s++) acc = g1_add(acc, slices[(size_t)(part * per + s) * len + i]);
-  }
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  if ((part & 1) == 0) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + 1]);
-  __syncthreads();
-  if (part == 0 && i < len) out[i] = g1_add(sh[threadIdx.x], sh[threadIdx.x + 2]);
-}
-
 void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot) {
   // buckets per running-sum segment of a slice: a rank's 1/world of the buckets leaves most of the chip idle, so the chain, not the
   // work, is what counts -- shorter segments, more threads (tuning knob SONIC_SLICE_SEGMENT: 1, 2, 4 or 8)
@@ -965,8 +947,9 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
     const long P = (long)1 << L;
     ws.buckets.ensure((size_t)P * sizeof(G1XYZZ));
     if (P > len) HIP_OK(hipMemsetAsync(ws.buckets.as<G1XYZZ>() + len, 0, (size_t)(P - len) * sizeof(G1XYZZ), st));
-    if (k >= 4 && k % 4 == 0) LAUNCH(k_sum_slices4, ceil_div(len, 64), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
-    else LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+    // (a quad per bucket, and four lanes per bucket with an LDS tree, both measured slower at 65536 buckets x 8 slices -- 0.21 / 0.22 against
+    // 0.15 ms: the kernel reads 100 MB once and is bound by that, not by its chain of 7 additions)
+    LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
     MsmBatchDev b1;
     memset(&b1, 0, sizeof b1);
     b1.k = 1;
