@@ -250,21 +250,21 @@ def main():
             _lib.check(L.sonic_poly_mul_fr_dev(da, na, db, nb, do))
         L.sonic_profile_enable(0)
         per = {}
-        for nm in ("k_ntt_stage2", "k_ntt_stage", "k_ntt_local", "k_fr_pointwise_mul"):
+        for nm in ("k_ntt_wide", "k_ntt_local", "k_fr_pointwise_mul"):
             ms, cnt = C.c_double(), C.c_int64()
             L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
             per[nm] = {"ms_per_product": round(ms.value / reps, 4), "launches_per_product": cnt.value // reps}
         t_ms = sum(v["ms_per_product"] for v in per.values())
-        passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_stage2", "k_ntt_stage", "k_ntt_local")) // 3
+        passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_wide", "k_ntt_local")) // 3
         alg = 288.0 * M
-        ntt = {"bound": "hbm", "kernel": "three radix-2 transforms of size M + the pointwise product (k_ntt_stage2 / k_ntt_stage / k_ntt_local / k_fr_pointwise_mul)",
+        ntt = {"bound": "hbm", "kernel": "three radix-2 transforms of size M + the pointwise product (k_ntt_wide / k_ntt_local / k_fr_pointwise_mul)",
                "M": M, "achieved": round(alg / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_product": round(t_ms, 4),
                "algorithmic_bytes": alg, "algorithmic_bytes_rule": "288 M: each transform reads and writes M x 32 B once (3 x 64 M) + 96 M for the pointwise product (SURVEY 8d lower bound)",
                "hbm_passes_per_transform": passes, "bytes_by_design": float((3 * passes * 64 + 96) * M),
                "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
-               "note": "the HBM roof is SURVEY 8d's framing; the transforms are bound by VALU issue (one Fr product + add + sub per butterfly, ~400 "
-                       "instructions): fusing three wide stages per pass or two LDS stages per round trip changed nothing (DESIGN.md A.7)"}
+               "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS (round 4) the transforms "
+                       "are bound by VALU issue: one Fr product (328 instructions) + add + sub per butterfly (DESIGN.md section 5)"}
         for ptr in (da, db, do):
             L.sonic_dev_free(ptr)
 

@@ -263,13 +263,14 @@ HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
 #endif
 }
 
-// Fq add / sub on the device: two interleaved carry chains in one asm block (48 VALU instead of the
-// ~125 the compiler emits for the portable loops); Fr and the host keep the portable code.
+// add / sub on the device: two interleaved carry chains in one asm block (Fq: 48 VALU instead of the ~125 the compiler emits for
+// the portable loops; Fr, round 4: 32, canonical range -- the NTT butterflies and the scans are made of these); the host keeps
+// the portable code.
 template <class P>
 HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SONIC_NO_ASM_MUL)
   if constexpr (P::N == FQ_LIMBS) return sonic_fq_add_asm<P>(a, b);
-  else return fp_add_generic(a, b);
+  else return sonic_fr_add_asm<P>(a, b);
 #else
   return fp_add_generic(a, b);
 #endif
@@ -278,7 +279,7 @@ template <class P>
 HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SONIC_NO_ASM_MUL)
   if constexpr (P::N == FQ_LIMBS) return sonic_fq_sub_asm<P>(a, b);
-  else return fp_sub_generic(a, b);
+  else return sonic_fr_sub_asm<P>(a, b);
 #else
   return fp_sub_generic(a, b);
 #endif

@@ -8,6 +8,7 @@
 // Stages whose butterfly span fits a 2048-element tile (64 KB of the CU's 160 KB LDS) run fused in
 // one kernel out of LDS; wider stages stream through HBM one stage per launch.
 #include <algorithm>
+#include <stdlib.h>
 #include "internal.hpp"
 
 namespace sonic {
@@ -33,58 +34,55 @@ __global__ __launch_bounds__(256) void k_ntt_twiddles(Fr* __restrict__ tw, long 
   for (int j = 0; j < 16 && k0 + j < half; j++) { tw[k0 + j] = p; p = fp_mul(p, w); }
 }
 
-// one butterfly per thread, stage s of a DIF (forward) or DIT (inverse) pass through HBM
 // The streaming kernels below run grid-stride over a capped grid (WIDE_GRID workgroups).  Launched beside a bucket accumulation,
 // which holds every wave slot with long-lived waves, a kernel gets a slot only when an accumulation workgroup retires: with one
 // short workgroup per 256 elements a 2^23-point stage needed 8192 such grants and took 36 ms instead of 0.15 ms; a few hundred
 // long-lived workgroups need a few hundred.
-static constexpr int WIDE_GRID = 512;
+static const int WIDE_GRID = getenv("SONIC_NTT_GRID") ? atoi(getenv("SONIC_NTT_GRID")) : 512;
 static inline int wide_grid(long items) { long g = (items + 255) / 256; return (int)(g < WIDE_GRID ? g : WIDE_GRID); }
 
-__global__ __launch_bounds__(256) void k_ntt_stage(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s, int tw_shift, int inverse) {
-  const long halfn = 1L << (log2n - 1);
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < halfn; t += (long)gridDim.x * blockDim.x) {
-  long half = 1L << (log2n - 1 - s);
-  long j = t & (half - 1);
-  long i0 = ((t >> (log2n - 1 - s)) << (log2n - s)) + j;
-  long i1 = i0 + half;
-  Fr w = tw[(j << s) << tw_shift];
-  Fr a = d[i0], b = d[i1];
-  if (!inverse) { d[i0] = fp_add(a, b); d[i1] = fp_mul(fp_sub(a, b), w); }
-  else { Fr bw = fp_mul(b, w); d[i0] = fp_add(a, bw); d[i1] = fp_sub(a, bw); }
-  }
-}
-
-// Two consecutive wide stages in one pass through HBM (radix 4): a thread owns x[i0 + k q], k = 0..3, q = n >> (s + 2), and does
-// stage s (span 2q) and stage s + 1 (span q) on them -- DIF order forward, the reverse (DIT) order inverse.  Halves the number of
-// 64-B-per-element passes of the wide part (2^23 points: 12 -> 6 passes per transform).
-__global__ __launch_bounds__(256) void k_ntt_stage2(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s, int tw_shift, int inverse) {
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (1L << (log2n - 2)); t += (long)gridDim.x * blockDim.x) {
-  const int lq = log2n - 2 - s;                    // log2 q
-  const long q = 1L << lq;
-  const long j = t & (q - 1);
-  const long i0 = ((t >> lq) << (lq + 2)) + j;
-  Fr x0 = d[i0], x1 = d[i0 + q], x2 = d[i0 + 2 * q], x3 = d[i0 + 3 * q];
-  const Fr wa = tw[(j << s) << tw_shift];          // stage s, position j
-  const Fr wb = tw[((j + q) << s) << tw_shift];    // stage s, position j + q
-  const Fr wc = tw[(j << (s + 1)) << tw_shift];    // stage s + 1, position j
-  if (!inverse) {
-    const Fr y0 = fp_add(x0, x2), y2 = fp_mul(fp_sub(x0, x2), wa);
-    const Fr y1 = fp_add(x1, x3), y3 = fp_mul(fp_sub(x1, x3), wb);
-    d[i0] = fp_add(y0, y1);
-    d[i0 + q] = fp_mul(fp_sub(y0, y1), wc);
-    d[i0 + 2 * q] = fp_add(y2, y3);
-    d[i0 + 3 * q] = fp_mul(fp_sub(y2, y3), wc);
-  } else {
-    const Fr b1 = fp_mul(x1, wc), b3 = fp_mul(x3, wc);
-    const Fr y0 = fp_add(x0, b1), y1 = fp_sub(x0, b1);
-    const Fr y2 = fp_add(x2, b3), y3 = fp_sub(x2, b3);
-    const Fr c2 = fp_mul(y2, wa), c3 = fp_mul(y3, wb);
-    d[i0] = fp_add(y0, c2);
-    d[i0 + 2 * q] = fp_sub(y0, c2);
-    d[i0 + q] = fp_add(y1, c3);
-    d[i0 + 3 * q] = fp_sub(y1, c3);
-  }
+// Several consecutive WIDE stages in one pass through HBM (round 4; before: two per pass as radix-4 butterflies in registers, 6 passes
+// per 2^21-point transform, each bound by the ~4 TB/s its 32-byte strided accesses reach).  Stages s0 .. s0 + ns - 1 only connect
+// elements whose indices differ in the ns bits below bit log2n - s0: a workgroup takes the 2^ns "rows" i = base + k * stride
+// (stride = 2^(log2n - s0 - ns)) for C consecutive columns -- 1024 elements, 32 KB of LDS, C x 32 B contiguous per row -- runs the ns
+// stages out of LDS and writes the block back in place.  Ten wide stages are two passes of five.
+static constexpr int WIDE_ELEMS_LOG = 10;      // elements per workgroup block
+__global__ __launch_bounds__(256) void k_ntt_wide(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
+                                                  const Fr* __restrict__ scale) {
+  __shared__ Fr sh[1 << WIDE_ELEMS_LOG];
+  const int lc = WIDE_ELEMS_LOG - ns;                       // log2 C
+  const int lstride = log2n - s0 - ns;                      // log2 of the row stride
+  const long col_blocks = 1L << (lstride - lc);
+  const long nitems = col_blocks << s0;
+  for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const long u = item >> (lstride - lc), cb = item & (col_blocks - 1);
+    const long base = (u << (log2n - s0)) + (cb << lc);
+    for (int e = threadIdx.x; e < (1 << WIDE_ELEMS_LOG); e += 256) sh[e] = d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))];
+    __syncthreads();
+    for (int t = 0; t < ns; t++) {
+      const int tt = inverse ? ns - 1 - t : t;               // forward (DIF): widest span first; inverse (DIT): the reverse
+      const int s = s0 + tt;
+      const int hb = ns - 1 - tt;                            // the row bit this stage pairs
+      const int lhalf = log2n - 1 - s;                       // log2 of the butterfly span in elements
+      for (int bt = threadIdx.x; bt < (1 << (WIDE_ELEMS_LOG - 1)); bt += 256) {
+        const int c = bt & ((1 << lc) - 1), kp = bt >> lc;
+        const int k = ((kp >> hb) << (hb + 1)) | (kp & ((1 << hb) - 1));         // row with bit hb clear
+        const int e0 = (k << lc) | c, e1 = e0 + (1 << (hb + lc));
+        const long j = (((long)(k & ((1 << hb) - 1)) << lstride) + (cb << lc) + c) & ((1L << lhalf) - 1);
+        const Fr w = tw[(j << s) << tw_shift];
+        const Fr a = sh[e0], b = sh[e1];
+        if (!inverse) { sh[e0] = fp_add(a, b); sh[e1] = fp_mul(fp_sub(a, b), w); }
+        else { const Fr bw = fp_mul(b, w); sh[e0] = fp_add(a, bw); sh[e1] = fp_sub(a, bw); }
+      }
+      __syncthreads();
+    }
+    if (scale) {
+      const Fr sc = *scale;
+      for (int e = threadIdx.x; e < (1 << WIDE_ELEMS_LOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = fp_mul(sh[e], sc);
+    } else {
+      for (int e = threadIdx.x; e < (1 << WIDE_ELEMS_LOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = sh[e];
+    }
+    __syncthreads();
   }
 }
 
@@ -104,14 +102,24 @@ __global__ __launch_bounds__(256) void k_ntt_local(Fr* __restrict__ d, const Fr*
   for (int k = 0; k < tile_log; k++) {
     const int hl = inverse ? k : tile_log - 1 - k;       // log2(half)
     const int s = log2n - 1 - hl;
-    for (int bt = threadIdx.x; bt < tile / 2; bt += 256) {
-      int j = bt & ((1 << hl) - 1);
-      int i0 = ((bt >> hl) << (hl + 1)) + j;
-      int i1 = i0 + (1 << hl);
-      Fr w = tw[((long)j << s) << tw_shift];
-      Fr a = sh[i0], b = sh[i1];
-      if (!inverse) { sh[i0] = fp_add(a, b); sh[i1] = fp_mul(fp_sub(a, b), w); }
-      else { Fr bw = fp_mul(b, w); sh[i0] = fp_add(a, bw); sh[i1] = fp_sub(a, bw); }
+    // a thread's (up to four) butterflies of the stage: all twiddles and operands are requested first, then the arithmetic runs (the
+    // twiddle comes from L2 / HBM; with two waves per SIMD nothing else hides that latency)
+    constexpr int BPT = (1 << TILE_LOG) / 2 / 256;
+    Fr w[BPT], a[BPT], b[BPT];
+    int i0[BPT];
+#pragma unroll
+    for (int u = 0; u < BPT; u++) {
+      const int bt = threadIdx.x + u * 256;
+      const int j = bt & ((1 << hl) - 1);
+      i0[u] = ((bt >> hl) << (hl + 1)) + j;
+      if (bt < tile / 2) { w[u] = tw[((long)j << s) << tw_shift]; a[u] = sh[i0[u]]; b[u] = sh[i0[u] + (1 << hl)]; }
+    }
+#pragma unroll
+    for (int u = 0; u < BPT; u++) {
+      if (threadIdx.x + u * 256 >= tile / 2) continue;
+      const int i1 = i0[u] + (1 << hl);
+      if (!inverse) { sh[i0[u]] = fp_add(a[u], b[u]); sh[i1] = fp_mul(fp_sub(a[u], b[u]), w[u]); }
+      else { const Fr bw = fp_mul(b[u], w[u]); sh[i0[u]] = fp_add(a[u], bw); sh[i1] = fp_sub(a[u], bw); }
     }
     __syncthreads();
   }
@@ -154,22 +162,22 @@ static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool 
   const long n = 1L << log2n;
   const int nglobal = log2n - tile_log;
   const size_t lds = sizeof(Fr) << tile_log;
+  // the wide stages in passes of at most WIDE_MAX_STAGES, as even as possible (10 -> 5 + 5, 12 -> 6 + 6, 13 -> 5 + 4 + 4)
+  constexpr int WIDE_MAX_STAGES = 6;
+  const int passes = (nglobal + WIDE_MAX_STAGES - 1) / WIDE_MAX_STAGES;
+  int first[8], count[8];
+  for (int p = 0, s = 0; p < passes; p++) { count[p] = nglobal / passes + (p < nglobal % passes ? 1 : 0); first[p] = s; s += count[p]; }
+  auto wide = [&](int p, const Fr* scale) {
+    const long items = (1L << first[p]) << (log2n - first[p] - count[p] - (WIDE_ELEMS_LOG - count[p]));
+    LAUNCH(k_ntt_wide, (int)std::min<long>(items, 4L * WIDE_GRID), 256, 0, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);
+  };
   if (!inverse) {
-    int s = 0;
-    for (; s + 1 < nglobal; s += 2) LAUNCH(k_ntt_stage2, wide_grid(n / 4), 256, 0, st, d, table, log2n, s, tw_shift, 0);
-    for (; s < nglobal; s++) LAUNCH(k_ntt_stage, wide_grid(n / 2), 256, 0, st, d, table, log2n, s, tw_shift, 0);
+    for (int p = 0; p < passes; p++) wide(p, nullptr);
     LAUNCH(k_ntt_local, (int)std::min<long>(n >> tile_log, WIDE_GRID), 256, lds, st, d, table, log2n, tile_log, tw_shift, 0, (const Fr*)nullptr);
   } else {
     const Fr* ninv = tw.ninv.as<Fr>() + log2n;
-    if (nglobal == 0) {
-      LAUNCH(k_ntt_local, (int)std::min<long>(n >> tile_log, WIDE_GRID), 256, lds, st, d, table, log2n, tile_log, tw_shift, 1, ninv);
-    } else {
-      LAUNCH(k_ntt_local, (int)std::min<long>(n >> tile_log, WIDE_GRID), 256, lds, st, d, table, log2n, tile_log, tw_shift, 1, (const Fr*)nullptr);
-      int s = nglobal - 1;
-      if (nglobal & 1) { LAUNCH(k_ntt_stage, wide_grid(n / 2), 256, 0, st, d, table, log2n, s, tw_shift, 1); s--; }   // the odd one first: the forward pass did it last
-      for (; s >= 1; s -= 2) LAUNCH(k_ntt_stage2, wide_grid(n / 4), 256, 0, st, d, table, log2n, s - 1, tw_shift, 1);
-      fr_scale_enqueue(st, d, n, ninv);
-    }
+    LAUNCH(k_ntt_local, (int)std::min<long>(n >> tile_log, WIDE_GRID), 256, lds, st, d, table, log2n, tile_log, tw_shift, 1, nglobal == 0 ? ninv : (const Fr*)nullptr);
+    for (int p = passes - 1; p >= 0; p--) wide(p, p == 0 ? ninv : nullptr);      // the last pass also scales by 1/n
   }
 }
 

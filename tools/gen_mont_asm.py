@@ -490,13 +490,14 @@ def cxx(name: str, cls: str, N: int, p: int, lazy: bool = False, kind: str = "mu
     return "\n".join(lines)
 
 
-def addsub_cxx(fname: str, cls: str, N: int, sub: bool) -> str:
+def addsub_cxx(fname: str, cls: str, N: int, sub: bool, const: str = "p2") -> str:
     """r = a -/+ b as one asm block: two interleaved carry chains and a select.  Operands and result live in [0, 2p)
     (see the lazy Montgomery product), so the correction constant is 2p:
     sub:  d = a - b (borrow chain A), e = d + 2p (carry chain B, one link behind), r = borrow ? e : d
     add:  d = a + b (carry chain A),  e = d - 2p (borrow chain B),                 r = borrow(e) ? d : e
     Chain A carries in an SGPR pair, chain B in VCC; the v_mov that loads p_j is the filler that keeps two
-    instructions between a carry write and its read (gfx950 VALU-carry hazard)."""
+    instructions between a carry write and its read (gfx950 VALU-carry hazard).
+    const = "p": the same block for values kept canonical (Fr: operands and result in [0, p), the correction constant is p)."""
     opA0, opA = ("v_sub_co_u32_e64", "v_subb_co_u32_e64") if sub else ("v_add_co_u32_e64", "v_addc_co_u32_e64")
     opB0, opB = ("v_add_co_u32_e32", "v_addc_co_u32_e32") if sub else ("v_sub_co_u32_e32", "v_subb_co_u32_e32")
     # operand numbering: outputs r[0..N) = %0.., d[0..N) early-clobber temps, pv temps, cA (sgpr pair), then inputs a, b, p literals via "s"
@@ -530,7 +531,7 @@ def addsub_cxx(fname: str, cls: str, N: int, sub: bool) -> str:
         else:     # add: carry-out of A cannot happen (a + b < 2^(32N)); borrow of chain B (vcc) set -> d < p -> take d
             L.append(f"v_cndmask_b32_e32 {R_(j)}, {R_(j)}, {D_(j)}, vcc")
     outs = [f'"=&v"(r.l[{j}])' for j in range(N)] + [f'"=&v"(d{j})' for j in range(N)] + [f'"=&v"(p{j})' for j in range(N)] + ['"=&s"(ca)']
-    ins = [f'"v"(a.l[{j}])' for j in range(N)] + [f'"v"(b.l[{j}])' for j in range(N)] + [f'"s"(P::p2({j}))' for j in range(N)]
+    ins = [f'"v"(a.l[{j}])' for j in range(N)] + [f'"v"(b.l[{j}])' for j in range(N)] + [f'"s"(P::{const}({j}))' for j in range(N)]
     body = "\\n\\t".join(L)
     decl = " ".join(f"uint32_t d{j}, p{j};" for j in range(N))
     return f"""template <class P> __device__ __forceinline__ {cls} {fname}(const {cls}& a, const {cls}& b) {{
@@ -571,6 +572,8 @@ def render() -> str:
            "",
            addsub_cxx("sonic_fq_sub_asm", "Fp<P>", 12, True),
            addsub_cxx("sonic_fq_add_asm", "Fp<P>", 12, False),
+           addsub_cxx("sonic_fr_sub_asm", "Fp<P>", 8, True, const="p"),
+           addsub_cxx("sonic_fr_add_asm", "Fp<P>", 8, False, const="p"),
            "}  // namespace sonic",
            "#endif", ""]
     return "\n".join(out)
