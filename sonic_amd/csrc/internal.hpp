@@ -59,7 +59,7 @@ void srs_generate(hipStream_t st, sonic_srs* s, const Fr& x_std, const Fr& alpha
 // inverse: bit-reversed -> natural, scaled by 1/n.
 struct NttTables {
   int log2n = 0;
-  DevBuf fwd, inv;    // n/2 twiddles each: w^k, w^-k (Montgomery)
+  DevBuf fwd, inv;    // stage-major twiddles, 2^log2n entries each: [2^L - 2^(L-s) + j] = w^(+-j 2^s), j < 2^(L-1-s) (Montgomery; ntt.hip)
   DevBuf ninv;        // (2^k)^-1, k = 0..32
   void ensure(hipStream_t st, int log2n);
 };

@@ -34,6 +34,22 @@ __global__ __launch_bounds__(256) void k_ntt_twiddles(Fr* __restrict__ tw, long 
   for (int j = 0; j < 16 && k0 + j < half; j++) { tw[k0 + j] = p; p = fp_mul(p, w); }
 }
 
+// Stage-major twiddles: stage s of a 2^L-point transform reads w^(j 2^s), j < 2^(L-1-s).  Out of the plain table tw[k] = w^k those are
+// 2^s elements apart -- 32 KB between the twiddles of neighbouring lanes in the last wide stages: every lane its own cache line.
+// st[off(s) + j] = w^(j 2^s) with off(s) = 2^L - 2^(L-s) puts every stage's twiddles side by side (twice the memory: 2^L entries).
+// A 2^m-point transform inside a table built for 2^L reads stage s + (L - m): same layout, shifted.
+__global__ __launch_bounds__(256) void k_ntt_stage_major(const Fr* __restrict__ tw, Fr* __restrict__ st, int L) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;             // position in st: i = off(s) + j
+  const long N = 1L << L;
+  if (i >= N - 1) return;
+  // s = number of leading ones of i read as an L-bit number: off(s) <= i < off(s + 1)
+  int s = 0;
+  while (i >= N - (N >> (s + 1))) s++;
+  const long j = i - (N - (N >> s));
+  st[i] = tw[j << s];
+}
+__device__ __forceinline__ long stage_off(int L, int s) { return (1L << L) - (1L << (L - s)); }
+
 // The streaming kernels below run grid-stride over a capped grid (WIDE_GRID workgroups).  Launched beside a bucket accumulation,
 // which holds every wave slot with long-lived waves, a kernel gets a slot only when an accumulation workgroup retires: with one
 // short workgroup per 256 elements a 2^23-point stage needed 8192 such grants and took 36 ms instead of 0.15 ms; a few hundred
@@ -69,7 +85,7 @@ __global__ __launch_bounds__(256) void k_ntt_wide(Fr* __restrict__ d, const Fr* 
         const int k = ((kp >> hb) << (hb + 1)) | (kp & ((1 << hb) - 1));         // row with bit hb clear
         const int e0 = (k << lc) | c, e1 = e0 + (1 << (hb + lc));
         const long j = (((long)(k & ((1 << hb) - 1)) << lstride) + (cb << lc) + c) & ((1L << lhalf) - 1);
-        const Fr w = tw[(j << s) << tw_shift];
+        const Fr w = tw[stage_off(log2n + tw_shift, s + tw_shift) + j];
         const Fr a = sh[e0], b = sh[e1];
         if (!inverse) { sh[e0] = fp_add(a, b); sh[e1] = fp_mul(fp_sub(a, b), w); }
         else { const Fr bw = fp_mul(b, w); sh[e0] = fp_add(a, bw); sh[e1] = fp_sub(a, bw); }
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256) void k_ntt_local(Fr* __restrict__ d, const Fr*
       const int bt = threadIdx.x + u * 256;
       const int j = bt & ((1 << hl) - 1);
       i0[u] = ((bt >> hl) << (hl + 1)) + j;
-      if (bt < tile / 2) { w[u] = tw[((long)j << s) << tw_shift]; a[u] = sh[i0[u]]; b[u] = sh[i0[u] + (1 << hl)]; }
+      if (bt < tile / 2) { w[u] = tw[stage_off(log2n + tw_shift, s + tw_shift) + j]; a[u] = sh[i0[u]]; b[u] = sh[i0[u] + (1 << hl)]; }
     }
 #pragma unroll
     for (int u = 0; u < BPT; u++) {
@@ -146,10 +162,14 @@ void NttTables::ensure(hipStream_t st, int need) {
   if (need <= log2n) return;
   HIP_OK(hipStreamSynchronize(st));   // earlier launches may still read the old tables
   long half = 1L << (need - 1);
-  fwd.alloc(sizeof(Fr) * half);
-  inv.alloc(sizeof(Fr) * half);
-  LAUNCH(k_ntt_twiddles, ceil_div(ceil_div(half, 16), 256), 256, 0, st, fwd.as<Fr>(), half, need, 0);
-  LAUNCH(k_ntt_twiddles, ceil_div(ceil_div(half, 16), 256), 256, 0, st, inv.as<Fr>(), half, need, 1);
+  DevBuf plain(sizeof(Fr) * half);
+  fwd.alloc(sizeof(Fr) * 2 * half);
+  inv.alloc(sizeof(Fr) * 2 * half);
+  for (int dir = 0; dir < 2; dir++) {
+    LAUNCH(k_ntt_twiddles, ceil_div(ceil_div(half, 16), 256), 256, 0, st, plain.as<Fr>(), half, need, dir);
+    LAUNCH(k_ntt_stage_major, ceil_div(2 * half, 256), 256, 0, st, (const Fr*)plain.as<Fr>(), (dir ? inv : fwd).as<Fr>(), need);
+  }
+  HIP_OK(hipStreamSynchronize(st));       // `plain` goes out of scope
   if (!ninv.p) { ninv.alloc(sizeof(Fr) * 33); LAUNCH(k_fr_inv_pow2, 1, 64, 0, st, ninv.as<Fr>()); }
   log2n = need;
 }
