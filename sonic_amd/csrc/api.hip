@@ -5,6 +5,7 @@
 #include <vector>
 #include <memory>
 #include "internal.hpp"
+#include "endo.hpp"
 #include "g2.hpp"
 #include "srs_file.hpp"
 
@@ -176,6 +177,9 @@ struct sonic_srs {
   // basis b, window table w, exponent e  ->  tab[b][w * (2d+1) + e + d] = 2^(msm_even_shift(tab_W, w)) * g^{(alpha^b) x^e}
   // (w = 0 is the basis itself; tab_W = 1 when the window tables are switched off)
   int tab_c = 0, tab_W = 1;
+  // endomorphism tables (endo.hpp): tab_W windows over 130 bits instead of 255 -- 7 tables instead of 13 at c = 19 / 20 -- for SRS
+  // sizes whose full tables do not fit; every MSM then runs as two half-scalar MSMs (msm_enqueue_batch)
+  bool tab_endo = false;
   DevBuf g, ga;
   // verifier half: generated on first use from the trapdoor SRS.new was given -- which is wiped as soon as that has
   // happened -- or attached by sonic_srs_set_g2_points / read from a version-2 file
@@ -197,6 +201,7 @@ PointArray srs_basis(const sonic_srs* s, int b) { return s->basis(b); }
 int64_t srs_d(const sonic_srs* s) { return s->d; }
 int srs_tab_c(const sonic_srs* s) { return s->tab_c; }
 int srs_tab_W(const sonic_srs* s) { return s->tab_W; }
+bool srs_tab_endo(const sonic_srs* s) { return s->tab_endo; }
 
 // Window tables trade HBM capacity (288 GB) for work: W x the SRS size buys one shared bucket set per MSM.
 // c grows with d (MSM sizes are a fraction of d); off with SONIC_MSM_TABLES=0 or when memory is short.
@@ -213,13 +218,22 @@ sonic_srs* srs_alloc(int64_t d) {
   if (c < 9) c = 9;
   // W windows of even width (msm.hpp): the widest is ceil(255 / W) <= c
   int W = (255 + c - 1) / c;
-  c = (255 + W - 1) / W;
+  const int c_full = (255 + W - 1) / W;
   const char* env = getenv("SONIC_MSM_TABLES");
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  const size_t need = 2 * n * (size_t)SONIC_SRS_POINT_BYTES * (size_t)W;
-  if ((env && atoi(env) == 0) || need > free_b / 2) { c = 0; W = 1; }
-  s->tab_c = c; s->tab_W = W;
+  const size_t per_table = 2 * n * (size_t)SONIC_SRS_POINT_BYTES;
+  // endomorphism tables: windows over 130 bits -- half as many -- when the full set does not fit half of the free memory (or on
+  // request: SONIC_MSM_ENDO=1, tests); one more addition per term and window-pair than the full tables, no tables at all costs 2.5x
+  const int W_endo = (ENDO_BITS + c - 1) / c;
+  const char* eenv = getenv("SONIC_MSM_ENDO");
+  bool endo = false;
+  if (env && atoi(env) == 0) { c = 0; W = 1; }
+  else if ((eenv && atoi(eenv) == 1) || (per_table * (size_t)W > free_b / 2 && !(eenv && atoi(eenv) == 0))) {
+    if (per_table * (size_t)W_endo <= free_b / 2) { endo = true; W = W_endo; c = (ENDO_BITS + W - 1) / W; }
+    else { c = 0; W = 1; }
+  } else c = c_full;
+  s->tab_c = c; s->tab_W = W; s->tab_endo = endo;
   s->g.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
   s->ga.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
   return s;
@@ -234,7 +248,7 @@ void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std) { s->h
 // even when the SRS has tables, and 2^31 terms are refused (msm_enqueue_batch, sonic_msm_plan).
 MsmPlan srs_msm_plan(const sonic_srs* s, long n) {
   if (s->tab_W > 1 && s->tab_W <= MSM_TABLE_MAX_WINDOWS && n < MSM_TABLE_MAX_TERMS && msm_window_override() == 0 && n >= (1L << (s->tab_c - 1)) / 16)
-    return msm_plan_tables(n > 0 ? n : 1, s->tab_c, s->tab_W, 2 * s->d + 1);
+    return msm_plan_tables(n > 0 ? n : 1, s->tab_c, s->tab_W, 2 * s->d + 1, s->tab_endo);
   return msm_plan(n > 0 ? n : 1);
 }
 }  // namespace sonic
@@ -632,7 +646,7 @@ int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, 
 // term-range shard repeats in full on every rank -- is divided by the number of ranks this way.
 int sonic_msm_exchange_layout(const sonic_srs_t* srs, int world, int64_t* n_buckets, int64_t* slice_len) {
   if (!srs || world < 1 || !n_buckets || !slice_len) return SONIC_ERR_INVALID_ARG;
-  if (srs->tab_W <= 1) { set_error("bucket exchange needs the window tables of the SRS (one shared bucket set per MSM)"); return SONIC_ERR_INVALID_ARG; }
+  if (srs->tab_W <= 1 || srs->tab_endo) { set_error("bucket exchange needs the full window tables of the SRS (one shared bucket set per MSM)"); return SONIC_ERR_INVALID_ARG; }
   const int64_t NB = 1LL << (srs->tab_c - 1);
   int64_t S = (NB + world - 1) / world;
   S = (S + MSM_SLICE_QUANTUM - 1) / MSM_SLICE_QUANTUM * MSM_SLICE_QUANTUM;
@@ -646,7 +660,7 @@ int sonic_msm_accumulate_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
   API_BEGIN
   if (!l || !srs || n < 0 || (n > 0 && !d_scalars) || (basis != 0 && basis != 1) || !d_buckets) return SONIC_ERR_INVALID_ARG;
   if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
-  if (srs->tab_W <= 1) { set_error("sonic_msm_accumulate_dev needs the window tables of the SRS"); return SONIC_ERR_INVALID_ARG; }
+  if (srs->tab_W <= 1 || srs->tab_endo) { set_error("sonic_msm_accumulate_dev needs the full window tables of the SRS"); return SONIC_ERR_INVALID_ARG; }
   const int64_t NB = 1LL << (srs->tab_c - 1);
   if (capacity < NB) { set_error("sonic_msm_accumulate_dev: room for %ld buckets, the plan has %ld", (long)capacity, (long)NB); return SONIC_ERR_INVALID_ARG; }
   std::lock_guard<std::mutex> g(l->mu);
@@ -695,7 +709,7 @@ int sonic_g1_sum_dev_partials(const uint8_t* blobs, int k, uint8_t out_g1[96]) {
   std::unique_ptr<MsmSlot> s(new MsmSlot());
   for (int i = 0; i < k; i++) {
     memcpy(s.get(), blobs + sizeof(MsmSlot) * (size_t)i, sizeof(MsmSlot));
-    if (s->W < 0 || s->W > MSM_MAX_WINDOWS || (s->pad1 == 1 && s->W >= MSM_MAX_WINDOWS) || s->c < 0 || s->c > 32) { set_error("sonic_g1_sum_dev_partials: blob %d is not a device-side MSM result", i); return SONIC_ERR_INVALID_ARG; }
+    if (s->W < 0 || s->W > MSM_MAX_WINDOWS || (s->pad1 == 1 && s->W >= MSM_MAX_WINDOWS) || (s->pad1 == 2 && s->W >= MSM_MAX_WINDOWS - MSM_ENDO_SLOT_OFFSET) || s->pad1 < 0 || s->pad1 > 2 || s->c < 0 || s->c > 32) { set_error("sonic_g1_sum_dev_partials: blob %d is not a device-side MSM result", i); return SONIC_ERR_INVALID_ARG; }
     acc = g1_add(acc, msm_finish_host(*s));
   }
   g1_canonical_bytes_host(acc, out_g1);

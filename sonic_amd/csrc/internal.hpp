@@ -42,6 +42,7 @@ void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArra
                   uint8_t* out96, uint8_t* out_partial192);
 int srs_tab_c(const sonic_srs* s);
 int srs_tab_W(const sonic_srs* s);
+bool srs_tab_endo(const sonic_srs* s);
 MsmPlan srs_msm_plan(const sonic_srs* s, long n);
 // fills window tables 1 .. W-1 of both bases from table 0 (srs.hip)
 void srs_build_tables(hipStream_t st, sonic_srs* s);

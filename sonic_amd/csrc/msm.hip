@@ -28,6 +28,7 @@
 #include <stdexcept>
 #include "msm.hpp"
 #include "g1_quad.hpp"
+#include "endo.hpp"
 
 namespace sonic {
 
@@ -101,9 +102,11 @@ MsmPlan msm_plan(long n, bool fold) {
 // Fixed-base plan over precomputed window tables (tab[w][i] = 2^(c w) P_i): every window feeds ONE shared
 // set of 2^(c-1) buckets, so there is one running-sum reduction instead of W and no Horner tail, and c can
 // grow (fewer windows => fewer point additions) without multiplying the bucket count by W.
-MsmPlan msm_plan_tables(long n, int c, int W, long table_stride) {
+MsmPlan msm_plan_tables(long n, int c, int W, long table_stride, bool endo) {
   MsmPlan p;
   p.fold = true;
+  p.endo = endo;
+  p.bits = endo ? ENDO_BITS : 255;
   p.c = c;
   p.W = W;
   p.Wb = 1;
@@ -161,6 +164,9 @@ __device__ __forceinline__ uint32_t size_class(uint32_t sz) { return 255u - (sz 
 // kernel-argument view of a batch (by value); tile0[j] = first pass-1 workgroup of job j
 struct MsmBatchDev {
   int k;
+  int bits;                              // what the even-width windows cover (255, or 130 for the halves of an endomorphism split)
+  int slot_off[MSM_MAX_JOBS];            // first entry of MsmSlot::win the job's sums go to (0; MSM_ENDO_SLOT_OFFSET for a second half)
+  int slot_form;                         // MsmSlot::pad1 of the jobs' slots: 1 bit sums, 2 endomorphism pair
   uint32_t tile0[MSM_MAX_JOBS + 1];
   const char* points[MSM_MAX_JOBS];
   uint32_t pt_stride;                    // bytes between the points of every job (PointArray)
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void k_part_hist(const MsmBatchDev batch, int 
     ds.init(sc, i, i < n, mont, fold);
     for (int w = 0; w < W; w++) {
       uint32_t sign;
-      const uint32_t d = ds.next(keystride ? c : msm_even_width(W, w), sign);       // shared buckets over tables: even widths
+      const uint32_t d = ds.next(keystride ? c : msm_even_width(W, w, batch.bits), sign);       // shared buckets over tables: even widths
       const uint32_t key = (uint32_t)w * keystride + d - 1;
       lds_take(h, d != 0, key >> PART_LOW_BITS);
     }
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
     ds.init(sc, i, i < n, mont, fold);
     for (int w = 0; w < W; w++) {
       uint32_t sign;
-      const uint32_t d = ds.next(keystride ? c : msm_even_width(W, w), sign);       // shared buckets over tables: even widths
+      const uint32_t d = ds.next(keystride ? c : msm_even_width(W, w, batch.bits), sign);       // shared buckets over tables: even widths
       const uint32_t key = (uint32_t)w * keystride + d - 1;
       const uint32_t pos = lds_take(cur, d != 0, key >> PART_LOW_BITS);
       if (d) {
@@ -763,12 +769,13 @@ __global__ __launch_bounds__(256, 2) void k_bucket_tree_levels(G1XYZZ* __restric
   if (final_L > 0) {
     __syncthreads();
     MsmSlot* slot = batch.slot[blockIdx.x];
+    const int off = batch.slot_off[blockIdx.x];
     if ((int)threadIdx.x <= final_L) {
       G1XYZZ r = Z[s0 + ((int)threadIdx.x == final_L ? 0 : (size_t)1 << threadIdx.x)];
       r.x = fp_canonical(r.x); r.y = fp_canonical(r.y); r.zz = fp_canonical(r.zz); r.zzz = fp_canonical(r.zzz);   // leaves the device (lazy range)
-      slot->win[threadIdx.x] = r;
+      slot->win[off + threadIdx.x] = r;
     }
-    if (threadIdx.x == 0) { slot->W = final_L; slot->c = 1; slot->pad0 = (int)tot_mul; slot->pad1 = 1; }
+    if (threadIdx.x == 0 && off == 0) { slot->W = final_L; slot->c = 1; slot->pad0 = (int)tot_mul; slot->pad1 = batch.slot_form; }
   }
 }
 
@@ -804,17 +811,22 @@ G1XYZZ msm_finish_host(const MsmSlot& s) {
   // ~20 us per window sum (0.3 ms per proof), so every window sum is copied out once before it is used
   const int W = s.W, c = s.c;
   G1XYZZ acc = G1XYZZ::inf();
-  if (s.pad1 == 1) {
-    // bit-sum form (k_bucket_tree_levels): sum_j 2^j win[j] + pad0 * win[W]
-    for (int w = W - 1; w >= 0; w--) {
-      G1XYZZ win;
-      memcpy(&win, &s.win[w], sizeof win);
-      acc = g1_add(g1_dbl(acc), win);
-    }
-    G1XYZZ tot;
-    memcpy(&tot, &s.win[W], sizeof tot);
-    const uint32_t mul = (uint32_t)s.pad0;
-    return g1_add(acc, mul == 1 ? tot : g1_mul_small(tot, mul));
+  if (s.pad1 == 1 || s.pad1 == 2) {
+    // bit-sum form (k_bucket_tree_levels): sum_j 2^j win[off + j] + pad0 * win[off + W]
+    auto bitsum = [&](int off) {
+      G1XYZZ a = G1XYZZ::inf();
+      for (int w = W - 1; w >= 0; w--) {
+        G1XYZZ win;
+        memcpy(&win, &s.win[off + w], sizeof win);
+        a = g1_add(g1_dbl(a), win);
+      }
+      G1XYZZ tot;
+      memcpy(&tot, &s.win[off + W], sizeof tot);
+      const uint32_t mul = (uint32_t)s.pad0;
+      return g1_add(a, mul == 1 ? tot : g1_mul_small(tot, mul));
+    };
+    if (s.pad1 == 1) return bitsum(0);
+    return g1_add(bitsum(0), g1_endo(bitsum(MSM_ENDO_SLOT_OFFSET)));         // endomorphism pair: sum(s1 P) + phi(sum(s2 P))
   }
   for (int w = W - 1; w >= 0; w--) {
     G1XYZZ win;
@@ -828,10 +840,48 @@ G1XYZZ msm_finish_host(const MsmSlot& s) {
 // ---------------------------------------------------------------------------------------------
 bool msm_can_batch(const MsmPlan& pl) { return pl.Wb == 1 && pl.NB >= (1 << PART_LOW_BITS); }
 
+// s -> (s mod lambda, s div lambda) for every scalar of a job (endo.hpp); standard form out, upper halves zero
+__global__ __launch_bounds__(256) void k_endo_split(const Fr* __restrict__ sc, long n, int mont, Fr* __restrict__ s1, Fr* __restrict__ s2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = sc[i];
+  if (mont) s = fp_from_mont(s);
+  Fr a, b;
+  endo_split(s, a, b);
+  s1[i] = a; s2[i] = b;
+}
+
 void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, const MsmJob* jobs, int k, bool scalars_mont, G1XYZZ* ext_buckets) {
   if (k < 1 || k > MSM_MAX_JOBS) throw std::runtime_error("msm_enqueue_batch: 1..MSM_MAX_JOBS jobs");
   if (ext_buckets && (k != 1 || pl.Wb != 1)) throw std::runtime_error("msm_enqueue_batch: bucket hand-off needs one job over a shared bucket set");
   if (k > 1 && !msm_can_batch(pl)) throw std::runtime_error("msm_enqueue_batch: plan cannot be batched");
+  MsmJob split_jobs[MSM_MAX_JOBS];
+  bool fold = pl.fold;
+  if (pl.endo) {
+    // every job becomes two device jobs over the same points: the halves s1, s2 of its scalars (endo.hpp); both sums land in the
+    // job's slot (the second at win[MSM_ENDO_SLOT_OFFSET ..]) and the host adds phi(second) to the first
+    if (ext_buckets) { set_error("the bucket hand-off of a bucket-sharded MSM needs the full window tables (this SRS holds endomorphism tables)"); throw HipFail{SONIC_ERR_INVALID_ARG}; }
+    if (2 * k > MSM_MAX_JOBS) {
+      const int h = MSM_MAX_JOBS / 2;
+      for (int j0 = 0; j0 < k; j0 += h) msm_enqueue_batch(st, ws, pl, jobs + j0, k - j0 < h ? k - j0 : h, scalars_mont, nullptr);
+      return;
+    }
+    long n_all = 0;
+    for (int j = 0; j < k; j++) n_all += jobs[j].n;
+    ws.endo_scalars.ensure(sizeof(Fr) * 2 * (size_t)(n_all > 0 ? n_all : 1));
+    Fr* halves = ws.endo_scalars.as<Fr>();
+    for (int j = 0; j < k; j++) {
+      Fr* s1 = halves; Fr* s2 = halves + jobs[j].n;
+      halves += 2 * jobs[j].n;
+      if (jobs[j].n > 0) LAUNCH(k_endo_split, ceil_div(jobs[j].n, 256), 256, 0, st, jobs[j].scalars, jobs[j].n, (int)scalars_mont, s1, s2);
+      split_jobs[2 * j] = MsmJob{jobs[j].points, s1, jobs[j].n, jobs[j].slot};
+      split_jobs[2 * j + 1] = MsmJob{jobs[j].points, s2, jobs[j].n, jobs[j].slot};
+    }
+    jobs = split_jobs;
+    k = 2 * k;
+    scalars_mont = false;
+    fold = false;             // the halves are non-negative and below 2^128: nothing to fold, no carry out of the 130 bits
+  }
   for (int j = 0; j < k; j++) {
     const bool tables = pl.table_stride != 0;
     if (jobs[j].n >= (tables ? MSM_TABLE_MAX_TERMS : MSM_MAX_TERMS) || (tables && pl.W > MSM_TABLE_MAX_WINDOWS) || pl.W > MSM_MAX_WINDOWS) {
@@ -843,6 +893,9 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   MsmBatchDev batch;
   memset(&batch, 0, sizeof batch);
   batch.k = k;
+  batch.bits = pl.bits;
+  batch.slot_form = pl.endo ? 2 : 1;
+  for (int j = 0; j < k; j++) batch.slot_off[j] = (pl.endo && (j & 1)) ? MSM_ENDO_SLOT_OFFSET : 0;
   batch.pt_stride = jobs[0].points.stride;
   long n_total = 0;
   for (int j = 0; j < k; j++) {
@@ -871,13 +924,13 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     const int ht = ceil_div((long)hn + 1, 2048);
     uint32_t* total = tiles + ht;
     const uint32_t pgrid = pblk < PASS1_GRID ? pblk : PASS1_GRID;
-    LAUNCH(k_part_hist, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, hist);
+    LAUNCH(k_part_hist, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, hist);
     // (a single-launch chained scan with decoupled look-back was measured in round 3 and is not kept: 0.080 ms against 0.052 ms for
     // these three launches on an empty chip, and no difference inside prove())
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
-    LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)pl.fold, P, (const uint32_t*)hbase,
+    LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hbase,
            ws.digits.as<uint2>());
     const uint32_t nparts = (uint32_t)k * (uint32_t)P;
     LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, 256, 0, st, batch, (const uint2*)ws.digits.as<uint2>(),
@@ -896,7 +949,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
   if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)
   const int sets = k * pl.Wb;
-  if (g_use_tree && pl.tree && pl.Wb == 1 && pl.NB >= 4) {
+  if ((g_use_tree && pl.tree && pl.Wb == 1 && pl.NB >= 4) || pl.endo) {
     int L = 0;
     while ((1 << L) < pl.NB) L++;
     bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), sets, L, 1u, batch);
@@ -953,6 +1006,8 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
     MsmBatchDev b1;
     memset(&b1, 0, sizeof b1);
     b1.k = 1;
+    b1.bits = 255;
+    b1.slot_form = 1;
     b1.slot[0] = d_slot;
     bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), 1, L, (uint32_t)(base + 1), b1);
     return;

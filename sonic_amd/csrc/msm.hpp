@@ -10,8 +10,9 @@ namespace sonic {
 // most one bit (the first 255 % W windows are the wide ones).  With W = 13: eight 20-bit and five 19-bit windows.  A uniform
 // width c would leave the top window 254 - (W-1) c bits: its 2^14 buckets then hold N / 2^14 extra terms each, the walks over
 // them are 3x longer than the rest and set the duration of the whole accumulation (average residency 1.5 of 2 waves per SIMD).
-HD int msm_even_width(int W, int w) { return 255 / W + (w < 255 % W ? 1 : 0); }
-HD int msm_even_shift(int W, int w) { const int base = 255 / W, extra = 255 % W; return w * base + (w < extra ? w : extra); }
+// `bits`: what the windows cover -- 255 for a whole (folded) scalar, ENDO_BITS = 130 for the halves of an endomorphism split (endo.hpp)
+HD int msm_even_width(int W, int w, int bits = 255) { return bits / W + (w < bits % W ? 1 : 0); }
+HD int msm_even_shift(int W, int w, int bits = 255) { const int base = bits / W, extra = bits % W; return w * base + (w < extra ? w : extra); }
 
 struct MsmPlan {
   int c;        // window bits
@@ -33,13 +34,17 @@ struct MsmPlan {
   // exposed -- a stand-alone MSM, the last group of a proof, a rank's few pieces of a shared proof -- the segments where it hides under
   // other groups' accumulation (profiles/r04_bucket_tree.txt).
   bool tree = true;
+  // endomorphism plan (endo.hpp): the tables hold W windows over 130 bits; every job runs as TWO device jobs over the same points,
+  // with the halves s1, s2 of its scalars, and the host adds phi(second sum) to the first.  Tree reduction only.
+  bool endo = false;
+  int bits = 255;
   // fold scalars s > (r-1)/2 into r - s on the negated point: valid iff r P = O.  Every SRS element is in the r-torsion;
   // caller-supplied points of sonic_msm_g1 only have to be on the curve (E(Fq) has cofactor points, e.g. (0, 2) of order 3),
   // and s P then means the literal multiple the reference's `mul` computes, so that entry point does not fold.
   bool fold;
 };
 MsmPlan msm_plan(long n, bool fold = true);
-MsmPlan msm_plan_tables(long n, int c, int W, long table_stride);
+MsmPlan msm_plan_tables(long n, int c, int W, long table_stride, bool endo = false);
 // Trade latency for work in the bucket running sums: K buckets per segment.  A standalone MSM wants the shortest
 // dependent chain (K = 8); inside prove() the reduction of one MSM hides under the accumulation of others, so fewer,
 // longer segments (fewer small scalar multiplications) cost less MAD issue overall.
@@ -55,7 +60,8 @@ constexpr long MSM_MAX_TERMS = 1L << 31;
 // Per-MSM hand-off between the bulk kernels and the (deferred, batched) tail: the per-window sums.
 // Two forms: W window sums of a c-bit Horner walk (per-window bucket sets; pad1 == 0), or -- shared bucket sets reduced by the
 // bit-sum butterfly, pad1 == 1 -- win[j] = sum of the buckets whose index has bit j set (j < W), win[W] = the sum of all buckets
-// and pad0 = its weight: the MSM is sum_j 2^j win[j] + pad0 win[W].  msm_finish_host folds either.
+// and pad0 = its weight: the MSM is sum_j 2^j win[j] + pad0 win[W].  pad1 == 2: an endomorphism pair -- the same form twice, the
+// second at win[32 ..], result = first + phi(second).  msm_finish_host folds all of them.
 struct MsmSlot {
   int W, c, pad0, pad1;
   G1XYZZ win[MSM_MAX_WINDOWS];
@@ -63,7 +69,7 @@ struct MsmSlot {
 bool msm_tree_reduction();
 
 struct MsmWorkspace {
-  DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, heavy_meta, heavy_items, heavy_partial;
+  DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, heavy_meta, heavy_items, heavy_partial, endo_scalars;
   // n = total terms over the k jobs of a batch
   void reserve(long n, const MsmPlan& pl, int k = 1);
 };
@@ -78,6 +84,7 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArray
 // latency-bound phases (running sums, trees, sort passes) run k times wider instead of k times in a row.  The jobs may
 // differ in size, points and scalars; they share the plan (c, W, table stride).  k <= MSM_MAX_JOBS.
 constexpr int MSM_MAX_JOBS = 8;
+constexpr int MSM_ENDO_SLOT_OFFSET = 32;      // where the second half of an endomorphism pair sits in MsmSlot::win
 struct MsmJob { PointArray points; const Fr* scalars; long n; MsmSlot* slot; };      // the jobs of a batch share the point stride
 bool msm_can_batch(const MsmPlan& pl);
 // ext_buckets (k == 1, shared-bucket plan): the chain stops after the accumulation and leaves the NB bucket sums there

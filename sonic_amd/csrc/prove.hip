@@ -767,7 +767,7 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
     };
     bool folded = true;
     const int KS = K + (p->prepared ? (int)Q : 0);          // the C_q halves of the S_j are folded by tail() too
-    for (int i = 0; i < KS; i++) folded = folded && (hs[i].W == 1 || hs[i].pad1 == 1);
+    for (int i = 0; i < KS; i++) folded = folded && (hs[i].W == 1 || hs[i].pad1 != 0);
     if (folded) {
       for (int i = 0; i < K; i++) tail(i);
     } else {
@@ -1120,7 +1120,7 @@ int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, con
   {
     std::vector<G1XYZZ> sums((size_t)K);
     bool folded = true;
-    for (long i = 0; i < K; i++) folded = folded && (hs[i].W == 1 || hs[i].pad1 == 1);
+    for (long i = 0; i < K; i++) folded = folded && (hs[i].W == 1 || hs[i].pad1 != 0);
     if (folded) {
       for (long i = 0; i < K; i++) sums[i] = msm_finish_host(hs[i]);
     } else {

@@ -5,6 +5,7 @@
 // doing 2 x 32 table additions into XYZZ accumulators, then a batched (Montgomery-trick)
 // normalisation to affine, 64 points per inversion.
 #include "internal.hpp"
+#include "endo.hpp"
 
 namespace sonic {
 
@@ -102,7 +103,7 @@ void srs_build_tables(hipStream_t st, sonic_srs* s) {
       for (long base = 0; base < n; base += SLAB) {
         const long m = n - base < SLAB ? n - base : SLAB;
         LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (PointArray)(tab + (long)((size_t)(w - 1) * n + base)), x.as<G1XYZZ>(), m,
-               msm_even_width(W, w - 1));
+               msm_even_width(W, w - 1, srs_tab_endo(s) ? ENDO_BITS : 255));
         LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), tab + (size_t)w * n + base, pref.as<Fq>(), m);
       }
     }

@@ -2,6 +2,7 @@
 // The same headers are compiled by hipcc for gfx950; this only exercises their logic on the host.
 #include <string.h>
 #include "../../sonic_amd/csrc/g1.hpp"
+#include "../../sonic_amd/csrc/endo.hpp"
 using namespace sonic;
 
 template <class F> static F load(const uint8_t* b) { F a; memcpy(a.l, b, sizeof a.l); return a; }
@@ -39,6 +40,16 @@ int host_g1_op(int op, const uint8_t* a, const uint8_t* b, uint32_t k, uint8_t* 
     default: return -1;
   }
   store_pt(out, g1_to_affine(r)); return 0;
+}
+// the endomorphism split s = s1 + lambda s2 (endo.hpp): standard-form bytes in and out
+int host_endo_split(const uint8_t* s, uint8_t* s1, uint8_t* s2) {
+  Fr a, b;
+  endo_split(load<Fr>(s), a, b);
+  store(s1, a); store(s2, b); return 0;
+}
+// phi(P) = (beta x, y), through the XYZZ form with a non-trivial ZZ (2P)
+int host_endo_phi(const uint8_t* a, uint8_t* out) {
+  store_pt(out, g1_to_affine(g1_endo(g1_dbl_affine(load_pt(a))))); return 0;
 }
 int host_gen(uint8_t* out) { G1Affine g; uint32_t gx[12] = G1_GEN_X_MONT, gy[12] = G1_GEN_Y_MONT;
   memcpy(g.x.l, gx, 48); memcpy(g.y.l, gy, 48); store_pt(out, g); return 0; }

@@ -59,3 +59,24 @@ def test_g1_formulas(L, ref):
             assert gop(4, p, q) == p
         for k in [0, 1, 2, 3, 17, 65535, 32768]:
             assert gop(3, p, p, k) == (ref.g1_mul(p, 3 * k) if p else None)
+
+
+def test_endomorphism_split_and_phi(L, ref):
+    """endo.hpp on the host: s = s1 + lambda s2 with both halves below 2^128 for edge and random scalars, and phi(P) = (beta x, y)
+    equals lambda P (python big integers / the literal restatement's group law)"""
+    z = 0xd201000000010000
+    lam = z * z - 1
+    assert (lam * lam + lam + 1) % ref.R == 0
+    rng = random.Random(8)
+    vals = [0, 1, lam - 1, lam, lam + 1, 2 * lam - 1, 2 * lam, ref.R - 1, ref.R - lam, (ref.R - 1) // 2, lam * lam, lam * (lam + 1) - 1,
+            (1 << 128) - 1, 1 << 128, (1 << 254) + 12345] + [rng.randrange(ref.R) for _ in range(3000)]
+    for s in vals:
+        a, b = C.create_string_buffer(32), C.create_string_buffer(32)
+        assert L.host_endo_split(s.to_bytes(32, "little"), a, b) == 0
+        s1, s2 = int.from_bytes(a.raw, "little"), int.from_bytes(b.raw, "little")
+        assert (s1, s2) == (s % lam, s // lam) and s1 < 1 << 128 and s2 < 1 << 128, hex(s)
+    for k in (1, 2, 12345, rng.randrange(1, ref.R)):
+        P = ref.g1_mul(ref.G1_GEN, k)
+        out = C.create_string_buffer(96)
+        assert L.host_endo_phi(ref.g1_to_bytes(P), out) == 0
+        assert ref.g1_from_bytes(out.raw) == ref.g1_mul(P, 2 * lam % ref.R)        # phi(2P) = lambda 2P
