@@ -24,9 +24,11 @@ struct SlotShare { uint32_t lo = 0, hi = 0; };
 enum { POLY_R1 = 1, POLY_SY0 = 2, POLY_T = 4, POLY_SU = 8, POLY_SYJ0 = 16 /* << j, j < 27; beyond that all j share one bit */ };
 
 struct ShareCosts {
-  // term-equivalents; defaults measured on one MI355X at n = 2^20, Q = 2 (profiles/r04_prove_strong_emulated.txt)
-  double per_job_buckets = 3.0;     // x NB / W terms: the bucket reduction of one MSM piece
-  double r1 = 0.10, sy = 0.35, su = 0.45, tprod = 1.7;    // x n terms: build_r1, s(X,y), s(u,Y), the t(X,y) product incl. its operands
+  // term-equivalents; defaults from the least-squares fit of tools/prove_strong.py --fit on one MI355X at n = 2^20, Q = 2
+  // (profiles/r04_prove_strong_emulated.txt: 2.65 ms per n terms, t product 4.2 ms, everything else inside the noise -- the bucket
+  // reduction of a piece has cost next to nothing since it became a log-depth tree)
+  double per_job_buckets = 0.5;     // x NB / W terms: the bucket reduction of one MSM piece
+  double r1 = 0.02, sy = 0.05, su = 0.05, tprod = 1.6;    // x n terms: build_r1, s(X,y), s(u,Y), the t(X,y) product incl. its operands
   static double env(const char* name, double dflt) { const char* s = getenv(name); return s && *s ? atof(s) : dflt; }
   static ShareCosts from_env() {
     ShareCosts c;
