@@ -46,7 +46,7 @@ def test_endo_msm_matches_full_tables_and_oracle(sonic, orc, endo_env):
     edge = [0, 1, 2, LAM - 1, LAM, LAM + 1, 2 * LAM, R - 1, R - 2, R - LAM, (R - 1) // 2, (R + 1) // 2, LAM * LAM % R, (1 << 128) - 1, 1 << 128, 1 << 254]
     for n in (1, 3, len(edge), 700, 5000, 16000):
         sc = fr_bytes((edge + [pyr.randrange(R) for _ in range(n)])[:n]) if n <= 700 else rand_fr_array(np.random.default_rng(n), n)
-        for basis, e0 in ((0, -d), (1, 1), (0, d - n + 1)):
+        for basis, e0 in ((0, -d), (1, 1 if n < d else -d), (0, d - n + 1)):          # (basis 1 from -d crosses the empty slot e = 0)
             got = msm_g1_srs(srs_e, basis, e0, sc)
             assert got == msm_g1_srs(srs_f, basis, e0, sc) == orc.msm_srs(osrs, basis, e0, sc, 1, NCPU), (n, basis)
     # many equal scalars (heavy buckets) and all-zero scalars

@@ -133,10 +133,16 @@ def test_combine_synthetic_shares(world):
             sonic_amd.proof_from_shares(Q, shares[:-1] + [shares[0]], tr)
         assert e.value.code == 7
         # a piece that does not start where its neighbour ends
-        r_cut = next(r for r in range(world) if any(0 < lo < hi for lo, hi in plan[r][0]))
+        # (the plan may cut only between MSMs at this size: then shift the boundary of a whole piece instead)
+        r_cut = next((r for r in range(world) if any(0 < lo < hi for lo, hi in plan[r][0])), None)
         bad = [list(p) for p, _ in plan]
-        i_cut = next(i for i, (lo, hi) in enumerate(bad[r_cut]) if 0 < lo < hi)
-        bad[r_cut][i_cut] = (bad[r_cut][i_cut][0] + 1, bad[r_cut][i_cut][1])
+        if r_cut is None:
+            r_cut = 0
+            i_cut = next(i for i, (lo, hi) in enumerate(bad[0]) if hi > lo)
+            bad[r_cut][i_cut] = (bad[r_cut][i_cut][0], bad[r_cut][i_cut][1] - 1)
+        else:
+            i_cut = next(i for i, (lo, hi) in enumerate(bad[r_cut]) if 0 < lo < hi)
+            bad[r_cut][i_cut] = (bad[r_cut][i_cut][0] + 1, bad[r_cut][i_cut][1])
         with pytest.raises(_lib.SonicError) as e:
             sonic_amd.proof_from_shares(Q, [synth_share(want, Q, r, world, bad[r]) for r in range(world)], tr)
         assert e.value.code == 7 and "cover" in e.value.message
