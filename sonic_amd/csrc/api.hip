@@ -228,11 +228,12 @@ sonic_srs* srs_alloc(int64_t d) {
   const int W_endo = (ENDO_BITS + c - 1) / c;
   const char* eenv = getenv("SONIC_MSM_ENDO");
   bool endo = false;
+  const bool fits_full = per_table * (size_t)W <= free_b / 2, fits_endo = per_table * (size_t)W_endo <= free_b / 2;
+  const bool endo_forced = eenv && atoi(eenv) == 1, endo_off = eenv && atoi(eenv) == 0;
   if (env && atoi(env) == 0) { c = 0; W = 1; }
-  else if ((eenv && atoi(eenv) == 1) || (per_table * (size_t)W > free_b / 2 && !(eenv && atoi(eenv) == 0))) {
-    if (per_table * (size_t)W_endo <= free_b / 2) { endo = true; W = W_endo; c = (ENDO_BITS + W - 1) / W; }
-    else { c = 0; W = 1; }
-  } else c = c_full;
+  else if ((endo_forced || (!fits_full && !endo_off)) && fits_endo) { endo = true; W = W_endo; c = (ENDO_BITS + W - 1) / W; }
+  else if (fits_full && !endo_forced) c = c_full;
+  else { c = 0; W = 1; }
   s->tab_c = c; s->tab_W = W; s->tab_endo = endo;
   s->g.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
   s->ga.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
