@@ -304,6 +304,65 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
   }
 }
 
+// The same pass with its output STAGED in LDS (round 4).  The direct kernel above issues every record as its own 8-byte store to one of
+// 2048 partition cursors: 64 partial lines per wave store, 440 MB written for 109 MB of records (profiles/r03_pmc_msm.json).  Here the
+// workgroup first sorts its tile's records by partition inside LDS (the per-tile counts are the histogram's, so the local offsets are
+// a 2048-entry scan), then copies the sorted buffer out: consecutive lanes hold consecutive records of a run, and a run goes to
+// consecutive addresses.  LDS: records 8 B + partition id 2 B per (scalar, window) + two words per partition -- 148 KB at 13 windows
+// and 2048 partitions, one workgroup per CU (the pass is short); plans that need more than SORT_STAGE_MAX_LDS use the direct kernel.
+constexpr size_t SORT_STAGE_MAX_LDS = 156 * 1024;
+__global__ __launch_bounds__(256) void k_part_scatter_staged(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
+                                                             const uint32_t* __restrict__ hist, const uint32_t* __restrict__ base,
+                                                             uint2* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_stage[];
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem_stage);                 // [P]  running local cursor
+  uint32_t* delta = cur + P;                                                // [P]  global position - local position of the partition's run
+  uint2* recs = reinterpret_cast<uint2*>(delta + P);                        // [PART_TILE * W]
+  uint16_t* pid = reinterpret_cast<uint16_t*>(recs + (size_t)PART_TILE * W);  // [PART_TILE * W]
+  __shared__ uint32_t sc[256];
+  __shared__ uint32_t total_sh;
+  for (TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, batch.tile0[batch.k]); tw.cur < tw.end; tw.cur += tw.step) {
+    const uint32_t tile = tw.cur;
+    const int job = batch_job_of_tile(batch, tile);
+    const uint32_t blk = tile - batch.tile0[job], nblk = batch.tile0[job + 1] - batch.tile0[job];
+    const Fr* __restrict__ scal = batch.scalars[job];
+    const long n = batch.n[job];
+    const size_t row0 = (size_t)P * batch.tile0[job] + blk;
+    // local exclusive scan of this tile's per-partition counts: ceil(P / 256) consecutive partitions per thread
+    const int per = (P + 255) / 256;
+    uint32_t sum = 0;
+    for (int k = 0; k < per; k++) { const int t = threadIdx.x * per + k; if (t < P) sum += hist[row0 + (size_t)t * nblk]; }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan_256(sum, sc, &tot);
+    for (int k = 0; k < per; k++) {
+      const int t = threadIdx.x * per + k;
+      if (t < P) { cur[t] = ex; delta[t] = base[row0 + (size_t)t * nblk] - ex; ex += hist[row0 + (size_t)t * nblk]; }
+    }
+    if (threadIdx.x == 0) total_sh = tot;
+    __syncthreads();
+    for (int k = 0; k < PART_TILE / 256; k++) {
+      const long i = (long)blk * PART_TILE + k * 256 + threadIdx.x;
+      DigitStream ds;
+      ds.init(scal, i, i < n, mont, fold);
+      for (int w = 0; w < W; w++) {
+        uint32_t sign;
+        const uint32_t d = ds.next(keystride ? c : msm_even_width(W, w, batch.bits), sign);
+        const uint32_t key = (uint32_t)w * keystride + d - 1;
+        const uint32_t pr = key >> PART_LOW_BITS;
+        const uint32_t pos = lds_take(cur, d != 0, pr);
+        if (d) {
+          recs[pos] = make_uint2(key & ((1u << PART_LOW_BITS) - 1), (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (sign << 31));
+          pid[pos] = (uint16_t)pr;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t total = total_sh;
+    for (uint32_t i = threadIdx.x; i < total; i += 256) part[delta[pid[i]] + i] = recs[i];
+    __syncthreads();
+  }
+}
+
 // one (job, partition) per trip of a grid-stride loop (capped grid: see PART_SORT_GRID): bucket offsets, final placement, and the
 // size classes of the partition's buckets added to class_hist (k_border_place)
 __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, const uint2* __restrict__ part,
@@ -930,8 +989,17 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
-    LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hbase,
-           ws.digits.as<uint2>());
+    static const bool staged_on = !(getenv("SONIC_SORT_STAGED") && atoi(getenv("SONIC_SORT_STAGED")) == 0);
+    const size_t stage_lds = (size_t)P * 8 + (size_t)PART_TILE * pl.W * 10;
+    if (staged_on && stage_lds <= SORT_STAGE_MAX_LDS && P <= 65535) {
+      static bool attr_set = false;
+      if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_STAGE_MAX_LDS)); attr_set = true; }
+      LAUNCH(k_part_scatter_staged, pgrid, 256, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,
+             (const uint32_t*)hbase, ws.digits.as<uint2>());
+    } else {
+      LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hbase,
+             ws.digits.as<uint2>());
+    }
     const uint32_t nparts = (uint32_t)k * (uint32_t)P;
     LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, 256, 0, st, batch, (const uint2*)ws.digits.as<uint2>(),
            (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>(), hm->class_hist);
