@@ -365,9 +365,14 @@ __global__ __launch_bounds__(256) void k_part_scatter_staged(const MsmBatchDev b
 
 // one (job, partition) per trip of a grid-stride loop (capped grid: see PART_SORT_GRID): bucket offsets, final placement, and the
 // size classes of the partition's buckets added to class_hist (k_border_place)
+// stage_cap > 0 (round 4): a partition of at most stage_cap entries is placed in LDS first and copied out in order -- whole lines
+// instead of one 4-byte store per entry into a 26-KB window (323 MB written for 54 MB of entries before); larger partitions (the
+// protocol's heavy buckets, or MSMs much larger than the plan was sized for) take the direct path
 __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, const uint2* __restrict__ part,
                                                    const uint32_t* __restrict__ base, const uint32_t* __restrict__ total, size_t hn, int P,
-                                                   uint32_t jobstride, uint32_t* __restrict__ off, uint32_t* __restrict__ entries, uint32_t* __restrict__ class_hist) {
+                                                   uint32_t jobstride, uint32_t* __restrict__ off, uint32_t* __restrict__ entries, uint32_t* __restrict__ class_hist,
+                                                   uint32_t stage_cap) {
+  extern __shared__ uint32_t stage[];
   __shared__ uint32_t cnt[1 << PART_LOW_BITS];
   __shared__ uint32_t sc4[256];
   __shared__ uint32_t chist[256];
@@ -422,10 +427,14 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
       if (k0 + j >= trips) continue;
       const bool live = lo[j] != 0xffffffffu;
       const uint32_t pos = lds_take(cnt, live, lo[j] & ((1u << PART_LOW_BITS) - 1));
-      if (live) entries[beg + pos] = pay[j];
+      if (live) { if (span <= stage_cap) stage[pos] = pay[j]; else entries[beg + pos] = pay[j]; }
     }
   }
   __syncthreads();
+  if (span <= stage_cap) {
+    for (uint32_t i = threadIdx.x; i < span; i += 256) entries[beg + i] = stage[i];
+    __syncthreads();
+  }
   }
   const uint32_t c = chist[threadIdx.x];
   if (c) atomicAdd(&class_hist[threadIdx.x], c);
@@ -1001,8 +1010,19 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
              ws.digits.as<uint2>());
     }
     const uint32_t nparts = (uint32_t)k * (uint32_t)P;
-    LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, 256, 0, st, batch, (const uint2*)ws.digits.as<uint2>(),
-           (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>(), hm->class_hist);
+    // LDS stage of pass 2: room for 1.5x the mean partition of the largest job, a power of two between 2048 and 32768 entries (8 .. 128 KB)
+    uint32_t stage_cap = 0;
+    if (staged_on) {
+      long nmax = 0;
+      for (int j = 0; j < k; j++) nmax = jobs[j].n > nmax ? jobs[j].n : nmax;
+      const long mean = nmax * pl.W / (P > 0 ? P : 1);
+      stage_cap = 2048;
+      while (stage_cap < 32768 && (long)stage_cap < mean + mean / 2) stage_cap *= 2;
+      static bool attr2 = false;
+      if (!attr2) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4)); attr2 = true; }
+    }
+    LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, 256, (size_t)stage_cap * 4, st, batch, (const uint2*)ws.digits.as<uint2>(),
+           (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>(), hm->class_hist, stage_cap);
   }
   LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
          ws.order.as<uint32_t>());
