@@ -25,10 +25,10 @@ enum { POLY_R1 = 1, POLY_SY0 = 2, POLY_T = 4, POLY_SU = 8, POLY_SYJ0 = 16 /* << 
 
 struct ShareCosts {
   // term-equivalents; defaults from the least-squares fit of tools/prove_strong.py --fit on one MI355X at n = 2^20, Q = 2
-  // (profiles/r04_prove_strong_emulated.txt: 2.65 ms per n terms, t product 4.2 ms, everything else inside the noise -- the bucket
-  // reduction of a piece has cost next to nothing since it became a log-depth tree)
-  double per_job_buckets = 0.5;     // x NB / W terms: the bucket reduction of one MSM piece
-  double r1 = 0.02, sy = 0.05, su = 0.05, tprod = 1.6;    // x n terms: build_r1, s(X,y), s(u,Y), the t(X,y) product incl. its operands
+  // (profiles/r04_prove_strong_emulated.txt: 2.7 ms per n terms, ~0.2 ms per MSM piece whatever its size -- sort launches and the
+  // reduction tree of 2^19 buckets: 2 x NB / W terms -- the t product 4.2-5.0 ms, the other polynomials inside the noise)
+  double per_job_buckets = 2.0;     // x NB / W terms: the fixed part of one MSM piece
+  double r1 = 0.02, sy = 0.05, su = 0.05, tprod = 1.8;    // x n terms: build_r1, s(X,y), s(u,Y), the t(X,y) product incl. its operands
   static double env(const char* name, double dflt) { const char* s = getenv(name); return s && *s ? atof(s) : dflt; }
   static ShareCosts from_env() {
     ShareCosts c;

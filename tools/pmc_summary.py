@@ -30,7 +30,7 @@ def main():
            "msm_n": msm_n, "plan": {"window_bits": c, "windows": W, "bucket_sets": sets},
            "method": "MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 128-B requests "
                      "as 64 B, so reads are doubled"}
-    msm_kernels = ["k_part_hist", "k_part_scatter", "k_part_sort", "k_border_hist", "k_border_scatter", "k_border_place", "k_bucket_accum",
+    msm_kernels = ["k_part_hist", "k_part_scatter", "k_part_scatter_staged", "k_part_sort", "k_border_hist", "k_border_scatter", "k_border_place", "k_bucket_accum",
                    "k_heavy_accum", "k_heavy_finish", "k_bucket_segments", "k_group_sum", "k_window_sum", "k_bucket_tree_block", "k_bucket_tree_levels"]
     total = 0
     for k in msm_kernels:
