@@ -795,8 +795,9 @@ __device__ __forceinline__ void tree_item_quad(G1XYZZ* __restrict__ Z, size_t s0
 }
 // one level inside a workgroup: whole additions per lane while there are more additions than lanes, a quad per addition once at most
 // two rounds of quads cover the level (the chain, not the issue slots, is what the late levels wait for)
-__device__ __forceinline__ void tree_level(G1XYZZ* __restrict__ Z, size_t s0, int m, uint32_t items, bool quads_ok) {
-  if (quads_ok && items * 4 <= 2 * blockDim.x) {
+__device__ __forceinline__ void tree_level(G1XYZZ* __restrict__ Z, size_t s0, int m, uint32_t items, int quads) {
+  // quads = how many rounds of quads a level may take before whole additions per lane are preferred (0: never)
+  if (quads > 0 && items * 4 <= (uint32_t)quads * blockDim.x) {
     const int r = threadIdx.x & 3;
     for (uint32_t it = threadIdx.x >> 2; it < items; it += blockDim.x >> 2) tree_item_quad(Z, s0, m, it, r);
   } else {
@@ -809,18 +810,26 @@ __device__ __forceinline__ void tree_level(G1XYZZ* __restrict__ Z, size_t s0, in
 __global__ __launch_bounds__(256, 2) void k_bucket_tree_block(G1XYZZ* __restrict__ Z, int LB, int quads) {
   const size_t s0 = (size_t)blockIdx.x << LB;
   const uint32_t nthreads = 1u << (LB - 2);
-  if (threadIdx.x < nthreads) {
+  const bool leaf_in_registers = quads < 32;
+  if (!leaf_in_registers) {
+    tree_level(Z, s0, 1, 1u << (LB - 1), quads);
+    __syncthreads();
+    tree_level(Z, s0, 2, 2u << (LB - 2), quads);
+  } else if (threadIdx.x < nthreads) {
+    // (ordered so that at most two points are live beside an addition's own temporaries: with b1 and b3 held across the first three
+    // additions the kernel spilled 304 registers under its two-waves-per-SIMD bound)
     G1XYZZ* b = Z + s0 + 4 * (size_t)threadIdx.x;
-    const G1XYZZ b1 = b[1], b3 = b[3];
-    const G1XYZZ p01 = g1_add(b[0], b1);
-    const G1XYZZ p23 = g1_add(b[2], b3);
-    b[0] = g1_add(p01, p23);       // total
-    b[1] = g1_add(b1, b3);         // bit 0
-    b[2] = p23;                    // bit 1
+    const G1XYZZ odd = g1_add(b[1], b[3]);        // bit 0
+    const G1XYZZ p23 = g1_add(b[2], b[3]);        // bit 1
+    b[3] = odd;                                   // (b[3] is dead after this level: parked here until b[1] may be overwritten)
+    const G1XYZZ tot = g1_add(g1_add(b[0], b[1]), p23);
+    b[2] = p23;
+    b[0] = tot;
+    b[1] = b[3];
   }
   for (int m = 3; m <= LB; m++) {
     __syncthreads();
-    tree_level(Z, s0, m, (uint32_t)m << (LB - m), quads != 0);
+    tree_level(Z, s0, m, (uint32_t)m << (LB - m), quads);
   }
 }
 
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_tree_levels(G1XYZZ* __restric
   const size_t s0 = (size_t)blockIdx.x << span_log;
   for (int m = m_lo; m <= m_hi; m++) {
     if (m > m_lo) __syncthreads();
-    tree_level(Z, s0, m, (uint32_t)m << (span_log - m), quads != 0);
+    tree_level(Z, s0, m, (uint32_t)m << (span_log - m), quads);
   }
   if (final_L > 0) {
     __syncthreads();
@@ -855,7 +864,8 @@ static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint
   const int LB = L < TREE_BLOCK_LOG ? L : TREE_BLOCK_LOG;
   // (a first launch with 8 buckets per thread -- 11 additions in registers, blocks of 2048, one wave per SIMD -- measured the same:
   // 0.51 + 2 x 0.09 ms against 0.52 + 2 x 0.10 ms at 2^19 buckets)
-  static const int quads = getenv("SONIC_TREE_QUADS") ? atoi(getenv("SONIC_TREE_QUADS")) : 1;      // knob: 0 = whole additions per lane on every level
+  // knob: rounds of quads a level may take before whole additions per lane are preferred (0: never quads; >= 32: the leaf levels too)
+  static const int quads = getenv("SONIC_TREE_QUADS") ? atoi(getenv("SONIC_TREE_QUADS")) : 2;
   LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB, quads);
   int done = LB;
   if (L > done) {
