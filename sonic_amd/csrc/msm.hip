@@ -1008,11 +1008,17 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
-    static const bool staged_on = !(getenv("SONIC_SORT_STAGED") && atoi(getenv("SONIC_SORT_STAGED")) == 0);
+    // the LDS-staged passes need more dynamic LDS than the 64-KB default: asked for once per process (thread-safe static); a runtime that
+    // refuses keeps the direct kernels instead of failing the MSM
+    static const bool staged_on = [] {
+      if (getenv("SONIC_SORT_STAGED") && atoi(getenv("SONIC_SORT_STAGED")) == 0) return false;
+      const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_STAGE_MAX_LDS);
+      const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+      if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return false; }
+      return true;
+    }();
     const size_t stage_lds = (size_t)P * 8 + (size_t)PART_TILE * pl.W * 10;
     if (staged_on && stage_lds <= SORT_STAGE_MAX_LDS && P <= 65535) {
-      static bool attr_set = false;
-      if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_STAGE_MAX_LDS)); attr_set = true; }
       LAUNCH(k_part_scatter_staged, pgrid, 256, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,
              (const uint32_t*)hbase, ws.digits.as<uint2>());
     } else {
@@ -1028,8 +1034,6 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
       const long mean = nmax * pl.W / (P > 0 ? P : 1);
       stage_cap = 2048;
       while (stage_cap < 32768 && (long)stage_cap < mean + mean / 2) stage_cap *= 2;
-      static bool attr2 = false;
-      if (!attr2) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4)); attr2 = true; }
     }
     LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, 256, (size_t)stage_cap * 4, st, batch, (const uint2*)ws.digits.as<uint2>(),
            (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>(), hm->class_hist, stage_cap);
