@@ -262,6 +262,16 @@ __global__ __launch_bounds__(256) void k_chain_quad(G1XYZZ* out, const G1Affine*
   reinterpret_cast<Fq*>(&out[q])[r] = acc;
 }
 
+// NTT butterflies from registers only (no LDS, no memory): what the stages of ntt.hip could reach if nothing but issue counted
+__global__ __launch_bounds__(256) void k_butterfly(Fr* out, int iters) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  Fr a, b, w;
+  for (int i = 0; i < 8; i++) { a.l[i] = 0x9e3779b9u * (t + i + 1); b.l[i] = 0x85ebca6bu * (t + 3 * i + 7); w.l[i] = 0xc2b2ae35u * (t + 5 * i + 11); }
+  a.l[7] &= 0x3fffffffu; b.l[7] &= 0x3fffffffu; w.l[7] &= 0x3fffffffu;
+  for (int i = 0; i < iters; i++) { const Fr s = fp_add(a, b); b = fp_mul(fp_sub(a, b), w); a = s; }
+  out[t] = fp_add(a, b);
+}
+
 template <class F> float time_ms(F f, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -305,6 +315,11 @@ int main(int argc, char** argv) {
     printf("g1_add_mixed:  %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
   { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd_walk, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
     printf("g1_add_mixed_walk (fused asm): %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
+  for (int wps = 1; wps <= 4; wps *= 2) {
+    int it = 2048; const int bl = pr.multiProcessorCount * wps, th = 256;
+    float ms = time_ms([&] { hipLaunchKernelGGL(k_butterfly, bl, th, 0, 0, (Fr*)buf, it); }, 3);
+    printf("Fr butterfly (add, sub, product) from registers, %d wave(s) per SIMD: %.3e butterflies/s (a stage of 2^20 in %.1f us)\n", wps, (double)bl * th * it / (ms * 1e-3), 1048576.0 / ((double)bl * th * it / (ms * 1e-3)) * 1e6);
+  }
   // latency of a dependent addition: ONE wave per SIMD (the late levels of the bucket-reduction tree), whole addition per lane vs per quad
   { int it = 32; const int bl = pr.multiProcessorCount, th = 256;
     float m1 = time_ms([&] { hipLaunchKernelGGL(k_chain_full, bl, th, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
