@@ -455,6 +455,22 @@ def main():
                 ns_proof = sp.prove_bytes(ns_tr[max(1, W) + i])
             barrier()
             dt_ns = max_over_ranks([time.perf_counter() - t0])[0]
+            # what every rank spends on its own share (no collective in the timed part): the slowest and the mean over the ranks show how
+            # well the plan balances on real hardware, next to the end-to-end time above
+            share_stats = None
+            if world > 1:
+                t_sh = []
+                for _ in range(3):
+                    L.sonic_device_sync()
+                    t0 = time.perf_counter()
+                    sp.prove_share(ns_tr[max(1, W) + K - 1])
+                    t_sh.append(time.perf_counter() - t0)
+                mine_ms = 1e3 * min(t_sh)
+                t = torch.tensor([mine_ms], dtype=torch.float64, device=coll_dev)
+                tmax, tsum = t.clone(), t.clone()
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                share_stats = {"slowest_share_ms": round(float(tmax.item()), 3), "mean_share_ms": round(float(tsum.item()) / world, 3)}
             same_ns = None
             if rank == 0 and world > 1:       # the same proof made by this GPU alone (untimed): the bytes must not depend on the sharing
                 alone = sonic_amd.Prover(srs_ns, circuit_ns, prepare=False)
@@ -466,7 +482,7 @@ def main():
                             "method": ("every rank builds the polynomials its pieces read and runs a contiguous, cost-balanced piece of the proof's 7+4Q MSMs "
                                        "(cuts inside an MSM split its term range); one all-gather of %d-byte shares; sonic_proof_from_shares on every rank"
                                        % L.sonic_proof_share_size(Q)) if world > 1 else "single rank: the plain sequential prove() (baseline of the curve)",
-                            "same_bytes_as_one_gpu_alone": same_ns, "proof_bytes": len(ns_proof), "srs_new_s": round(t_srs_ns, 2)}
+                            "same_bytes_as_one_gpu_alone": same_ns, "proof_bytes": len(ns_proof), "srs_new_s": round(t_srs_ns, 2), "shares": share_stats}
             if world == 1 and args.strong_emulate > 1:
                 E = args.strong_emulate
                 tr_e = ns_tr[max(1, W) + K - 1]
