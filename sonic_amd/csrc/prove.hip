@@ -662,6 +662,10 @@ static int prove_finish_share(sonic_prover_t* p, uint8_t* out_share) {
   const int K = (int)(7 + 4 * Q), F = (int)(3 + 2 * Q);
   HIP_OK(hipStreamSynchronize(p->st));
   p->proofs_done++;
+  if (getenv("SONIC_DEBUG_TIMING"))
+    fprintf(stderr, "[sonic] share %d/%d: enqueue %.3f ms, then waited %.3f ms for the device\n", p->share_rank, p->share_world,
+            std::chrono::duration<double, std::milli>(p->t_enq - p->t_begin).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->t_enq).count());
   const MsmSlot* hs = p->h_slots;
   memset(out_share, 0, sonic_proof_share_size(Q));
   ShareHeader h{SHARE_MAGIC, 1, p->share_rank, p->share_world > 1 ? p->share_world : 1, Q, *p->h_flags, 0};
