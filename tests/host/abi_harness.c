@@ -104,6 +104,24 @@ int main(void) {
   proof3[psz - 1] ^= 1;                               /* v */
   rc = sonic_verify_fs(srs, N, Q, wL, wR, wO, cs, proof3, &ok);
   if (ok != 0) { fprintf(stderr, "abi_harness: verify_fs accepted a tampered proof (status %d)\n", rc); return 1; }
+  /* ONE proof made by three ranks: each runs its share on the same handle in turn (on a node: one handle per GPU), the shares are
+   * what the ranks would all-gather, sonic_proof_from_shares lays out the same bytes */
+  {
+    const size_t ssz = sonic_proof_share_size(Q);
+    uint8_t* shares = malloc(3 * ssz);
+    int r;
+    if (!shares) return 1;
+    for (r = 0; r < 3; r++) {
+      if ((rc = sonic_prover_set_share(p, r, 3))) return fail("sonic_prover_set_share", rc);
+      if ((rc = sonic_prover_prove_share(p, tr, shares + (size_t)r * ssz))) return fail("sonic_prover_prove_share", rc);
+    }
+    if ((rc = sonic_proof_from_shares(Q, 3, shares, tr, proof2))) return fail("sonic_proof_from_shares", rc);
+    if (memcmp(proof, proof2, psz)) { fprintf(stderr, "abi_harness: the proof made of three shares differs from the proof of one GPU\n"); return 1; }
+    rc = sonic_proof_from_shares(Q, 2, shares, tr, proof2);               /* a share missing: refused, not guessed */
+    if (rc != SONIC_ERR_INVALID_ARG) { fprintf(stderr, "abi_harness: an incomplete set of shares gave status %d\n", rc); return 1; }
+    if ((rc = sonic_prover_set_share(p, 0, 1))) return fail("sonic_prover_set_share(whole)", rc);
+    free(shares);
+  }
   sonic_prover_free(p);
 
   /* Protocol.hs:54-55: d < 7 n is refused with a status, never an abort */
@@ -114,6 +132,6 @@ int main(void) {
   sonic_srs_free(small);
   sonic_srs_free(srs);
   free(proof); free(proof2); free(proof3); free(fs_tr);
-  printf("abi_harness: OK (%lu proof bytes, prove + verify + handle + Fiat-Shamir + error contract through the C ABI)\n", (unsigned long)psz);
+  printf("abi_harness: OK (%lu proof bytes, prove + verify + handle + Fiat-Shamir + shared proof + error contract through the C ABI)\n", (unsigned long)psz);
   return 0;
 }
