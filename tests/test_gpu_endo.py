@@ -94,3 +94,39 @@ def test_endo_prove_bytes(sonic, orc, ref, endo_env, n, Q, prepare):
     fz, W = sonic.open_poly(srs, z, poly)
     ofz, oW = orc.open_poly(osrs, z, exps, co)
     assert fz == ofz and sonic.g1_to_bytes(W) == oW
+
+
+def test_endo_prove_at_the_bench_size_equals_full_tables(sonic, endo_env):
+    """n = 2^18, d = 2^21 -- where the endomorphism plan has its production shape (7 windows of 19 / 18 bits, 2^18 buckets per half, the
+    same tree and sort paths as d >= 2^25): the proof over the endomorphism SRS equals, byte for byte, the proof over the full tables
+    (which tests/test_gpu_fullsize.py pins to the oracle at this size), whole and as eight ranks' shares"""
+    n, Q = 1 << 18, 2
+    d = 8 * n
+    x, alpha = 0x1234567891abcdef, 0xfedcba9876543211
+    circ = big_circuit(1818, n, Q)
+    circuit = sonic.ArithCircuit(sonic.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"])
+    asg = sonic.Assignment(circ["aL"], circ["aR"], circ["aO"])
+    tr = rand_fr_array(np.random.default_rng(18), 8 + 2 * Q)
+    tr[:, 0] |= 1
+    srs_e = sonic.SRS.new(d, x, alpha)
+    assert _plan(sonic, srs_e, 3 * n) == (19, 7, 1)
+    pe = sonic.Prover(srs_e, circuit)
+    pe.set_assignment(asg)
+    got = pe.prove_bytes(tr)
+    shares = []
+    for r in range(8):
+        pe.set_share(r, 8)
+        shares.append(pe.prove_share(tr))
+    assert sonic.proof_from_shares(Q, shares, tr) == got
+    pe.close()
+    srs_e.close()
+    os.environ["SONIC_MSM_ENDO"] = "0"
+    try:
+        srs_f = sonic.SRS.new(d, x, alpha)
+    finally:
+        os.environ["SONIC_MSM_ENDO"] = "1"
+    assert _plan(sonic, srs_f, 3 * n) == (20, 13, 1)
+    pf = sonic.Prover(srs_f, circuit)
+    pf.set_assignment(asg)
+    assert pf.prove_bytes(tr) == got
+    pf.close()
