@@ -66,6 +66,7 @@ struct NttTables {
 };
 void ntt_forward_enqueue(hipStream_t st, const NttTables& tw, Fr* d, int log2n);
 void ntt_inverse_enqueue(hipStream_t st, const NttTables& tw, Fr* d, int log2n);
+void ntt_inverse_of_product_enqueue(hipStream_t st, const NttTables& tw, Fr* d, const Fr* other, int log2n);
 void fr_pointwise_mul_enqueue(hipStream_t st, Fr* a, const Fr* b, long n);
 void fr_scale_enqueue(hipStream_t st, Fr* a, long n, const Fr* d_s);
 void fr_bitrev_permute_enqueue(hipStream_t st, Fr* d, int log2n);

@@ -103,15 +103,18 @@ __global__ __launch_bounds__(256) void k_ntt_wide(Fr* __restrict__ d, const Fr* 
 }
 
 // all stages with span <= tile, fused in LDS.  tile_log = min(log2n, TILE_LOG).
-__global__ __launch_bounds__(256) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
-                                                   int inverse, const Fr* __restrict__ scale) {
+__global__ __launch_bounds__(512, 2) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
+                                                       int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Fr* sh = reinterpret_cast<Fr*>(smem);
   const int tile = 1 << tile_log;
+  const int THREADS = blockDim.x;                 // 256 or 512
   const long ntiles = 1L << (log2n - tile_log);
   for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {       // grid-stride over the tiles (see WIDE_GRID)
   const long base = tl << tile_log;
-  for (int i = threadIdx.x; i < tile; i += 256) sh[i] = d[base + i];
+  // (mul: the pointwise product of two transforms folded into the inverse transform's first load)
+  if (mul) { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = fp_mul(d[base + i], mul[base + i]); }
+  else { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = d[base + i]; }
   __syncthreads();
   // forward: stages s = log2n - tile_log .. log2n - 1 (half = tile/2 .. 1)
   // inverse: the same stages in reverse order (half = 1 .. tile/2)
@@ -120,27 +123,27 @@ __global__ __launch_bounds__(256) void k_ntt_local(Fr* __restrict__ d, const Fr*
     const int s = log2n - 1 - hl;
     // a thread's (up to four) butterflies of the stage: all twiddles and operands are requested first, then the arithmetic runs (the
     // twiddle comes from L2 / HBM; with two waves per SIMD nothing else hides that latency)
-    constexpr int BPT = (1 << TILE_LOG) / 2 / 256;
+    constexpr int BPT = (1 << TILE_LOG) / 2 / 256;     // butterflies per thread at 256 threads (half of them at 512)
     Fr w[BPT], a[BPT], b[BPT];
     int i0[BPT];
 #pragma unroll
     for (int u = 0; u < BPT; u++) {
-      const int bt = threadIdx.x + u * 256;
+      const int bt = threadIdx.x + u * THREADS;
       const int j = bt & ((1 << hl) - 1);
       i0[u] = ((bt >> hl) << (hl + 1)) + j;
       if (bt < tile / 2) { w[u] = tw[stage_off(log2n + tw_shift, s + tw_shift) + j]; a[u] = sh[i0[u]]; b[u] = sh[i0[u] + (1 << hl)]; }
     }
 #pragma unroll
     for (int u = 0; u < BPT; u++) {
-      if (threadIdx.x + u * 256 >= tile / 2) continue;
+      if (threadIdx.x + u * THREADS >= tile / 2) continue;
       const int i1 = i0[u] + (1 << hl);
       if (!inverse) { sh[i0[u]] = fp_add(a[u], b[u]); sh[i1] = fp_mul(fp_sub(a[u], b[u]), w[u]); }
       else { const Fr bw = fp_mul(b[u], w[u]); sh[i0[u]] = fp_add(a[u], bw); sh[i1] = fp_sub(a[u], bw); }
     }
     __syncthreads();
   }
-  if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += 256) d[base + i] = fp_mul(sh[i], sc); }
-  else { for (int i = threadIdx.x; i < tile; i += 256) d[base + i] = sh[i]; }
+  if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(sh[i], sc); }
+  else { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = sh[i]; }
   __syncthreads();
   }
 }
@@ -174,7 +177,11 @@ void NttTables::ensure(hipStream_t st, int need) {
   log2n = need;
 }
 
-static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool inverse) {
+static const int LOCAL_THREADS = getenv("SONIC_NTT_LOCAL_THREADS") ? atoi(getenv("SONIC_NTT_LOCAL_THREADS")) : 256;
+static void local_launch(hipStream_t st, int grid, size_t lds, Fr* d, const Fr* table, int log2n, int tile_log, int tw_shift, int inverse, const Fr* scale, const Fr* mul) {
+  LAUNCH(k_ntt_local, grid, LOCAL_THREADS == 512 ? 512 : 256, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
+}
+static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool inverse, const Fr* mul = nullptr) {
   if (log2n == 0) return;
   const int tile_log = log2n < TILE_LOG ? log2n : TILE_LOG;
   const int tw_shift = tw.log2n - log2n;
@@ -193,16 +200,22 @@ static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool 
   };
   if (!inverse) {
     for (int p = 0; p < passes; p++) wide(p, nullptr);
-    LAUNCH(k_ntt_local, (int)std::min<long>(n >> tile_log, WIDE_GRID), 256, lds, st, d, table, log2n, tile_log, tw_shift, 0, (const Fr*)nullptr);
+    local_launch(st, (int)std::min<long>(n >> tile_log, WIDE_GRID), lds, d, table, log2n, tile_log, tw_shift, 0, nullptr, nullptr);
   } else {
     const Fr* ninv = tw.ninv.as<Fr>() + log2n;
-    LAUNCH(k_ntt_local, (int)std::min<long>(n >> tile_log, WIDE_GRID), 256, lds, st, d, table, log2n, tile_log, tw_shift, 1, nglobal == 0 ? ninv : (const Fr*)nullptr);
+    local_launch(st, (int)std::min<long>(n >> tile_log, WIDE_GRID), lds, d, table, log2n, tile_log, tw_shift, 1, nglobal == 0 ? ninv : nullptr, mul);
     for (int p = passes - 1; p >= 0; p--) wide(p, p == 0 ? ninv : nullptr);      // the last pass also scales by 1/n
   }
 }
 
 void ntt_forward_enqueue(hipStream_t st, const NttTables& tw, Fr* d, int log2n) { ntt_run(st, tw, d, log2n, false); }
 void ntt_inverse_enqueue(hipStream_t st, const NttTables& tw, Fr* d, int log2n) { ntt_run(st, tw, d, log2n, true); }
+// inverse transform of the pointwise product d[i] * other[i] (both in the bit-reversed order the forward transforms leave): the product
+// is formed as the first stage loads its tile -- one pass over both arrays less than a separate pointwise kernel
+void ntt_inverse_of_product_enqueue(hipStream_t st, const NttTables& tw, Fr* d, const Fr* other, int log2n) {
+  if (log2n == 0) { fr_pointwise_mul_enqueue(st, d, other, 1); return; }
+  ntt_run(st, tw, d, log2n, true, other);
+}
 
 __global__ __launch_bounds__(256) void k_fr_pointwise_mul(Fr* __restrict__ a, const Fr* __restrict__ b, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a[i] = fp_mul(a[i], b[i]);

@@ -539,8 +539,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     add_into_enqueue(ts, fb + (s_lo - r_lo), sy, s_len);
     ntt_forward_enqueue(ts, p->ntt, fa, p->log2m);
     ntt_forward_enqueue(ts, p->ntt, fb, p->log2m);
-    fr_pointwise_mul_enqueue(ts, fa, fb, M);
-    ntt_inverse_enqueue(ts, p->ntt, fa, p->log2m);
+    ntt_inverse_of_product_enqueue(ts, p->ntt, fa, fb, p->log2m);
     sub_k_of_y_enqueue(ts, fa + (0 - t_lo), cs, p->kpow.as<Fr>(), Q, flags, 0);
     HIP_OK(hipEventRecord(p->ev_t, ts));
   }
@@ -1416,8 +1415,8 @@ int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb
     ntt_forward_enqueue(st, shared_ntt(), fa.as<Fr>(), lg);
     ntt_forward_enqueue(st, shared_ntt(), fb.as<Fr>(), lg);
   }
-  fr_pointwise_mul_enqueue(st, fa.as<Fr>(), fb.as<Fr>(), M);
-  if (lg > 0) ntt_inverse_enqueue(st, shared_ntt(), fa.as<Fr>(), lg);
+  if (lg > 0) ntt_inverse_of_product_enqueue(st, shared_ntt(), fa.as<Fr>(), fb.as<Fr>(), lg);
+  else fr_pointwise_mul_enqueue(st, fa.as<Fr>(), fb.as<Fr>(), M);
   fr_from_mont_enqueue(st, fa.as<Fr>(), rl);
   int fl = read_flags(st, flags);
   if (fl) return flags_to_status(fl, "sonic_poly_mul_fr");
@@ -1450,8 +1449,8 @@ int sonic_poly_mul_fr_dev(const void* d_a, int64_t na, const void* d_b, int64_t 
     ntt_forward_enqueue(st, shared_ntt(), fa->as<Fr>(), lg);
     ntt_forward_enqueue(st, shared_ntt(), fb->as<Fr>(), lg);
   }
-  fr_pointwise_mul_enqueue(st, fa->as<Fr>(), fb->as<Fr>(), M);
-  if (lg > 0) ntt_inverse_enqueue(st, shared_ntt(), fa->as<Fr>(), lg);
+  if (lg > 0) ntt_inverse_of_product_enqueue(st, shared_ntt(), fa->as<Fr>(), fb->as<Fr>(), lg);
+  else fr_pointwise_mul_enqueue(st, fa->as<Fr>(), fb->as<Fr>(), M);
   fr_from_mont_enqueue(st, fa->as<Fr>(), rl);
   HIP_OK(hipMemcpyAsync(d_out, fa->p, 32 * rl, hipMemcpyDeviceToDevice, st));
   int fl = read_flags(st, *flags);
