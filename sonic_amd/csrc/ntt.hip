@@ -60,12 +60,28 @@ static inline int wide_grid(long items) { long g = (items + 255) / 256; return (
 // Several consecutive WIDE stages in one pass through HBM (round 4; before: two per pass as radix-4 butterflies in registers, 6 passes
 // per 2^21-point transform, each bound by the ~4 TB/s its 32-byte strided accesses reach).  Stages s0 .. s0 + ns - 1 only connect
 // elements whose indices differ in the ns bits below bit log2n - s0: a workgroup takes the 2^ns "rows" i = base + k * stride
-// (stride = 2^(log2n - s0 - ns)) for C consecutive columns -- 1024 elements, 32 KB of LDS, C x 32 B contiguous per row -- runs the ns
+// (stride = 2^(log2n - s0 - ns)) for C consecutive columns -- 2048 elements, 64 KB of LDS, C x 32 B contiguous per row -- runs the ns
 // stages out of LDS and writes the block back in place.  Ten wide stages are two passes of five.
-static constexpr int WIDE_ELEMS_LOG = 10;      // elements per workgroup block
-__global__ __launch_bounds__(256) void k_ntt_wide(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
-                                                  const Fr* __restrict__ scale) {
-  __shared__ Fr sh[1 << WIDE_ELEMS_LOG];
+//
+// The butterflies are the generated routines sonic_ntt_bfly4_fwd / _inv (mont_asm.hpp): the four butterflies a thread owns in a stage
+// as one scheduled program that reads its operands from LDS and its twiddles from the stage-major table, in the lazy range [0, 2r).
+// Values are canonical again where they leave the transform: the forward transform's last store, the inverse transform's 1/n scaling.
+static constexpr int WIDE_ELEMS_LOG = 11;      // elements per workgroup block
+static_assert((1 << WIDE_ELEMS_LOG) == 2 * 4 * 256, "four butterflies per thread of a 256-thread workgroup");
+
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }      // the low half of a flat LDS pointer is the LDS offset
+__device__ __forceinline__ Fr fr_canonical(const Fr& a) { return fp_add(a, Fr::zero()); }              // [0, 2r) -> [0, r)
+__device__ __forceinline__ void ntt_bfly4(int inverse, const uint32_t (&e0)[4], const uint32_t (&tj)[4], uint32_t span, const Fr* stw) {
+#if defined(__HIP_DEVICE_COMPILE__)       // (the generated routines exist in the device pass only)
+  if (!inverse) sonic_ntt_bfly4_fwd(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
+  else sonic_ntt_bfly4_inv(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
+#endif
+}
+
+__global__ __launch_bounds__(256, 2) void k_ntt_wide(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
+                                                     const Fr* __restrict__ scale) {
+  __shared__ __attribute__((aligned(16))) Fr sh[1 << WIDE_ELEMS_LOG];
+  const uint32_t lds0 = lds_address(sh);
   const int lc = WIDE_ELEMS_LOG - ns;                       // log2 C
   const int lstride = log2n - s0 - ns;                      // log2 of the row stride
   const long col_blocks = 1L << (lstride - lc);
@@ -80,16 +96,19 @@ __global__ __launch_bounds__(256) void k_ntt_wide(Fr* __restrict__ d, const Fr* 
       const int s = s0 + tt;
       const int hb = ns - 1 - tt;                            // the row bit this stage pairs
       const int lhalf = log2n - 1 - s;                       // log2 of the butterfly span in elements
-      for (int bt = threadIdx.x; bt < (1 << (WIDE_ELEMS_LOG - 1)); bt += 256) {
+      const Fr* stw = tw + stage_off(log2n + tw_shift, s + tw_shift);
+      uint32_t e0[4], tj[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int bt = threadIdx.x + q * 256;
         const int c = bt & ((1 << lc) - 1), kp = bt >> lc;
         const int k = ((kp >> hb) << (hb + 1)) | (kp & ((1 << hb) - 1));         // row with bit hb clear
-        const int e0 = (k << lc) | c, e1 = e0 + (1 << (hb + lc));
         const long j = (((long)(k & ((1 << hb) - 1)) << lstride) + (cb << lc) + c) & ((1L << lhalf) - 1);
-        const Fr w = tw[stage_off(log2n + tw_shift, s + tw_shift) + j];
-        const Fr a = sh[e0], b = sh[e1];
-        if (!inverse) { sh[e0] = fp_add(a, b); sh[e1] = fp_mul(fp_sub(a, b), w); }
-        else { const Fr bw = fp_mul(b, w); sh[e0] = fp_add(a, bw); sh[e1] = fp_sub(a, bw); }
+        e0[q] = lds0 + (uint32_t)(((k << lc) | c) * (int)sizeof(Fr));
+        tj[q] = (uint32_t)j * (uint32_t)sizeof(Fr);
       }
+      const uint32_t span = (uint32_t)sizeof(Fr) << (hb + lc);
+      ntt_bfly4(inverse, e0, tj, span, stw);
       __syncthreads();
     }
     if (scale) {
@@ -102,13 +121,15 @@ __global__ __launch_bounds__(256) void k_ntt_wide(Fr* __restrict__ d, const Fr* 
   }
 }
 
-// all stages with span <= tile, fused in LDS.  tile_log = min(log2n, TILE_LOG).
-__global__ __launch_bounds__(512, 2) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
-                                                       int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
+// all stages with span <= tile, fused in LDS.  tile_log = min(log2n, TILE_LOG).  Full tiles (2048 elements: every transform the prover
+// runs) go through the generated butterflies, four per thread and stage; smaller transforms through the plain C++ ones.
+__global__ __launch_bounds__(256, 2) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
+                                                      int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Fr* sh = reinterpret_cast<Fr*>(smem);
+  const uint32_t lds0 = lds_address(sh);
   const int tile = 1 << tile_log;
-  const int THREADS = blockDim.x;                 // 256 or 512
+  constexpr int THREADS = 256;
   const long ntiles = 1L << (log2n - tile_log);
   for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {       // grid-stride over the tiles (see WIDE_GRID)
   const long base = tl << tile_log;
@@ -118,32 +139,44 @@ __global__ __launch_bounds__(512, 2) void k_ntt_local(Fr* __restrict__ d, const 
   __syncthreads();
   // forward: stages s = log2n - tile_log .. log2n - 1 (half = tile/2 .. 1)
   // inverse: the same stages in reverse order (half = 1 .. tile/2)
-  for (int k = 0; k < tile_log; k++) {
-    const int hl = inverse ? k : tile_log - 1 - k;       // log2(half)
-    const int s = log2n - 1 - hl;
-    // a thread's (up to four) butterflies of the stage: all twiddles and operands are requested first, then the arithmetic runs (the
-    // twiddle comes from L2 / HBM; with two waves per SIMD nothing else hides that latency)
-    constexpr int BPT = (1 << TILE_LOG) / 2 / 256;     // butterflies per thread at 256 threads (half of them at 512)
-    Fr w[BPT], a[BPT], b[BPT];
-    int i0[BPT];
+  if (tile_log == TILE_LOG) {
+    for (int k = 0; k < TILE_LOG; k++) {
+      const int hl = inverse ? k : TILE_LOG - 1 - k;       // log2(half)
+      const int s = log2n - 1 - hl;
+      const Fr* stw = tw + stage_off(log2n + tw_shift, s + tw_shift);
+      uint32_t e0[4], tj[4];
 #pragma unroll
-    for (int u = 0; u < BPT; u++) {
-      const int bt = threadIdx.x + u * THREADS;
-      const int j = bt & ((1 << hl) - 1);
-      i0[u] = ((bt >> hl) << (hl + 1)) + j;
-      if (bt < tile / 2) { w[u] = tw[stage_off(log2n + tw_shift, s + tw_shift) + j]; a[u] = sh[i0[u]]; b[u] = sh[i0[u] + (1 << hl)]; }
+      for (int q = 0; q < 4; q++) {
+        const int bt = threadIdx.x + q * THREADS;
+        const int j = bt & ((1 << hl) - 1);
+        e0[q] = lds0 + (uint32_t)((((bt >> hl) << (hl + 1)) + j) * (int)sizeof(Fr));
+        tj[q] = (uint32_t)(j * (int)sizeof(Fr));
+      }
+      const uint32_t span = (uint32_t)sizeof(Fr) << hl;
+      ntt_bfly4(inverse, e0, tj, span, stw);
+      __syncthreads();
     }
-#pragma unroll
-    for (int u = 0; u < BPT; u++) {
-      if (threadIdx.x + u * THREADS >= tile / 2) continue;
-      const int i1 = i0[u] + (1 << hl);
-      if (!inverse) { sh[i0[u]] = fp_add(a[u], b[u]); sh[i1] = fp_mul(fp_sub(a[u], b[u]), w[u]); }
-      else { const Fr bw = fp_mul(b[u], w[u]); sh[i0[u]] = fp_add(a[u], bw); sh[i1] = fp_sub(a[u], bw); }
+    // the lazy range ends here: canonical out of the forward transform (and out of an inverse one that is scaled here)
+    if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(sh[i], sc); }
+    else if (!inverse) { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fr_canonical(sh[i]); }
+    else { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = sh[i]; }
+  } else {
+    for (int k = 0; k < tile_log; k++) {
+      const int hl = inverse ? k : tile_log - 1 - k;
+      const int s = log2n - 1 - hl;
+      for (int bt = threadIdx.x; bt < tile / 2; bt += THREADS) {
+        const int j = bt & ((1 << hl) - 1);
+        const int i0 = ((bt >> hl) << (hl + 1)) + j, i1 = i0 + (1 << hl);
+        const Fr w = tw[stage_off(log2n + tw_shift, s + tw_shift) + j];
+        const Fr a = sh[i0], b = sh[i1];
+        if (!inverse) { sh[i0] = fp_add(a, b); sh[i1] = fp_mul(fp_sub(a, b), w); }
+        else { const Fr bw = fp_mul(b, w); sh[i0] = fp_add(a, bw); sh[i1] = fp_sub(a, bw); }
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(sh[i], sc); }
+    else { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = sh[i]; }
   }
-  if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(sh[i], sc); }
-  else { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = sh[i]; }
   __syncthreads();
   }
 }
@@ -177,9 +210,8 @@ void NttTables::ensure(hipStream_t st, int need) {
   log2n = need;
 }
 
-static const int LOCAL_THREADS = getenv("SONIC_NTT_LOCAL_THREADS") ? atoi(getenv("SONIC_NTT_LOCAL_THREADS")) : 256;
 static void local_launch(hipStream_t st, int grid, size_t lds, Fr* d, const Fr* table, int log2n, int tile_log, int tw_shift, int inverse, const Fr* scale, const Fr* mul) {
-  LAUNCH(k_ntt_local, grid, LOCAL_THREADS == 512 ? 512 : 256, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
+  LAUNCH(k_ntt_local, grid, 256, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
 }
 static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool inverse, const Fr* mul = nullptr) {
   if (log2n == 0) return;

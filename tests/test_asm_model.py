@@ -30,6 +30,10 @@ class Lane:
         self.core_prog = core_prog      # one routine, or {symbol: routine}
         self.target, self.calls = None, []
         self.trace = []          # (kind, carry-register) per issued instruction, for the hazard check
+        self.lds, self.glob, self.s64 = {}, {}, {}      # byte address -> 32-bit word (the NTT butterflies' operands); 64-bit SGPR pairs
+        self.loads_in_flight = []         # registers a load has been issued for and no s_waitcnt has covered yet
+        self.store_reads = []             # (slot, registers) of LDS stores, for the data-hold check
+        self.reg_writes = []              # (slot, register)
 
     def rd(self, tok):
         tok = tok.strip()
@@ -39,11 +43,14 @@ class Lane:
             return int(tok)
         if tok[0] == "s":
             return self.s[tok]
-        return self.v.get(tok, 0xDEADBEEF) if tok not in self.v else self.v[tok]
+        val = self.v.get(tok, 0xDEADBEEF)
+        assert not isinstance(val, tuple), f"{tok} is read before the s_waitcnt that covers its load"
+        return val
 
     def wr(self, tok, val):
         if self.exec:
             self.v[tok.strip()] = val & M32
+            self.reg_writes.append((len(self.trace), tok.strip()))
 
     def pair(self, tok):
         m = re.match(r"v\[(\d+):(\d+)\]", tok.strip())
@@ -84,9 +91,54 @@ class Lane:
         if op == "s_or_b64":
             self.c[a[0]] = self.c[a[1]] | self.c[a[2]]
             return
+        if op == "s_andn2_b64" and a[0] != "exec":
+            self.c[a[0]] = self.c[a[1]] & (1 - self.c[a[2]])
+            self.trace.append(("salu", None, None))
+            return
         if op == "s_andn2_b64":
             assert a[0] == "exec" and a[1] == "exec"
             self.exec = self.exec and not self.c[a[2]]
+            return
+        if op in ("ds_read_b128", "ds_write_b128", "global_load_dwordx4"):
+            m = re.match(r"v\[(\d+):(\d+)\]", a[1] if op == "ds_write_b128" else a[0])
+            regs = [f"v{k}" for k in range(int(m.group(1)), int(m.group(2)) + 1)]
+            off = int(rest.split("offset:")[1]) if "offset:" in rest else 0
+            if op == "ds_read_b128":
+                base = self.rd(a[1].split()[0]) + off
+                for k, r in enumerate(regs):
+                    self.v[r] = ("pending", self.lds[base + 4 * k])
+                self.loads_in_flight.append(("lds", regs))
+            elif op == "global_load_dwordx4":
+                sp = re.match(r"(s\[\d+:\d+\])", a[2]).group(1)
+                base = self.rd(a[1]) + self.s64[sp] + off
+                for k, r in enumerate(regs):
+                    self.v[r] = ("pending", self.glob[base + 4 * k])
+                self.loads_in_flight.append(("vm", regs))
+            else:
+                base = self.rd(a[0]) + off
+                for k, r in enumerate(regs):
+                    self.lds[base + 4 * k] = self.rd(r)
+                self.store_reads.append((len(self.trace), regs))
+            self.trace.append(("mem", None, None))
+            return
+        if op == "s_waitcnt":
+            vm = int(re.search(r"vmcnt\((\d+)\)", rest).group(1)) if "vmcnt" in rest else None
+            lgkm = int(re.search(r"lgkmcnt\((\d+)\)", rest).group(1)) if "lgkmcnt" in rest else None
+            for kind, n in (("vm", vm), ("lds", lgkm)):
+                if n is None:
+                    continue
+                mine = [x for x in self.loads_in_flight if x[0] == kind]
+                done = mine[:max(0, len(mine) - n)]            # in-order return: all but the last n
+                for x in done:
+                    for r in x[1]:
+                        if isinstance(self.v.get(r), tuple):
+                            self.v[r] = self.v[r][1]
+                    self.loads_in_flight.remove(x)
+            self.trace.append(("salu", None, None))
+            return
+        if op == "v_add_u32_e32":
+            self.wr(a[0], self.rd(a[1]) + self.rd(a[2]))
+            self.trace.append(("valu", None, None))
             return
         # ---- VALU ----
         if op == "v_mov_b32_e32":
@@ -134,6 +186,12 @@ class Lane:
         else:
             raise AssertionError("instruction not modelled: " + ins)
         self.trace.append(("valu", carry_read, carry_write))
+
+    def check_store_hold(self, hold=2):
+        """no register an LDS store reads is rewritten within `hold` slots of the store"""
+        for at, regs in self.store_reads:
+            for slot, r in self.reg_writes:
+                assert not (r in regs and at < slot <= at + hold), f"{r} rewritten {slot - at} slots after the store that reads it"
 
     def check_carry_hazard(self):
         last_write = {}
@@ -349,3 +407,48 @@ def test_committed_header_is_generated():
     """sonic_amd/csrc/mont_asm.hpp is what the generator produces today (nobody edited one without the other)"""
     path = os.path.join(os.path.dirname(__file__), "..", "sonic_amd", "csrc", "mont_asm.hpp")
     assert open(path).read() == G.render()
+
+
+# ---- the NTT butterflies ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("inverse", [False, True])
+def test_ntt_butterfly_model(inverse):
+    """four butterflies of one stage out of LDS: operands anywhere in the lazy range [0, 2r) (edge values included), twiddles
+    canonical; results congruent to the radix-2 butterfly, again below 2r, written where the operands came from; no operand is
+    read before the wait that covers its load, no carry inside the hazard window, no store's data rewritten under it"""
+    N, p = 8, G.R
+    Rm = 1 << 256
+    Ri = pow(Rm, -1, p)
+    rng = random.Random(77 + inverse)
+    body = G.ntt_bfly_text(inverse)[:-1]             # without the return
+    assert not any(l.startswith("s_nop") for l in body) or sum(1 for l in body if l.startswith("s_nop")) <= 4
+    edge = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p - 2, (1 << 255), (1 << 255) - 1]
+    for it in range(12):
+        lane = Lane()
+        span, twbase = 32 * rng.choice([1, 2, 64, 1024]), 0x7F0012340000
+        lane.s[G.NTT_SPAN] = span
+        lane.s64[G.NTT_TWB] = twbase
+        e0s, tws = [], []
+        vals = []
+        for u in range(G.NTT_U):
+            e0 = 1024 * it + (32 * u if span >= 32 * G.NTT_U else 2 * span * u)        # the butterflies of a stage never share an element
+            a = edge[(it + u) % len(edge)] if it < 6 else rng.randrange(2 * p)
+            b = edge[(it * 3 + u + 1) % len(edge)] if it < 9 else rng.randrange(2 * p)
+            w = [0, 1, p - 1, Rm % p][u] if it == 0 else rng.randrange(p)
+            t = 32 * rng.randrange(1 << 20)
+            for k in range(N):
+                lane.lds[e0 + 4 * k], lane.lds[e0 + span + 4 * k], lane.glob[twbase + t + 4 * k] = limbs(a, N)[k], limbs(b, N)[k], limbs(w, N)[k]
+            lane.v[f"v{G.NTT_E0 + u}"], lane.v[f"v{G.NTT_TW + u}"] = e0, t
+            e0s.append(e0); tws.append(t); vals.append((a, b, w))
+        lane.run(body)
+        lane.check_carry_hazard()
+        lane.check_store_hold()
+        assert not lane.loads_in_flight
+        for u, (a, b, w) in enumerate(vals):
+            x = unlimbs([lane.lds[e0s[u] + 4 * k] for k in range(N)])
+            y = unlimbs([lane.lds[e0s[u] + span + 4 * k] for k in range(N)])
+            assert x < 2 * p and y < 2 * p, (it, u)
+            if not inverse:
+                assert x % p == (a + b) % p and y % p == (a - b) * w * Ri % p, (it, u, hex(a), hex(b), hex(w))
+            else:
+                assert x % p == (a + b * w * Ri) % p and y % p == (a - b * w * Ri) % p, (it, u, hex(a), hex(b), hex(w))
+        # the zero halves and T_N are left as the next call expects them -- they are rewritten by the prologue anyway

@@ -35,11 +35,12 @@ ALU_LATENCY = 1
 
 
 class Ins:
-    __slots__ = ("text", "reads", "writes", "idx", "deps", "users", "prio", "carry_reads")
+    __slots__ = ("text", "reads", "writes", "idx", "deps", "users", "prio", "carry_reads", "hold")
 
     def __init__(self, text, reads, writes, carry_reads=()):
         self.text, self.reads, self.writes, self.carry_reads = text, set(reads), set(writes), set(carry_reads)
         self.deps, self.users, self.prio = set(), set(), 0
+        self.hold = 0          # issue slots after this instruction in which nothing may overwrite what it reads (LDS / memory stores)
 
 
 def build(N: int, p: int, lazy: bool = False, core: bool = False, kind: str = "mul", cd_base=None):
@@ -206,6 +207,8 @@ def schedule(prog):
         for k in ready:
             ins = prog[k]
             if any(slot - carry_written_at.get(c, -10) <= CARRY_GAP for c in ins.carry_reads):
+                continue
+            if any(prog[d].hold and slot - done_at[d] <= prog[d].hold for d in ins.deps):
                 continue
             # latency model: prefer instructions whose producers' results have had time to land (a MAD result
             # takes a few issue slots); among those the longest remaining critical path
@@ -544,6 +547,208 @@ def addsub_cxx(fname: str, cls: str, N: int, sub: bool, const: str = "p2") -> st
 }}"""
 
 
+# ---- NTT butterflies over Fr: the U butterflies a thread owns in one stage, operands in LDS, as ONE scheduled program ----------
+NTT_U = 4
+NTT_NV = 176            # VGPRs v0 .. v175
+# register map (VGPRs): T pairs v0..v17, Q pairs v18..v33, m v34, limbs of 2r v36..v43, butterfly u: a v[44+24u ..], b (+8), w (+16),
+# the sum x v140.. (the other results go where an operand was), chain temporaries v148.. / v156..; inputs: LDS byte address of the
+# butterfly's first element v164+u, byte offset of its twiddle v168+u (the second element's address goes to v172+u)
+NTT_E0, NTT_TW, NTT_E1 = 164, 168, 172
+NTT_SPAN, NTT_TWB = "s70", "s[68:69]"
+
+
+def ntt_bfly_program(inverse: bool, U: int = NTT_U):
+    """One stage's butterflies of a thread, values in the lazy range [0, 2r) (2r < 2^256), twiddles canonical:
+        forward (DIF):  x = a + b,      y = (a - b) w        inverse (DIT):  t = b w,  x = a + t,  y = a - t
+    a = LDS[e0], b = LDS[e0 + span], w = table[tw]; x and y go back where a and b came from.  A product of a value below 2r with a
+    canonical twiddle is below r (2r / 2^256 + 1) < 1.91 r without any final subtraction, sums and differences are brought back
+    below 2r by one conditional -+ 2r.  All loads are issued first; the products run one after another (they share the T / Q
+    registers), the add / sub chains fill the slots around them.
+    Returns (prologue, scheduled body, epilogue) as instruction lists."""
+    N, p = 8, R
+    p2 = 2 * p
+    assert p2 < 1 << 256
+    TPlo = lambda j: 2 * j
+    TPhi = lambda j: 2 * j + 1
+    QA = lambda j: 18 + 2 * j
+    M = 34
+    P2 = lambda j: 36 + j
+    Ar = lambda u, j: 44 + 24 * u + j
+    Br = lambda u, j: 52 + 24 * u + j
+    Wr = lambda u, j: 60 + 24 * u + j
+    X = lambda j: 140 + j
+    D1 = lambda j: 148 + j
+    D2 = lambda j: 156 + j
+    assert Wr(U - 1, 7) < 140
+    SP = lambda j: 36 + j
+    SINV = 36 + N
+    C1, C2, JUNK = "vcc", "s[50:51]", "s[54:55]"
+    CA1, CB1, CA2, CB2, MASK = "s[58:59]", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]"
+    inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+    v = lambda r: f"v{r}"
+    vp = lambda r: f"v[{r}:{r + 1}]"
+    v4 = lambda r: f"v[{r}:{r + 3}]"
+
+    pre = [f"s_mov_b32 s{SP(j)}, 0x{limb32(p, j):08x}" for j in range(N)] + [f"s_mov_b32 s{SINV}, 0x{inv:08x}"]
+    for u in range(U):
+        pre.append(f"v_add_u32_e32 {v(NTT_E1 + u)}, {NTT_SPAN}, {v(NTT_E0 + u)}")
+        pre.append(f"ds_read_b128 {v4(Ar(u, 0))}, {v(NTT_E0 + u)}")
+        pre.append(f"ds_read_b128 {v4(Ar(u, 4))}, {v(NTT_E0 + u)} offset:16")
+        pre.append(f"ds_read_b128 {v4(Br(u, 0))}, {v(NTT_E1 + u)}")
+        pre.append(f"ds_read_b128 {v4(Br(u, 4))}, {v(NTT_E1 + u)} offset:16")
+        pre.append(f"global_load_dwordx4 {v4(Wr(u, 0))}, {v(NTT_TW + u)}, {NTT_TWB}")
+        pre.append(f"global_load_dwordx4 {v4(Wr(u, 4))}, {v(NTT_TW + u)}, {NTT_TWB} offset:16")
+    for j in range(N + 1):
+        pre.append(f"v_mov_b32_e32 {v(TPhi(j))}, 0")
+    pre.append(f"v_mov_b32_e32 {v(TPlo(N))}, 0")
+    for j in range(N):
+        pre.append(f"v_mov_b32_e32 {v(P2(j))}, 0x{limb32(p2, j):08x}")
+
+    prog = []
+
+    def emit(text, reads, writes, carry_reads=()):
+        prog.append(Ins(text, reads, writes, carry_reads))
+        return prog[-1]
+
+    def chain(op0, op, dst, c, x, y):
+        """dst = x op y limb by limb, carry / borrow in the SGPR pair (or vcc) c"""
+        for j in range(N):
+            if j == 0:
+                emit(f"{op0}_e64 {v(dst(j))}, {c}, {v(x(j))}, {v(y(j))}", [v(x(j)), v(y(j))], [v(dst(j)), c])
+            else:
+                emit(f"{op}_e64 {v(dst(j))}, {c}, {v(x(j))}, {v(y(j))}, {c}", [v(x(j)), v(y(j)), c], [v(dst(j)), c], [c])
+
+    def add_lazy(out, x, y, D, ca, cb):
+        """out = x + y (- 2r if that is not negative).  x + y may pass 2^256: with the carry c1 of the sum and the borrow b1 of the
+        subtraction as a ninth limb, (x + y - 2r) is negative exactly when b1 and not c1."""
+        chain("v_add_co_u32", "v_addc_co_u32", D, ca, x, y)
+        chain("v_sub_co_u32", "v_subb_co_u32", out, cb, D, P2)
+        emit(f"s_andn2_b64 {MASK}, {cb}, {ca}", [cb, ca], [MASK], [cb, ca])
+        for j in range(N):
+            emit(f"v_cndmask_b32_e64 {v(out(j))}, {v(out(j))}, {v(D(j))}, {MASK}", [v(out(j)), v(D(j)), MASK], [v(out(j))])
+
+    def sub_lazy(out, x, y, D, ca, cb):
+        """out = x - y (+ 2r if the difference is negative)"""
+        chain("v_sub_co_u32", "v_subb_co_u32", D, ca, x, y)
+        chain("v_add_co_u32", "v_addc_co_u32", out, cb, D, P2)
+        for j in range(N):
+            emit(f"v_cndmask_b32_e64 {v(out(j))}, {v(D(j))}, {v(out(j))}, {ca}", [v(D(j)), v(out(j)), ca], [v(out(j))], [ca])
+
+    def add_first(dst, c, x, y):
+        if c == "vcc":
+            emit(f"v_add_co_u32_e32 {v(dst)}, vcc, {v(x)}, {v(y)}", [v(x), v(y)], [v(dst), c])
+        else:
+            emit(f"v_add_co_u32_e64 {v(dst)}, {c}, {v(x)}, {v(y)}", [v(x), v(y)], [v(dst), c])
+
+    def add_carry(dst, c, x, y):
+        if c == "vcc":
+            emit(f"v_addc_co_u32_e32 {v(dst)}, vcc, {v(x)}, {v(y)}, vcc", [v(x), v(y), c], [v(dst), c], [c])
+        else:
+            emit(f"v_addc_co_u32_e64 {v(dst)}, {c}, {v(x)}, {v(y)}, {c}", [v(x), v(y), c], [v(dst), c], [c])
+
+    def product(xa, xb, out):
+        """out (eight consecutive registers) = xa * xb / 2^256 mod r without the final subtraction; same rows as build(kind="mul"),
+        the last reduction row folds into `out` instead of the T pairs.  Returns the first instruction (see the waits below)."""
+        head = None
+        for i in range(N):
+            for j in range(N):
+                if i == 0:
+                    ins = emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(xa(j))}, {v(xb(i))}, 0", [v(xa(j)), v(xb(i))], [v(QA(j)), v(QA(j) + 1)])
+                    head = head or ins
+                else:
+                    emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(xa(j))}, {v(xb(i))}, {vp(TPlo(j))}",
+                         [v(xa(j)), v(xb(i)), v(TPlo(j)), v(TPhi(j))], [v(QA(j)), v(QA(j) + 1)])
+            emit(f"v_mul_lo_u32 {v(M)}, {v(QA(0))}, s{SINV}", [v(QA(0))], [v(M)])
+            emit(f"v_mov_b32_e32 {v(TPlo(0))}, {v(QA(0))}", [v(QA(0))], [v(TPlo(0))])
+            for j in range(1, N):
+                (add_first if j == 1 else add_carry)(TPlo(j), C1, QA(j), QA(j - 1) + 1)
+            add_carry(TPlo(N), C1, TPlo(N), QA(N - 1) + 1)
+            for j in range(N):
+                emit(f"v_mad_u64_u32 {vp(QA(j))}, {JUNK}, {v(M)}, s{SP(j)}, {vp(TPlo(j))}",
+                     [v(M), v(TPlo(j)), v(TPhi(j))], [v(QA(j)), v(QA(j) + 1)])
+            dst = (lambda j: out(j)) if i == N - 1 else TPlo
+            for j in range(1, N):
+                (add_first if j == 1 else add_carry)(dst(j - 1), C2, QA(j), QA(j - 1) + 1)
+            add_carry(dst(N - 1), C2, TPlo(N), QA(N - 1) + 1)
+            emit(f"v_addc_co_u32_e64 {v(TPlo(N))}, {C2}, 0, 0, {C2}", [C2], [v(TPlo(N)), C2], [C2])
+        return head
+
+    def store(addr, src):
+        for h in (0, 4):
+            ins = emit(f"ds_write_b128 {v(addr)}, {v4(src(h))}" + (" offset:16" if h else ""), [v(addr)] + [v(src(h + k)) for k in range(4)], [])
+            ins.hold = 2          # its data registers must not be rewritten in the next two slots
+
+    # Waits: the LDS reads all at once (a partial lgkmcnt would have to trust that nothing else is in flight on that counter), the
+    # twiddles one butterfly at a time, each behind the product of the butterfly before (by then it has long arrived).  The forward
+    # butterflies run all their sums and differences first -- those need the LDS operands only, the twiddles are still in flight.
+    A_ = lambda u: (lambda j: Ar(u, j))
+    B_ = lambda u: (lambda j: Br(u, j))
+    W_ = lambda u: (lambda j: Wr(u, j))
+    lds_regs = [v(Ar(k, j)) for k in range(U) for j in range(N)] + [v(Br(k, j)) for k in range(U) for j in range(N)]
+    emit("s_waitcnt lgkmcnt(0)", lds_regs, lds_regs)
+
+    def wait_twiddle(u, after):
+        regs = [v(Wr(u, j)) for j in range(N)]
+        emit(f"s_waitcnt vmcnt({2 * (U - 1 - u)})", regs + after, regs)
+
+    if not inverse:
+        for u in range(U):
+            add_lazy(X, A_(u), B_(u), D1, CA1, CB1)
+            store(NTT_E0 + u, X)
+            sub_lazy(A_(u), A_(u), B_(u), D2, CA2, CB2)           # a - b where a was
+        for u in range(U):
+            wait_twiddle(u, [v(Ar(k, j)) for k in range(U) for j in range(N)] if u == 0 else [v(QA(0))])
+            product(A_(u), W_(u), B_(u))                          # y where b was
+            store(NTT_E1 + u, B_(u))
+    else:
+        for u in range(U):
+            wait_twiddle(u, [] if u == 0 else [v(QA(0))])
+            product(B_(u), W_(u), W_(u))                          # t where w was
+            add_lazy(X, A_(u), W_(u), D1, CA1, CB1)
+            store(NTT_E0 + u, X)
+            sub_lazy(B_(u), A_(u), W_(u), D2, CA2, CB2)           # y where b was
+            store(NTT_E1 + u, B_(u))
+    post = ["s_waitcnt lgkmcnt(0)"]
+    return pre, prog, post
+
+
+def ntt_bfly_text(inverse: bool):
+    pre, prog, post = ntt_bfly_program(inverse)
+    return pre + schedule(prog) + post + ["s_setpc_b64 s[30:31]"]
+
+
+def ntt_bfly_cxx(inverse: bool) -> str:
+    name = "sonic_ntt_bfly4_inv" if inverse else "sonic_ntt_bfly4_fwd"
+    body = ntt_bfly_text(inverse)
+    mads = sum(1 for l in body if l.startswith("v_mad_u64"))
+    nops = sum(1 for l in body if l.startswith("s_nop"))
+    what = "t = b w, x = a + t, y = a - t" if inverse else "x = a + b, y = (a - b) w"
+    lines = routine_section(name, body, f"// {name}: {NTT_U} radix-2 butterflies ({what}) on Fr values in LDS, lazy range [0, 2r): {len(body)} instructions "
+                                        f"({mads} v_mad_u64_u32, {nops} s_nop), VGPRs v0..v{NTT_NV - 1}")
+    U = NTT_U
+    args = ", ".join([f"uint32_t e{u}" for u in range(U)] + [f"uint32_t t{u}" for u in range(U)] + ["uint32_t span", "const void* twiddles"])
+    lines.append(f"// e_u: LDS byte address of butterfly u's first element (the second one is `span` bytes further), t_u: byte offset of its twiddle from `twiddles`")
+    lines.append(f"__device__ __forceinline__ void {name}({args}) {{")
+    lines.append("  asm volatile(")
+    for u in range(U):
+        lines.append(f'      "v_mov_b32_e32 v{NTT_E0 + u}, %{u}\\n\\t"')
+    for u in range(U):
+        lines.append(f'      "v_mov_b32_e32 v{NTT_TW + u}, %{U + u}\\n\\t"')
+    lines.append(f'      "s_mov_b32 {NTT_SPAN}, %{2 * U}\\n\\t"')
+    lines.append(f'      "s_mov_b64 {NTT_TWB}, %{2 * U + 1}\\n\\t"')
+    lines.append('      "s_getpc_b64 s[56:57]\\n\\t"')
+    lines.append(f'      "s_add_u32 s56, s56, {name}@rel32@lo+4\\n\\t"')
+    lines.append(f'      "s_addc_u32 s57, s57, {name}@rel32@hi+12\\n\\t"')
+    lines.append('      "s_swappc_b64 s[30:31], s[56:57]"')
+    ins = ", ".join([f'"v"(e{u})' for u in range(U)] + [f'"v"(t{u})' for u in range(U)] + ['"s"(span)', '"s"(twiddles)'])
+    clob = [f'"v{k}"' for k in range(NTT_NV)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 71))] + ['"vcc"', '"scc"', '"memory"']
+    lines.append("      :")
+    lines.append(f"      : {ins}")
+    lines.append(f"      : {', '.join(clob)});")
+    lines.append("}")
+    return "\n".join(lines)
+
+
 def render() -> str:
     """The text of sonic_amd/csrc/mont_asm.hpp (tests/test_asm_model.py checks that the committed file is this)."""
     out = ["// GENERATED by tools/gen_mont_asm.py -- do not edit.",
@@ -574,6 +779,10 @@ def render() -> str:
            addsub_cxx("sonic_fq_add_asm", "Fp<P>", 12, False),
            addsub_cxx("sonic_fr_sub_asm", "Fp<P>", 8, True, const="p"),
            addsub_cxx("sonic_fr_add_asm", "Fp<P>", 8, False, const="p"),
+           "",
+           ntt_bfly_cxx(False),
+           "",
+           ntt_bfly_cxx(True),
            "}  // namespace sonic",
            "#endif", ""]
     return "\n".join(out)
