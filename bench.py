@@ -264,7 +264,7 @@ def main():
                "hbm_passes_per_transform": passes, "bytes_by_design": float((3 * passes * 64 + 96) * M),
                "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
                "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS (round 4) the transforms "
-                       "are bound by VALU issue: one Fr product (328 instructions) + add + sub per butterfly (DESIGN.md section 5)"}
+                       "are bound by VALU issue: 348 instructions per butterfly in the generated assembly routines sonic_ntt_bfly4_fwd / _inv (DESIGN.md section 5)"}
         for ptr in (da, db, do):
             L.sonic_dev_free(ptr)
 

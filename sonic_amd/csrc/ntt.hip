@@ -71,9 +71,11 @@ static_assert((1 << WIDE_ELEMS_LOG) == 2 * 4 * 256, "four butterflies per thread
 
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }      // the low half of a flat LDS pointer is the LDS offset
 __device__ __forceinline__ Fr fr_canonical(const Fr& a) { return fp_add(a, Fr::zero()); }              // [0, 2r) -> [0, r)
-__device__ __forceinline__ void ntt_bfly4(int inverse, const uint32_t (&e0)[4], const uint32_t (&tj)[4], uint32_t span, const Fr* stw) {
+// (unit: the stage with a span of one element -- every twiddle is w^0 = 1, the butterfly is a sum and a difference)
+__device__ __forceinline__ void ntt_bfly4(int inverse, const uint32_t (&e0)[4], const uint32_t (&tj)[4], uint32_t span, const Fr* stw, bool unit = false) {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the generated routines exist in the device pass only)
-  if (!inverse) sonic_ntt_bfly4_fwd(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
+  if (unit) sonic_ntt_bfly4_unit(e0[0], e0[1], e0[2], e0[3], span);
+  else if (!inverse) sonic_ntt_bfly4_fwd(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
   else sonic_ntt_bfly4_inv(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
 #endif
 }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_local(Fr* __restrict__ d, const 
         tj[q] = (uint32_t)(j * (int)sizeof(Fr));
       }
       const uint32_t span = (uint32_t)sizeof(Fr) << hl;
-      ntt_bfly4(inverse, e0, tj, span, stw);
+      ntt_bfly4(inverse, e0, tj, span, stw, hl == 0);
       __syncthreads();
     }
     // the lazy range ends here: canonical out of the forward transform (and out of an inverse one that is scaled here)

@@ -399,6 +399,30 @@ def test_ntt_matches_oracle(sonic, orc, log2n):
     assert np.array_equal(rt, a)
 
 
+@pytest.mark.parametrize("log2n", [11, 12, 16])
+def test_ntt_extreme_inputs(sonic, orc, log2n):
+    """the assembly butterflies keep values in [0, 2r) between stages (sums pass 2^256, differences borrow): inputs that sit on the
+    edges of the field -- all r - 1, zeros and r - 1 alternating, blocks of the two, a single non-zero element, a constant -- must
+    still give the oracle's canonical transform in both directions"""
+    from sonic_amd import _lib
+    n = 1 << log2n
+    top = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
+    one = np.frombuffer((1).to_bytes(32, "little"), np.uint8)
+    cases = []
+    a = np.tile(top, (n, 1)); cases.append(a)
+    a = np.zeros((n, 32), np.uint8); a[::2] = top; cases.append(a)
+    a = np.zeros((n, 32), np.uint8); a[1::2] = top; a[::2] = one; cases.append(a)
+    a = np.zeros((n, 32), np.uint8); a[: n // 2] = top; cases.append(a)
+    a = np.zeros((n, 32), np.uint8); a[n - 1] = top; cases.append(a)
+    a = np.zeros((n, 32), np.uint8); a[(np.arange(n) // 1024) % 2 == 1] = top; cases.append(a)
+    for a in cases:
+        a = np.ascontiguousarray(a)
+        for inverse in (0, 1):
+            got = a.copy()
+            _lib.check(_lib.lib().sonic_ntt_fr(got.ctypes.data, log2n, inverse))
+            assert np.array_equal(got, orc.ntt(a, bool(inverse)))
+
+
 @pytest.mark.parametrize("na,nb", [(1, 1), (3, 5), (100, 37), (1025, 1024), (5000, 7000)])
 def test_poly_mul_matches_schoolbook(sonic, orc, na, nb):
     """the `*` of Constraints.hs:61 as a dense product, against the oracle's schoolbook convolution"""

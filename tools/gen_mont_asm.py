@@ -557,13 +557,15 @@ NTT_E0, NTT_TW, NTT_E1 = 164, 168, 172
 NTT_SPAN, NTT_TWB = "s70", "s[68:69]"
 
 
-def ntt_bfly_program(inverse: bool, U: int = NTT_U):
+def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
     """One stage's butterflies of a thread, values in the lazy range [0, 2r) (2r < 2^256), twiddles canonical:
         forward (DIF):  x = a + b,      y = (a - b) w        inverse (DIT):  t = b w,  x = a + t,  y = a - t
     a = LDS[e0], b = LDS[e0 + span], w = table[tw]; x and y go back where a and b came from.  A product of a value below 2r with a
     canonical twiddle is below r (2r / 2^256 + 1) < 1.91 r without any final subtraction, sums and differences are brought back
     below 2r by one conditional -+ 2r.  All loads are issued first; the products run one after another (they share the T / Q
     registers), the add / sub chains fill the slots around them.
+    unit: the stage whose twiddles are all 1 (span of one element): x = a + b, y = a - b in either direction, no loads from the
+    table, no product.
     Returns (prologue, scheduled body, epilogue) as instruction lists."""
     N, p = 8, R
     p2 = 2 * p
@@ -589,18 +591,20 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U):
     vp = lambda r: f"v[{r}:{r + 1}]"
     v4 = lambda r: f"v[{r}:{r + 3}]"
 
-    pre = [f"s_mov_b32 s{SP(j)}, 0x{limb32(p, j):08x}" for j in range(N)] + [f"s_mov_b32 s{SINV}, 0x{inv:08x}"]
+    pre = [] if unit else [f"s_mov_b32 s{SP(j)}, 0x{limb32(p, j):08x}" for j in range(N)] + [f"s_mov_b32 s{SINV}, 0x{inv:08x}"]
     for u in range(U):
         pre.append(f"v_add_u32_e32 {v(NTT_E1 + u)}, {NTT_SPAN}, {v(NTT_E0 + u)}")
         pre.append(f"ds_read_b128 {v4(Ar(u, 0))}, {v(NTT_E0 + u)}")
         pre.append(f"ds_read_b128 {v4(Ar(u, 4))}, {v(NTT_E0 + u)} offset:16")
         pre.append(f"ds_read_b128 {v4(Br(u, 0))}, {v(NTT_E1 + u)}")
         pre.append(f"ds_read_b128 {v4(Br(u, 4))}, {v(NTT_E1 + u)} offset:16")
-        pre.append(f"global_load_dwordx4 {v4(Wr(u, 0))}, {v(NTT_TW + u)}, {NTT_TWB}")
-        pre.append(f"global_load_dwordx4 {v4(Wr(u, 4))}, {v(NTT_TW + u)}, {NTT_TWB} offset:16")
-    for j in range(N + 1):
-        pre.append(f"v_mov_b32_e32 {v(TPhi(j))}, 0")
-    pre.append(f"v_mov_b32_e32 {v(TPlo(N))}, 0")
+        if not unit:
+            pre.append(f"global_load_dwordx4 {v4(Wr(u, 0))}, {v(NTT_TW + u)}, {NTT_TWB}")
+            pre.append(f"global_load_dwordx4 {v4(Wr(u, 4))}, {v(NTT_TW + u)}, {NTT_TWB} offset:16")
+    if not unit:
+        for j in range(N + 1):
+            pre.append(f"v_mov_b32_e32 {v(TPhi(j))}, 0")
+        pre.append(f"v_mov_b32_e32 {v(TPlo(N))}, 0")
     for j in range(N):
         pre.append(f"v_mov_b32_e32 {v(P2(j))}, 0x{limb32(p2, j):08x}")
 
@@ -691,7 +695,13 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U):
         regs = [v(Wr(u, j)) for j in range(N)]
         emit(f"s_waitcnt vmcnt({2 * (U - 1 - u)})", regs + after, regs)
 
-    if not inverse:
+    if unit:
+        for u in range(U):
+            add_lazy(W_(u), A_(u), B_(u), D1, CA1, CB1)           # (the twiddle registers are free: every butterfly has its own outputs)
+            store(NTT_E0 + u, W_(u))
+            sub_lazy(A_(u), A_(u), B_(u), D2, CA2, CB2)
+            store(NTT_E1 + u, A_(u))
+    elif not inverse:
         for u in range(U):
             add_lazy(X, A_(u), B_(u), D1, CA1, CB1)
             store(NTT_E0 + u, X)
@@ -712,35 +722,38 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U):
     return pre, prog, post
 
 
-def ntt_bfly_text(inverse: bool):
-    pre, prog, post = ntt_bfly_program(inverse)
+def ntt_bfly_text(inverse: bool, unit: bool = False):
+    pre, prog, post = ntt_bfly_program(inverse, unit=unit)
     return pre + schedule(prog) + post + ["s_setpc_b64 s[30:31]"]
 
 
-def ntt_bfly_cxx(inverse: bool) -> str:
-    name = "sonic_ntt_bfly4_inv" if inverse else "sonic_ntt_bfly4_fwd"
-    body = ntt_bfly_text(inverse)
+def ntt_bfly_cxx(inverse: bool, unit: bool = False) -> str:
+    name = "sonic_ntt_bfly4_unit" if unit else "sonic_ntt_bfly4_inv" if inverse else "sonic_ntt_bfly4_fwd"
+    body = ntt_bfly_text(inverse, unit)
     mads = sum(1 for l in body if l.startswith("v_mad_u64"))
     nops = sum(1 for l in body if l.startswith("s_nop"))
-    what = "t = b w, x = a + t, y = a - t" if inverse else "x = a + b, y = (a - b) w"
+    what = "x = a + b, y = a - b: the stage whose twiddles are all 1" if unit else "t = b w, x = a + t, y = a - t" if inverse else "x = a + b, y = (a - b) w"
     lines = routine_section(name, body, f"// {name}: {NTT_U} radix-2 butterflies ({what}) on Fr values in LDS, lazy range [0, 2r): {len(body)} instructions "
                                         f"({mads} v_mad_u64_u32, {nops} s_nop), VGPRs v0..v{NTT_NV - 1}")
     U = NTT_U
-    args = ", ".join([f"uint32_t e{u}" for u in range(U)] + [f"uint32_t t{u}" for u in range(U)] + ["uint32_t span", "const void* twiddles"])
-    lines.append(f"// e_u: LDS byte address of butterfly u's first element (the second one is `span` bytes further), t_u: byte offset of its twiddle from `twiddles`")
+    args = ", ".join([f"uint32_t e{u}" for u in range(U)] + ([] if unit else [f"uint32_t t{u}" for u in range(U)]) + ["uint32_t span"] + ([] if unit else ["const void* twiddles"]))
+    lines.append("// e_u: LDS byte address of butterfly u's first element (the second one is `span` bytes further)" + ("" if unit else ", t_u: byte offset of its twiddle from `twiddles`"))
     lines.append(f"__device__ __forceinline__ void {name}({args}) {{")
     lines.append("  asm volatile(")
+    k = 0
     for u in range(U):
-        lines.append(f'      "v_mov_b32_e32 v{NTT_E0 + u}, %{u}\\n\\t"')
-    for u in range(U):
-        lines.append(f'      "v_mov_b32_e32 v{NTT_TW + u}, %{U + u}\\n\\t"')
-    lines.append(f'      "s_mov_b32 {NTT_SPAN}, %{2 * U}\\n\\t"')
-    lines.append(f'      "s_mov_b64 {NTT_TWB}, %{2 * U + 1}\\n\\t"')
+        lines.append(f'      "v_mov_b32_e32 v{NTT_E0 + u}, %{k}\\n\\t"'); k += 1
+    if not unit:
+        for u in range(U):
+            lines.append(f'      "v_mov_b32_e32 v{NTT_TW + u}, %{k}\\n\\t"'); k += 1
+    lines.append(f'      "s_mov_b32 {NTT_SPAN}, %{k}\\n\\t"'); k += 1
+    if not unit:
+        lines.append(f'      "s_mov_b64 {NTT_TWB}, %{k}\\n\\t"'); k += 1
     lines.append('      "s_getpc_b64 s[56:57]\\n\\t"')
     lines.append(f'      "s_add_u32 s56, s56, {name}@rel32@lo+4\\n\\t"')
     lines.append(f'      "s_addc_u32 s57, s57, {name}@rel32@hi+12\\n\\t"')
     lines.append('      "s_swappc_b64 s[30:31], s[56:57]"')
-    ins = ", ".join([f'"v"(e{u})' for u in range(U)] + [f'"v"(t{u})' for u in range(U)] + ['"s"(span)', '"s"(twiddles)'])
+    ins = ", ".join([f'"v"(e{u})' for u in range(U)] + ([] if unit else [f'"v"(t{u})' for u in range(U)]) + ['"s"(span)'] + ([] if unit else ['"s"(twiddles)']))
     clob = [f'"v{k}"' for k in range(NTT_NV)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 71))] + ['"vcc"', '"scc"', '"memory"']
     lines.append("      :")
     lines.append(f"      : {ins}")
@@ -783,6 +796,8 @@ def render() -> str:
            ntt_bfly_cxx(False),
            "",
            ntt_bfly_cxx(True),
+           "",
+           ntt_bfly_cxx(False, unit=True),
            "}  // namespace sonic",
            "#endif", ""]
     return "\n".join(out)
