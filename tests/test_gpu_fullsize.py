@@ -210,3 +210,27 @@ def test_msm_full_size_properties(sonic, orc):
         pw[i] = pw[i - 1] * x0 % R
     got = msm_g1_srs(srs, 1, 1, fr_bytes(pw))
     assert got == orc.g1_mul(orc.g1_gen(), alpha * x % R * geom(x0 * x % R, 0, M - 1) % R)
+
+
+@pytest.mark.parametrize("log2n", [21, 24])
+def test_ntt_full_size_closed_form(sonic, log2n):
+    """the transforms at the bench size (2^21: ten wide stages in two passes) and with three wide passes (2^24: 5 + 4 + 4 stages),
+    beyond what the CPU oracle transforms in seconds: the transform of an input with three non-zero coefficients has the closed
+    form out[i] = sum_k c_k w^(k i), w = 7^((r-1)/2^log2n) (include/sonic_hip.h); sampled positions against python integers, and
+    the inverse transform of the result must be the input again.  (The product of src/Sonic/Constraints.hs:61 runs on these
+    transforms; the assembly butterflies keep values in [0, 2r) between the stages.)"""
+    from sonic_amd import _lib
+    n = 1 << log2n
+    pyr = random.Random(log2n)
+    w = pow(7, (R - 1) >> log2n, R)
+    terms = {0: R - 1, pyr.randrange(1, n): pyr.randrange(1, R), n - 1: pyr.randrange(1, R)}
+    a = np.zeros((n, 32), np.uint8)
+    for k, c in terms.items():
+        a[k] = np.frombuffer(c.to_bytes(32, "little"), np.uint8)
+    got = a.copy()
+    _lib.check(_lib.lib().sonic_ntt_fr(got.ctypes.data, log2n, 0))
+    for i in [0, 1, 2, n // 2, n - 1, 2047, 2048, 2049] + [pyr.randrange(n) for _ in range(56)]:
+        want = sum(c * pow(w, k * i, R) for k, c in terms.items()) % R
+        assert int.from_bytes(got[i].tobytes(), "little") == want, (log2n, i)
+    _lib.check(_lib.lib().sonic_ntt_fr(got.ctypes.data, log2n, 1))
+    assert np.array_equal(got, a)
