@@ -74,6 +74,10 @@ __device__ __forceinline__ Fr fr_canonical(const Fr& a) { return fp_add(a, Fr::z
 // (unit: the stage with a span of one element -- every twiddle is w^0 = 1, the butterfly is a sum and a difference)
 __device__ __forceinline__ void ntt_bfly4(int inverse, const uint32_t (&e0)[4], const uint32_t (&tj)[4], uint32_t span, const Fr* stw, bool unit = false) {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the generated routines exist in the device pass only)
+#if defined(SONIC_NTT_PROBE)              // timing probes (tools only; results are wrong): 1 = no butterflies at all, 2 = every stage as the unit stage
+  if (SONIC_NTT_PROBE == 1) return;
+  unit = true;
+#endif
   if (unit) sonic_ntt_bfly4_unit(e0[0], e0[1], e0[2], e0[3], span);
   else if (!inverse) sonic_ntt_bfly4_fwd(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
   else sonic_ntt_bfly4_inv(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
