@@ -410,8 +410,9 @@ def test_committed_header_is_generated():
 
 
 # ---- the NTT butterflies ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("U", [4, 2])
 @pytest.mark.parametrize("inverse,unit", [(False, False), (True, False), (False, True)])
-def test_ntt_butterfly_model(inverse, unit):
+def test_ntt_butterfly_model(inverse, unit, U):
     """four butterflies of one stage out of LDS: operands anywhere in the lazy range [0, 2r) (edge values included), twiddles
     canonical; results congruent to the radix-2 butterfly, again below 2r, written where the operands came from; no operand is
     read before the wait that covers its load, no carry inside the hazard window, no store's data rewritten under it"""
@@ -419,8 +420,9 @@ def test_ntt_butterfly_model(inverse, unit):
     Rm = 1 << 256
     Ri = pow(Rm, -1, p)
     rng = random.Random(77 + inverse)
-    body = G.ntt_bfly_text(inverse, unit)[:-1]             # without the return (unit: the stage whose twiddles are all 1)
-    assert not any(l.startswith("s_nop") for l in body) or sum(1 for l in body if l.startswith("s_nop")) <= 4
+    rg = G.ntt_regs(U)
+    body = G.ntt_bfly_text(inverse, unit, U)[:-1]             # without the return (unit: the stage whose twiddles are all 1)
+    assert sum(1 for l in body if l.startswith("s_nop")) <= 8
     edge = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p - 2, (1 << 255), (1 << 255) - 1]
     for it in range(12):
         lane = Lane()
@@ -429,15 +431,15 @@ def test_ntt_butterfly_model(inverse, unit):
         lane.s64[G.NTT_TWB] = twbase
         e0s, tws = [], []
         vals = []
-        for u in range(G.NTT_U):
-            e0 = 1024 * it + (32 * u if span >= 32 * G.NTT_U else 2 * span * u)        # the butterflies of a stage never share an element
+        for u in range(U):
+            e0 = 1024 * it + (32 * u if span >= 32 * U else 2 * span * u)        # the butterflies of a stage never share an element
             a = edge[(it + u) % len(edge)] if it < 6 else rng.randrange(2 * p)
             b = edge[(it * 3 + u + 1) % len(edge)] if it < 9 else rng.randrange(2 * p)
-            w = Rm % p if unit else [0, 1, p - 1, Rm % p][u] if it == 0 else rng.randrange(p)
+            w = Rm % p if unit else [0, 1, p - 1, Rm % p][(u + 2 * (U == 2)) % 4] if it == 0 else rng.randrange(p)
             t = 32 * rng.randrange(1 << 20)
             for k in range(N):
                 lane.lds[e0 + 4 * k], lane.lds[e0 + span + 4 * k], lane.glob[twbase + t + 4 * k] = limbs(a, N)[k], limbs(b, N)[k], limbs(w, N)[k]
-            lane.v[f"v{G.NTT_E0 + u}"], lane.v[f"v{G.NTT_TW + u}"] = e0, t
+            lane.v[f"v{rg['E0'] + u}"], lane.v[f"v{rg['TW'] + u}"] = e0, t
             e0s.append(e0); tws.append(t); vals.append((a, b, w))
         lane.run(body)
         lane.check_carry_hazard()

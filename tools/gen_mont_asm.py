@@ -549,12 +549,25 @@ def addsub_cxx(fname: str, cls: str, N: int, sub: bool, const: str = "p2") -> st
 
 # ---- NTT butterflies over Fr: the U butterflies a thread owns in one stage, operands in LDS, as ONE scheduled program ----------
 NTT_U = 4
-NTT_NV = 176            # VGPRs v0 .. v175
-# register map (VGPRs): T pairs v0..v17, Q pairs v18..v33, m v34, limbs of 2r v36..v43, butterfly u: a v[44+24u ..], b (+8), w (+16),
-# the sum x v140.. (the other results go where an operand was), chain temporaries v148.. / v156..; inputs: LDS byte address of the
-# butterfly's first element v164+u, byte offset of its twiddle v168+u (the second element's address goes to v172+u)
-NTT_E0, NTT_TW, NTT_E1 = 164, 168, 172
 NTT_SPAN, NTT_TWB = "s70", "s[68:69]"
+
+
+def ntt_regs(U: int = NTT_U):
+    """VGPR map of the butterfly routines: T pairs v0..v17, Q pairs v18..v33, m v34, limbs of 2r v36..v43, butterfly u: a v[44+24u ..],
+    b (+8), w (+16), then the sum x (8; the other results go where an operand was) and -- four butterflies per thread -- two banks of
+    chain temporaries (8 + 8).  The two-butterfly routines (four waves per SIMD: at most 128 VGPRs for the whole kernel) borrow the Q
+    pairs for those: their chains then wait for the products instead of filling slots between them.  Inputs: LDS byte address of the
+    butterfly's first element (E0 + u), byte offset of its twiddle (TW + u); the second element's address goes to E1 + u."""
+    top = 44 + 24 * U
+    if U >= 4:
+        x, d1, d2, nxt = top, top + 8, top + 16, top + 24
+    else:
+        x, d1, d2, nxt = top, 18, 26, top + 8
+    return {"X": x, "D1": d1, "D2": d2, "E0": nxt, "TW": nxt + U, "E1": nxt + 2 * U, "NV": nxt + 3 * U}
+
+
+NTT_NV = ntt_regs()["NV"]            # VGPRs v0 .. v175
+NTT_E0, NTT_TW, NTT_E1 = ntt_regs()["E0"], ntt_regs()["TW"], ntt_regs()["E1"]
 
 
 def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
@@ -578,10 +591,12 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
     Ar = lambda u, j: 44 + 24 * u + j
     Br = lambda u, j: 52 + 24 * u + j
     Wr = lambda u, j: 60 + 24 * u + j
-    X = lambda j: 140 + j
-    D1 = lambda j: 148 + j
-    D2 = lambda j: 156 + j
-    assert Wr(U - 1, 7) < 140
+    rg = ntt_regs(U)
+    X = lambda j: rg["X"] + j
+    D1 = lambda j: rg["D1"] + j
+    D2 = lambda j: rg["D2"] + j
+    NTT_E0, NTT_TW, NTT_E1 = rg["E0"], rg["TW"], rg["E1"]
+    assert Wr(U - 1, 7) < rg["X"]
     SP = lambda j: 36 + j
     SINV = 36 + N
     C1, C2, JUNK = "vcc", "s[50:51]", "s[54:55]"
@@ -722,20 +737,21 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
     return pre, prog, post
 
 
-def ntt_bfly_text(inverse: bool, unit: bool = False):
-    pre, prog, post = ntt_bfly_program(inverse, unit=unit)
+def ntt_bfly_text(inverse: bool, unit: bool = False, U: int = NTT_U):
+    pre, prog, post = ntt_bfly_program(inverse, U, unit=unit)
     return pre + schedule(prog) + post + ["s_setpc_b64 s[30:31]"]
 
 
-def ntt_bfly_cxx(inverse: bool, unit: bool = False) -> str:
-    name = "sonic_ntt_bfly4_unit" if unit else "sonic_ntt_bfly4_inv" if inverse else "sonic_ntt_bfly4_fwd"
-    body = ntt_bfly_text(inverse, unit)
+def ntt_bfly_cxx(inverse: bool, unit: bool = False, U: int = NTT_U) -> str:
+    name = f"sonic_ntt_bfly{U}_" + ("unit" if unit else "inv" if inverse else "fwd")
+    body = ntt_bfly_text(inverse, unit, U)
+    rg = ntt_regs(U)
+    NTT_E0, NTT_TW, NTT_NV = rg["E0"], rg["TW"], rg["NV"]
     mads = sum(1 for l in body if l.startswith("v_mad_u64"))
     nops = sum(1 for l in body if l.startswith("s_nop"))
     what = "x = a + b, y = a - b: the stage whose twiddles are all 1" if unit else "t = b w, x = a + t, y = a - t" if inverse else "x = a + b, y = (a - b) w"
-    lines = routine_section(name, body, f"// {name}: {NTT_U} radix-2 butterflies ({what}) on Fr values in LDS, lazy range [0, 2r): {len(body)} instructions "
+    lines = routine_section(name, body, f"// {name}: {U} radix-2 butterflies ({what}) on Fr values in LDS, lazy range [0, 2r): {len(body)} instructions "
                                         f"({mads} v_mad_u64_u32, {nops} s_nop), VGPRs v0..v{NTT_NV - 1}")
-    U = NTT_U
     args = ", ".join([f"uint32_t e{u}" for u in range(U)] + ([] if unit else [f"uint32_t t{u}" for u in range(U)]) + ["uint32_t span"] + ([] if unit else ["const void* twiddles"]))
     lines.append("// e_u: LDS byte address of butterfly u's first element (the second one is `span` bytes further)" + ("" if unit else ", t_u: byte offset of its twiddle from `twiddles`"))
     lines.append(f"__device__ __forceinline__ void {name}({args}) {{")
