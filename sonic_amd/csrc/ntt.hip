@@ -55,6 +55,10 @@ __device__ __forceinline__ long stage_off(int L, int s) { return (1L << L) - (1L
 // short workgroup per 256 elements a 2^23-point stage needed 8192 such grants and took 36 ms instead of 0.15 ms; a few hundred
 // long-lived workgroups need a few hundred.
 static const int WIDE_GRID = getenv("SONIC_NTT_GRID") ? atoi(getenv("SONIC_NTT_GRID")) : 512;
+// workgroup caps of the two transform kernels (tools/ntt_time.py: 2048-element blocks one per workgroup up to 1024 measure best alone
+// on the chip -- 0.444 against 0.465 ms for the LDS kernel at 512 -- and the same inside prove)
+static const int WIDE_BLOCKS = getenv("SONIC_NTT_WIDE_BLOCKS") ? atoi(getenv("SONIC_NTT_WIDE_BLOCKS")) : 4 * WIDE_GRID;      // k_ntt_wide
+static const int LOCAL_BLOCKS = getenv("SONIC_NTT_LOCAL_BLOCKS") ? atoi(getenv("SONIC_NTT_LOCAL_BLOCKS")) : 2 * WIDE_GRID;    // k_ntt_local
 static inline int wide_grid(long items) { long g = (items + 255) / 256; return (int)(g < WIDE_GRID ? g : WIDE_GRID); }
 
 // Several consecutive WIDE stages in one pass through HBM (round 4; before: two per pass as radix-4 butterflies in registers, 6 passes
@@ -234,14 +238,14 @@ static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool 
   for (int p = 0, s = 0; p < passes; p++) { count[p] = nglobal / passes + (p < nglobal % passes ? 1 : 0); first[p] = s; s += count[p]; }
   auto wide = [&](int p, const Fr* scale) {
     const long items = (1L << first[p]) << (log2n - first[p] - count[p] - (WIDE_ELEMS_LOG - count[p]));
-    LAUNCH(k_ntt_wide, (int)std::min<long>(items, 4L * WIDE_GRID), 256, 0, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);
+    LAUNCH(k_ntt_wide, (int)std::min<long>(items, WIDE_BLOCKS), 256, 0, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);
   };
   if (!inverse) {
     for (int p = 0; p < passes; p++) wide(p, nullptr);
-    local_launch(st, (int)std::min<long>(n >> tile_log, WIDE_GRID), lds, d, table, log2n, tile_log, tw_shift, 0, nullptr, nullptr);
+    local_launch(st, (int)std::min<long>(n >> tile_log, LOCAL_BLOCKS), lds, d, table, log2n, tile_log, tw_shift, 0, nullptr, nullptr);
   } else {
     const Fr* ninv = tw.ninv.as<Fr>() + log2n;
-    local_launch(st, (int)std::min<long>(n >> tile_log, WIDE_GRID), lds, d, table, log2n, tile_log, tw_shift, 1, nglobal == 0 ? ninv : nullptr, mul);
+    local_launch(st, (int)std::min<long>(n >> tile_log, LOCAL_BLOCKS), lds, d, table, log2n, tile_log, tw_shift, 1, nglobal == 0 ? ninv : nullptr, mul);
     for (int p = passes - 1; p >= 0; p--) wide(p, p == 0 ? ninv : nullptr);      // the last pass also scales by 1/n
   }
 }
