@@ -250,12 +250,13 @@ def main():
             _lib.check(L.sonic_poly_mul_fr_dev(da, na, db, nb, do))
         L.sonic_profile_enable(0)
         per = {}
-        for nm in ("k_ntt_wide", "k_ntt_local", "k_fr_pointwise_mul"):
+        for nm in ("k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4", "k_fr_pointwise_mul"):       # (…4: the SONIC_NTT_WAVES=2 variants)
             ms, cnt = C.c_double(), C.c_int64()
             L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
             per[nm] = {"ms_per_product": round(ms.value / reps, 4), "launches_per_product": cnt.value // reps}
         t_ms = sum(v["ms_per_product"] for v in per.values())
-        passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_wide", "k_ntt_local")) // 3
+        passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4")) // 3
+        per = {k: v for k, v in per.items() if v["launches_per_product"] or k in ("k_ntt_wide", "k_ntt_local")}
         alg = 288.0 * M
         ntt = {"bound": "hbm", "kernel": "three radix-2 transforms of size M, the pointwise product folded into the inverse transform's first load (k_ntt_wide / k_ntt_local)",
                "M": M, "achieved": round(alg / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -264,7 +265,7 @@ def main():
                "hbm_passes_per_transform": passes, "bytes_by_design": float((3 * passes * 64 + 96) * M),
                "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
                "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS (round 4) the transforms "
-                       "are bound by VALU issue: 348 instructions per butterfly in the generated assembly routines sonic_ntt_bfly4_fwd / _inv (DESIGN.md section 5)"}
+                       "are bound by VALU issue: ~356 instructions per butterfly in the generated assembly routines sonic_ntt_bfly2_fwd / _inv (DESIGN.md section 5)"}
         for ptr in (da, db, do):
             L.sonic_dev_free(ptr)
 

@@ -55,51 +55,62 @@ __device__ __forceinline__ long stage_off(int L, int s) { return (1L << L) - (1L
 // short workgroup per 256 elements a 2^23-point stage needed 8192 such grants and took 36 ms instead of 0.15 ms; a few hundred
 // long-lived workgroups need a few hundred.
 static const int WIDE_GRID = getenv("SONIC_NTT_GRID") ? atoi(getenv("SONIC_NTT_GRID")) : 512;
-// workgroup caps of the two transform kernels (tools/ntt_time.py: 2048-element blocks one per workgroup up to 1024 measure best alone
-// on the chip -- 0.444 against 0.465 ms for the LDS kernel at 512 -- and the same inside prove)
-static const int WIDE_BLOCKS = getenv("SONIC_NTT_WIDE_BLOCKS") ? atoi(getenv("SONIC_NTT_WIDE_BLOCKS")) : 4 * WIDE_GRID;      // k_ntt_wide
-static const int LOCAL_BLOCKS = getenv("SONIC_NTT_LOCAL_BLOCKS") ? atoi(getenv("SONIC_NTT_LOCAL_BLOCKS")) : 2 * WIDE_GRID;    // k_ntt_local
+// workgroup caps of the two transform kernels (tools/ntt_time.py: one block or tile per workgroup up to these caps measures best alone
+// on the chip -- 0.444 against 0.465 ms for the LDS kernel at 1024 against 512 workgroups -- and the same inside prove)
+static const int WIDE_BLOCKS = getenv("SONIC_NTT_WIDE_BLOCKS") ? atoi(getenv("SONIC_NTT_WIDE_BLOCKS")) : 4 * WIDE_GRID;      // 2048-element blocks (twice as many of 1024)
+static const int LOCAL_BLOCKS = getenv("SONIC_NTT_LOCAL_BLOCKS") ? atoi(getenv("SONIC_NTT_LOCAL_BLOCKS")) : 2 * WIDE_GRID;    // 2048-element tiles
 static inline int wide_grid(long items) { long g = (items + 255) / 256; return (int)(g < WIDE_GRID ? g : WIDE_GRID); }
 
 // Several consecutive WIDE stages in one pass through HBM (round 4; before: two per pass as radix-4 butterflies in registers, 6 passes
 // per 2^21-point transform, each bound by the ~4 TB/s its 32-byte strided accesses reach).  Stages s0 .. s0 + ns - 1 only connect
 // elements whose indices differ in the ns bits below bit log2n - s0: a workgroup takes the 2^ns "rows" i = base + k * stride
-// (stride = 2^(log2n - s0 - ns)) for C consecutive columns -- 2048 elements, 64 KB of LDS, C x 32 B contiguous per row -- runs the ns
+// (stride = 2^(log2n - s0 - ns)) for C consecutive columns -- 1024 elements, 32 KB of LDS, C x 32 B contiguous per row -- runs the ns
 // stages out of LDS and writes the block back in place.  Ten wide stages are two passes of five.
 //
-// The butterflies are the generated routines sonic_ntt_bfly4_fwd / _inv (mont_asm.hpp): the four butterflies a thread owns in a stage
-// as one scheduled program that reads its operands from LDS and its twiddles from the stage-major table, in the lazy range [0, 2r).
+// The butterflies are the generated routines sonic_ntt_bfly2_fwd / _inv / _unit (mont_asm.hpp): the butterflies a thread owns in a
+// stage as one scheduled program that reads its operands from LDS and its twiddles from the stage-major table, in the lazy range
+// [0, 2r).  Two per thread keep a kernel within 128 VGPRs -- four waves per SIMD, which hide each other's LDS round trips and barriers
+// (the four-per-thread routines, two waves per SIMD, are kept behind SONIC_NTT_WAVES=2: 7 % slower).
 // Values are canonical again where they leave the transform: the forward transform's last store, the inverse transform's 1/n scaling.
-static constexpr int WIDE_ELEMS_LOG = 11;      // elements per workgroup block
-static_assert((1 << WIDE_ELEMS_LOG) == 2 * 4 * 256, "four butterflies per thread of a 256-thread workgroup");
+static constexpr int WIDE_ELEMS_LOG = 11;      // elements per workgroup block (four butterflies per thread; 10 with two)
 
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }      // the low half of a flat LDS pointer is the LDS offset
 __device__ __forceinline__ Fr fr_canonical(const Fr& a) { return fp_add(a, Fr::zero()); }              // [0, 2r) -> [0, r)
-// (unit: the stage with a span of one element -- every twiddle is w^0 = 1, the butterfly is a sum and a difference)
-__device__ __forceinline__ void ntt_bfly4(int inverse, const uint32_t (&e0)[4], const uint32_t (&tj)[4], uint32_t span, const Fr* stw, bool unit = false) {
+// U butterflies of a thread in one stage (unit: the stage with a span of one element -- every twiddle is w^0 = 1, the butterfly is a
+// sum and a difference).  U = 4: 176 VGPRs inside the routine, two waves per SIMD; U = 2: 106, four waves per SIMD.
+template <int U>
+__device__ __forceinline__ void ntt_bfly(int inverse, const uint32_t (&e0)[U], const uint32_t (&tj)[U], uint32_t span, const Fr* stw, bool unit = false) {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the generated routines exist in the device pass only)
 #if defined(SONIC_NTT_PROBE)              // timing probes (tools only; results are wrong): 1 = no butterflies at all, 2 = every stage as the unit stage
   if (SONIC_NTT_PROBE == 1) return;
   unit = true;
 #endif
-  if (unit) sonic_ntt_bfly4_unit(e0[0], e0[1], e0[2], e0[3], span);
-  else if (!inverse) sonic_ntt_bfly4_fwd(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
-  else sonic_ntt_bfly4_inv(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
+  if constexpr (U == 4) {
+    if (unit) sonic_ntt_bfly4_unit(e0[0], e0[1], e0[2], e0[3], span);
+    else if (!inverse) sonic_ntt_bfly4_fwd(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
+    else sonic_ntt_bfly4_inv(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
+  } else {
+    if (unit) sonic_ntt_bfly2_unit(e0[0], e0[1], span);
+    else if (!inverse) sonic_ntt_bfly2_fwd(e0[0], e0[1], tj[0], tj[1], span, stw);
+    else sonic_ntt_bfly2_inv(e0[0], e0[1], tj[0], tj[1], span, stw);
+  }
 #endif
 }
 
-__global__ __launch_bounds__(256, 2) void k_ntt_wide(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
-                                                     const Fr* __restrict__ scale) {
-  __shared__ __attribute__((aligned(16))) Fr sh[1 << WIDE_ELEMS_LOG];
+// ELOG: log2 of the block's elements = 2 U x 256 threads
+template <int U, int ELOG>
+__device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
+                                              const Fr* __restrict__ scale) {
+  static_assert((1 << ELOG) == 2 * U * 256, "U butterflies per thread of a 256-thread workgroup");
   const uint32_t lds0 = lds_address(sh);
-  const int lc = WIDE_ELEMS_LOG - ns;                       // log2 C
+  const int lc = ELOG - ns;                                 // log2 C
   const int lstride = log2n - s0 - ns;                      // log2 of the row stride
   const long col_blocks = 1L << (lstride - lc);
   const long nitems = col_blocks << s0;
   for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
     const long u = item >> (lstride - lc), cb = item & (col_blocks - 1);
     const long base = (u << (log2n - s0)) + (cb << lc);
-    for (int e = threadIdx.x; e < (1 << WIDE_ELEMS_LOG); e += 256) sh[e] = d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))];
+    for (int e = threadIdx.x; e < (1 << ELOG); e += 256) sh[e] = d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))];
     __syncthreads();
     for (int t = 0; t < ns; t++) {
       const int tt = inverse ? ns - 1 - t : t;               // forward (DIF): widest span first; inverse (DIT): the reverse
@@ -107,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void k_ntt_wide(Fr* __restrict__ d, const F
       const int hb = ns - 1 - tt;                            // the row bit this stage pairs
       const int lhalf = log2n - 1 - s;                       // log2 of the butterfly span in elements
       const Fr* stw = tw + stage_off(log2n + tw_shift, s + tw_shift);
-      uint32_t e0[4], tj[4];
+      uint32_t e0[U], tj[U];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < U; q++) {
         const int bt = threadIdx.x + q * 256;
         const int c = bt & ((1 << lc) - 1), kp = bt >> lc;
         const int k = ((kp >> hb) << (hb + 1)) | (kp & ((1 << hb) - 1));         // row with bit hb clear
@@ -118,28 +129,40 @@ __global__ __launch_bounds__(256, 2) void k_ntt_wide(Fr* __restrict__ d, const F
         tj[q] = (uint32_t)j * (uint32_t)sizeof(Fr);
       }
       const uint32_t span = (uint32_t)sizeof(Fr) << (hb + lc);
-      ntt_bfly4(inverse, e0, tj, span, stw);
+      ntt_bfly<U>(inverse, e0, tj, span, stw);
       __syncthreads();
     }
     if (scale) {
       const Fr sc = *scale;
-      for (int e = threadIdx.x; e < (1 << WIDE_ELEMS_LOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = fp_mul(sh[e], sc);
+      for (int e = threadIdx.x; e < (1 << ELOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = fp_mul(sh[e], sc);
     } else {
-      for (int e = threadIdx.x; e < (1 << WIDE_ELEMS_LOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = sh[e];
+      for (int e = threadIdx.x; e < (1 << ELOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = sh[e];
     }
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256, 2) void k_ntt_wide4(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
+                                                     const Fr* __restrict__ scale) {
+  __shared__ __attribute__((aligned(16))) Fr sh[1 << WIDE_ELEMS_LOG];
+  ntt_wide_body<4, WIDE_ELEMS_LOG>(sh, d, tw, log2n, s0, ns, tw_shift, inverse, scale);
+}
+// the default: 1024-element blocks, two butterflies per thread, four workgroups per CU (SONIC_NTT_WAVES=2 selects the kernel above)
+__global__ __launch_bounds__(256, 4) void k_ntt_wide(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
+                                                      const Fr* __restrict__ scale) {
+  __shared__ __attribute__((aligned(16))) Fr sh[1 << (WIDE_ELEMS_LOG - 1)];
+  ntt_wide_body<2, WIDE_ELEMS_LOG - 1>(sh, d, tw, log2n, s0, ns, tw_shift, inverse, scale);
+}
 
 // all stages with span <= tile, fused in LDS.  tile_log = min(log2n, TILE_LOG).  Full tiles (2048 elements: every transform the prover
-// runs) go through the generated butterflies, four per thread and stage; smaller transforms through the plain C++ ones.
-__global__ __launch_bounds__(256, 2) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
-                                                      int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
+// runs) go through the generated butterflies, U per thread and stage (1024 / U threads); smaller transforms through the plain C++ ones.
+template <int U>
+__device__ __forceinline__ void ntt_local_body(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
+                                               int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Fr* sh = reinterpret_cast<Fr*>(smem);
   const uint32_t lds0 = lds_address(sh);
   const int tile = 1 << tile_log;
-  constexpr int THREADS = 256;
+  constexpr int THREADS = 1024 / U;
   const long ntiles = 1L << (log2n - tile_log);
   for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {       // grid-stride over the tiles (see WIDE_GRID)
   const long base = tl << tile_log;
@@ -154,16 +177,16 @@ __global__ __launch_bounds__(256, 2) void k_ntt_local(Fr* __restrict__ d, const 
       const int hl = inverse ? k : TILE_LOG - 1 - k;       // log2(half)
       const int s = log2n - 1 - hl;
       const Fr* stw = tw + stage_off(log2n + tw_shift, s + tw_shift);
-      uint32_t e0[4], tj[4];
+      uint32_t e0[U], tj[U];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < U; q++) {
         const int bt = threadIdx.x + q * THREADS;
         const int j = bt & ((1 << hl) - 1);
         e0[q] = lds0 + (uint32_t)((((bt >> hl) << (hl + 1)) + j) * (int)sizeof(Fr));
         tj[q] = (uint32_t)(j * (int)sizeof(Fr));
       }
       const uint32_t span = (uint32_t)sizeof(Fr) << hl;
-      ntt_bfly4(inverse, e0, tj, span, stw, hl == 0);
+      ntt_bfly<U>(inverse, e0, tj, span, stw, hl == 0);
       __syncthreads();
     }
     // the lazy range ends here: canonical out of the forward transform (and out of an inverse one that is scaled here)
@@ -189,6 +212,14 @@ __global__ __launch_bounds__(256, 2) void k_ntt_local(Fr* __restrict__ d, const 
   }
   __syncthreads();
   }
+}
+__global__ __launch_bounds__(256, 2) void k_ntt_local4(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
+                                                      int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
+  ntt_local_body<4>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
+}
+__global__ __launch_bounds__(512, 2) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
+                                                       int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
+  ntt_local_body<2>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
 }
 
 __global__ __launch_bounds__(256) void k_fr_scale(Fr* __restrict__ a, long n, const Fr* __restrict__ s) {
@@ -220,8 +251,12 @@ void NttTables::ensure(hipStream_t st, int need) {
   log2n = need;
 }
 
+// waves per SIMD the transform kernels are built for: 4 (two butterflies per thread, <= 128 VGPRs; default: 0.87 against 0.93 ms per product
+// at M = 2^21, 3.20 against 3.48 at 2^23) or 2 (four butterflies per thread: k_ntt_wide4 / k_ntt_local4)
+static const int NTT_WAVES = getenv("SONIC_NTT_WAVES") ? atoi(getenv("SONIC_NTT_WAVES")) : 4;
 static void local_launch(hipStream_t st, int grid, size_t lds, Fr* d, const Fr* table, int log2n, int tile_log, int tw_shift, int inverse, const Fr* scale, const Fr* mul) {
-  LAUNCH(k_ntt_local, grid, 256, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
+  if (NTT_WAVES == 4) LAUNCH(k_ntt_local, grid, 512, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
+  else LAUNCH(k_ntt_local4, grid, 256, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
 }
 static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool inverse, const Fr* mul = nullptr) {
   if (log2n == 0) return;
@@ -237,8 +272,10 @@ static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool 
   int first[8], count[8];
   for (int p = 0, s = 0; p < passes; p++) { count[p] = nglobal / passes + (p < nglobal % passes ? 1 : 0); first[p] = s; s += count[p]; }
   auto wide = [&](int p, const Fr* scale) {
-    const long items = (1L << first[p]) << (log2n - first[p] - count[p] - (WIDE_ELEMS_LOG - count[p]));
-    LAUNCH(k_ntt_wide, (int)std::min<long>(items, WIDE_BLOCKS), 256, 0, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);
+    const int elog = NTT_WAVES == 4 ? WIDE_ELEMS_LOG - 1 : WIDE_ELEMS_LOG;
+    const long items = 1L << (log2n - elog);
+    if (NTT_WAVES == 4) LAUNCH(k_ntt_wide, (int)std::min<long>(items, 2L * WIDE_BLOCKS), 256, 0, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);
+    else LAUNCH(k_ntt_wide4, (int)std::min<long>(items, WIDE_BLOCKS), 256, 0, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);
   };
   if (!inverse) {
     for (int p = 0; p < passes; p++) wide(p, nullptr);

@@ -814,6 +814,12 @@ def render() -> str:
            ntt_bfly_cxx(True),
            "",
            ntt_bfly_cxx(False, unit=True),
+           "",
+           ntt_bfly_cxx(False, U=2),
+           "",
+           ntt_bfly_cxx(True, U=2),
+           "",
+           ntt_bfly_cxx(False, unit=True, U=2),
            "}  // namespace sonic",
            "#endif", ""]
     return "\n".join(out)
