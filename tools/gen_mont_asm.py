@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates sonic_amd/csrc/mont_asm.hpp: hand-scheduled gfx950 assembly for the Montgomery
-product over Fq (12 x u32) and Fr (8 x u32).
+product over Fq (12 x u32) and Fr (8 x u32), the fused point additions and the NTT butterflies built on it.
 
 Why assembly: hipcc lowers the C++ CIOS loop to 288 v_mad_u64_u32 plus ~950 v_mov / v_lshl_add_u64
 (it materialises every 64-bit addend), i.e. ~1250 VALU instructions per Fq product.  The routine
@@ -21,6 +21,9 @@ return address s[30:31]; clobbers v[2N : 6N+3), s[36:57], vcc, scc.  The C++ wra
 constraints, moves them to / from the routine's fixed registers inside the asm text and calls with s_swappc_b64.
 Fq runs in the lazy range [0, 2q) (no final conditional subtraction; result in the low halves of T); the "core" variant
 leaves the prologue to its caller, the fused mixed addition sonic_g1_madd_asm (fused_madd_cxx below).
+
+The same scheduler also builds the NTT butterfly routines (ntt_bfly_program): the two (or four) radix-2 butterflies a thread owns in
+one stage as ONE program with the LDS reads, the twiddle loads and the LDS writes inside, Fr values in the lazy range [0, 2r).
 
 Run from the repo root:  python tools/gen_mont_asm.py
 """
