@@ -255,6 +255,7 @@ def main():
             L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
             per[nm] = {"ms_per_product": round(ms.value / reps, 4), "launches_per_product": cnt.value // reps}
         t_ms = sum(v["ms_per_product"] for v in per.values())
+        pmc_ntt, pmc_ntt_src = load_profile_json("pmc_ntt.json")        # committed rocprofv3 --pmc passes of tools/ntt_time.py (per product, M = 2^21)
         passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4")) // 3
         per = {k: v for k, v in per.items() if v["launches_per_product"] or k in ("k_ntt_wide", "k_ntt_local")}
         alg = 288.0 * M
@@ -264,6 +265,8 @@ def main():
                "algorithmic_bytes": alg, "algorithmic_bytes_rule": "288 M: each transform reads and writes M x 32 B once (3 x 64 M) + 96 M for the pointwise product (SURVEY 8d lower bound)",
                "hbm_passes_per_transform": passes, "bytes_by_design": float((3 * passes * 64 + 96) * M),
                "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
+               "traffic": (pmc_ntt or {}).get("hbm_bytes_per_product") if M == (pmc_ntt or {}).get("M") else None, "traffic_source": pmc_ntt_src,
+               "rocprof_ms_per_product": (pmc_ntt or {}).get("rocprof_ms_per_product"),
                "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS (round 4) the transforms "
                        "are bound by VALU issue: ~356 instructions per butterfly in the generated assembly routines sonic_ntt_bfly2_fwd / _inv (DESIGN.md section 5)"}
         for ptr in (da, db, do):

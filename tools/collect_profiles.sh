@@ -12,6 +12,11 @@ python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/ba_bench > $OUT/ba_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm_only -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 5 --warmup 1 > $OUT/msm_only.json 2> $OUT/msm_only.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python3 bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
+# the NTT product alone (roofline_ntt's kernels): per-kernel durations as the profiler sees them, and their HBM traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt_only -o t -- python3 tools/ntt_time.py > $OUT/ntt_only.txt 2> $OUT/ntt_only.err
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/ntt_pmc_$C -o t -- python3 tools/ntt_time.py > /dev/null 2> $OUT/ntt_pmc_$C.err
+done
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done

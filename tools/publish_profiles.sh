@@ -9,6 +9,11 @@ for f in bench.json microbench.txt ba_bench.txt bucket_tree.txt prove_strong_emu
 done
 cp $(find $IN/msm_only -name "*kernel_stats.csv" | head -1) $P/${TAG}_msm_only_kernel_stats.csv
 cp $(find $IN/bench_prof -name "*kernel_stats.csv" | head -1) $P/${TAG}_bench_kernel_stats.csv
+[ -d $IN/ntt_only ] && cp $(find $IN/ntt_only -name "*kernel_stats.csv" | head -1) $P/${TAG}_ntt_only_kernel_stats.csv && cp $IN/ntt_only.txt $P/${TAG}_ntt_only.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  [ -d $IN/ntt_pmc_$C ] && cp $(find $IN/ntt_pmc_$C -name "*counter_collection.csv" | head -1) $P/${TAG}_ntt_pmc_${C}_counter_collection.csv
+done
+[ -d $IN/ntt_pmc_WRITE_SIZE ] && python3 tools/pmc_ntt_summary.py $P/${TAG}_ntt_pmc_FETCH_SIZE_counter_collection.csv $P/${TAG}_ntt_pmc_WRITE_SIZE_counter_collection.csv $P/${TAG}_ntt_only_kernel_stats.csv > $P/${TAG}_pmc_ntt.json
 for C in FETCH_SIZE WRITE_SIZE SQ; do
   cp $(find $IN/pmc_$C -name "*counter_collection.csv" | head -1) $P/${TAG}_pmc_${C}_counter_collection.csv
 done
