@@ -362,3 +362,35 @@ def test_bench_under_the_driver_launch_line_one_rank_rccl():
     assert ps["n"] == 1 << 13 and ps["n_gpus"] == 1 and ps["ms_per_proof"] > 0
     assert ps["emulated_shares"]["world"] == 8 and ps["emulated_shares"]["combined_equals_whole_proof"] is True
     assert j["north_star"]["n"] == 1 << 13 and j["north_star"]["ms_per_proof"] == ps["ms_per_proof"]
+
+
+_NTT_ALT = r"""
+import sys, hashlib
+sys.path.insert(0, "tests")
+import numpy as np
+from sonic_amd import _lib
+from util import rand_fr_array
+L = _lib.lib(); _lib.check(L.sonic_init(0))
+h = hashlib.sha256()
+for log2n in (11, 13, 16):
+    a = rand_fr_array(np.random.default_rng(log2n), 1 << log2n)
+    for inverse in (0, 1):
+        got = a.copy(); _lib.check(L.sonic_ntt_fr(got.ctypes.data, log2n, inverse)); h.update(got.tobytes())
+g = np.random.default_rng(9)
+pa, pb = rand_fr_array(g, 5000), rand_fr_array(g, 7000)
+out = np.zeros((11999, 32), np.uint8)
+_lib.check(L.sonic_poly_mul_fr(pa.ctypes.data, 5000, pb.ctypes.data, 7000, out.ctypes.data)); h.update(out.tobytes())
+print("NTT_DIGEST", h.hexdigest())
+"""
+
+
+def test_ntt_kernel_variants_agree():
+    """the transform kernels exist in two builds of the same generated butterflies -- two per thread and four waves per SIMD (the
+    default), four per thread and two waves (SONIC_NTT_WAVES=2) -- and in any workgroup cap (SONIC_NTT_GRID): same bytes from all of
+    them (the default build is the one tests/test_gpu_parity.py holds against the oracle)"""
+    digests = []
+    for extra in ({}, {"SONIC_NTT_WAVES": "2"}, {"SONIC_NTT_GRID": "3"}, {"SONIC_NTT_WAVES": "2", "SONIC_NTT_GRID": "5"}):
+        out = subprocess.run([sys.executable, "-c", _NTT_ALT], cwd=ROOT, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "NTT_DIGEST" in out.stdout, out.stderr[-3000:]
+        digests.append(out.stdout.split("NTT_DIGEST")[1].split()[0])
+    assert len(set(digests)) == 1, digests
