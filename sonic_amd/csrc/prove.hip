@@ -1373,7 +1373,7 @@ static NttTables& shared_ntt() { static NttTables* t = new NttTables(); return *
 
 int sonic_ntt_fr(uint8_t* data, int log2n, int inverse) {
   API_BEGIN
-  if (!data || log2n < 0 || log2n > 28) return SONIC_ERR_INVALID_ARG;
+  if (!data || log2n < 0 || log2n > 27) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(call_mutex());
   hipStream_t st = default_stream();
   const long n = 1L << log2n;
