@@ -162,7 +162,7 @@ int sonic_msm_lane_sync(sonic_msm_lane_t* lane);
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]);
 /* the same for k device-side results of SONIC_G1_DEV_PARTIAL_BYTES each (host only) */
 int sonic_g1_sum_dev_partials(const uint8_t* blobs, int k, uint8_t out_g1[96]);
-/* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n) */
+/* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n); 0 <= log2n <= 27 (SONIC_ERR_INVALID_ARG beyond) */
 int sonic_ntt_fr(uint8_t* data, int log2n, int inverse);
 /* dense product of two coefficient arrays (the `*` at Constraints.hs:61): out has na+nb-1 Fr */
 int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out);

@@ -399,6 +399,15 @@ def test_ntt_matches_oracle(sonic, orc, log2n):
     assert np.array_equal(rt, a)
 
 
+def test_ntt_size_limit(sonic):
+    """2^27 points is the largest transform (32-bit twiddle offsets inside the butterfly routines): beyond it the call is refused
+    before anything is read"""
+    from sonic_amd import _lib
+    buf = np.zeros((4, 32), np.uint8)
+    for log2n in (28, 40, -1):
+        assert _lib.lib().sonic_ntt_fr(buf.ctypes.data, log2n, 0) == 7        # SONIC_ERR_INVALID_ARG
+
+
 @pytest.mark.parametrize("log2n", [11, 12, 16])
 def test_ntt_extreme_inputs(sonic, orc, log2n):
     """the assembly butterflies keep values in [0, 2r) between stages (sums pass 2^256, differences borrow): inputs that sit on the
