@@ -120,13 +120,21 @@ HD G1XYZZ g1_add_mixed(const G1XYZZ& acc, const G1Affine& q) {
 // The same addition for the bucket walks: on the device the whole formula is one generated asm statement around ten calls of
 // the product core (mont_asm.hpp, sonic_g1_madd_asm); lanes in an exceptional position come back flagged and unchanged and are
 // redone by the general function above.
-HD G1XYZZ g1_add_mixed_walk(G1XYZZ acc, const G1Affine& q) {
+// negy != 0: acc - q (the sign of a signed digit: the fused statement negates q.y on the way into its first product -- 24
+// instructions instead of the ~95 of a 12-limb negation in C++ ahead of it).
+HD G1XYZZ g1_add_mixed_walk(G1XYZZ acc, const G1Affine& q, uint32_t negy = 0) {
 #if SONIC_FQ_LAZY && !defined(SONIC_NO_FUSED_MADD)
   const uint32_t special = (acc.is_inf() || q.is_inf()) ? 1u : 0u;
-  if (sonic_g1_madd_asm(acc, q.x, q.y, special)) acc = g1_add_mixed(acc, q);
+  if (sonic_g1_madd_asm(acc, q.x, q.y, special, negy)) {
+    G1Affine t = q;
+    if (negy) t.y = fp_neg(t.y);
+    acc = g1_add_mixed(acc, t);
+  }
   return acc;
 #else
-  return g1_add_mixed(acc, q);
+  G1Affine t = q;
+  if (negy) t.y = fp_neg(t.y);
+  return g1_add_mixed(acc, t);
 #endif
 }
 

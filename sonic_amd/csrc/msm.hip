@@ -572,8 +572,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
     for (uint32_t e = beg + 2; e < end; e++) {
       const uint32_t e_nn = entries[e + 2 <= last ? e + 2 : last];
       const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
-      if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
-      acc = g1_add_mixed_walk(acc, p_cur);
+      acc = g1_add_mixed_walk(acc, p_cur, e_cur >> 31);          // (bit 31 of an entry: the digit's sign)
       p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
     }
   }
@@ -607,8 +606,7 @@ __global__ __launch_bounds__(256, 2) void k_heavy_accum(const MsmBatchDev batch,
       for (; e < end; e += 256) {
         const uint32_t e_nn = entries[e + 512 <= last ? e + 512 : last];
         const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
-        if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
-        acc = g1_add_mixed_walk(acc, p_cur);
+        acc = g1_add_mixed_walk(acc, p_cur, e_cur >> 31);
         p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
       }
     }

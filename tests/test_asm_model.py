@@ -328,7 +328,7 @@ def xyzz_madd(p, X1, Y1, ZZ1, ZZZ1, x2, y2):
     return X3, Y3, mul(ZZ1, PP), mul(ZZZ1, PPP)
 
 
-def run_fused(acc, q, special, affine_acc=False):
+def run_fused(acc, q, special, affine_acc=False, negy=0):
     N, p = 12, G.Q
     L, nv = G.fused_madd_program(p, affine_acc)
     cores = {"sonic_mont_mul_fq_core": G.function_text("core", N, p, lazy=True, core=True)[0],
@@ -342,6 +342,7 @@ def run_fused(acc, q, special, affine_acc=False):
         for j in range(N):
             lane.v[f"%{4 * N + 1 + k * N + j}"] = limbs(q[k], N)[j]
     lane.v[f"%{6 * N + 1}"] = special
+    lane.v[f"%{6 * N + 2}"] = negy
     lane.run(L)
     assert lane.exec is True, "EXEC not restored"
     lane.check_carry_hazard()
@@ -361,6 +362,18 @@ def test_fused_mixed_addition_model():
             acc[1] = 0                               # Y1 = 0: the negated operand of the two-product core is 2q itself
         want = xyzz_madd(p, *acc, *q)
         got, exc = run_fused([rep(v) for v in acc], [rep(v) for v in q], 0)
+        assert exc == 0 and all(g < 2 * p for g in got)
+        assert [g % p for g in got] == list(want)
+    # the sign of a signed digit: negy != 0 adds (q.x, -q.y), for either representative of q.y and for q.y = 0 (whose negation is the
+    # representative 2q: the product takes it; such a point is of order two -- not on this curve's prime-order part, but the
+    # statement must not care)
+    for it in range(12):
+        acc = [rng.randrange(p) for _ in range(4)]
+        q = [rng.randrange(p) for _ in range(2)]
+        if it == 0:
+            q[1] = 0
+        want = xyzz_madd(p, *acc, q[0], (-q[1]) % p)
+        got, exc = run_fused([rep(v) for v in acc], [rep(q[0]), rep(q[1]) if q[1] else 0], 0, negy=1 + it)
         assert exc == 0 and all(g < 2 * p for g in got)
         assert [g % p for g in got] == list(want)
     # U2 == X1 (the doubling / cancellation position): flagged, accumulator untouched -- with U2 - X1 represented as 0 or as q

@@ -341,7 +341,8 @@ def fused_madd_program(p: int, affine_acc: bool = False):
     QX = [f"%{4 * N + 1 + j}" for j in range(N)]
     QY = [f"%{5 * N + 1 + j}" for j in range(N)]
     SPECIAL = f"%{6 * N + 1}"
-    CA, SAVE, MASK, TMPM = "s[58:59]", "s[60:61]", "s[62:63]", "s[64:65]"
+    NEGY = f"%{6 * N + 2}"                                     # (mixed addition only) != 0: add (q.x, -q.y)
+    CA, SAVE, MASK, TMPM, NEGM = "s[58:59]", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]"
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
     L = []
     mov = lambda dst, src: [L.append(f"v_mov_b32_e32 {dst[j]}, {src[j]}") for j in range(N)]
@@ -365,8 +366,15 @@ def fused_madd_program(p: int, affine_acc: bool = False):
         emit_addsub(L, N, True, R1, QY, ACCY, D, Pv, CA, 2 * p)
         emit_addsub(L, N, True, A, QX, ACCX, D, Pv, CA, 2 * p)
     else:
-        # 1. S2 = q.y * ZZZ1;  R = S2 - Y1
-        mov(A, QY); mov(B, ACCZZZ); call()
+        # 1. S2 = (+-q.y) * ZZZ1;  R = S2 - Y1.  The sign of a signed digit is applied here, on the way into the product's operand:
+        #    2q - q.y (one borrow chain; the copy of ZZZ1 fills its wait states) or q.y itself.  q.y = 0 gives 2q, which the product
+        #    takes like any other representative (its bound needs a <= 2q: the result stays below 1.41 q) -- and such a point is at
+        #    infinity or of order two and comes in flagged `special` anyway.
+        L.append(f"v_cmp_ne_u32_e64 {NEGM}, 0, {NEGY}")
+        emit_negate(L, N, D, QY, 2 * p, Pv, [f"v_mov_b32_e32 {B[j]}, {ACCZZZ[j]}" for j in range(N)])
+        for j in range(N):
+            L.append(f"v_cndmask_b32_e64 {A[j]}, {QY[j]}, {D[j]}, {NEGM}")
+        call()
         emit_addsub(L, N, True, R1, T, ACCY, D, Pv, CA, 2 * p)
         # 2. U2 = q.x * ZZ1;  P = U2 - X1 (into A), exceptional lanes off
         mov(A, QX); mov(B, ACCZZ); call()
@@ -428,7 +436,7 @@ def fused_madd_program(p: int, affine_acc: bool = False):
 
 def fused_madd_cxx(p: int, affine_acc: bool = False) -> str:
     """The C++ wrapper around fused_madd_program: operands %0..%47 = accumulator (in/out), %48 = exceptional flag (out),
-    %49..%72 = the affine point, %73 = "an operand is at infinity" (in)."""
+    %49..%72 = the affine point, %73 = "an operand is at infinity" (in), %74 (mixed addition only) = "subtract the point" (in)."""
     N = 12
     L, nv = fused_madd_program(p, affine_acc)
     fname = "sonic_g1_aadd_asm" if affine_acc else "sonic_g1_madd_asm"
@@ -437,11 +445,11 @@ def fused_madd_cxx(p: int, affine_acc: bool = False) -> str:
     NLs = "\\n\\t"
     outs = [f'"+v"(acc.x.l[{j}])' for j in range(N)] + [f'"+v"(acc.y.l[{j}])' for j in range(N)] + \
            [f'"+v"(acc.zz.l[{j}])' for j in range(N)] + [f'"+v"(acc.zzz.l[{j}])' for j in range(N)] + ['"=&v"(exc)']
-    ins = [f'"v"(qx.l[{j}])' for j in range(N)] + [f'"v"(qy.l[{j}])' for j in range(N)] + ['"v"(special)']
-    clob = [f'"v{k}"' for k in range(nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 66))] + ['"vcc"', '"scc"']
+    ins = [f'"v"(qx.l[{j}])' for j in range(N)] + [f'"v"(qy.l[{j}])' for j in range(N)] + ['"v"(special)'] + ([] if affine_acc else ['"v"(negy)'])
+    clob = [f'"v{k}"' for k in range(nv)] + [f'"s{k}"' for k in [30, 31] + list(range(36, 68))] + ['"vcc"', '"scc"']
     head = [f"// {fname}: {len(L)} instructions around {ncalls[0]} calls of sonic_mont_mul_fq_core, {ncalls[1]} of sonic_mont_sqr_fq_core and {ncalls[2]} of "
             f"sonic_mont_mul2_fq_core ({n_mov} v_mov), VGPRs v0..v{nv - 1}" + ("; the accumulator comes in affine (acc.x, acc.y), ZZ = ZZZ = 1 implied" if affine_acc else ""),
-            f"template <class XYZZ, class F> __device__ __forceinline__ bool {fname}(XYZZ& acc, const F& qx, const F& qy, uint32_t special) {{",
+            f"template <class XYZZ, class F> __device__ __forceinline__ bool {fname}(XYZZ& acc, const F& qx, const F& qy, uint32_t special" + ("" if affine_acc else ", uint32_t negy") + ") {",
             "  uint32_t exc;", "  asm volatile("]
     body = [f'      "{l}{NLs}"' for l in L[:-1]] + [f'      "{L[-1]}"']
     tail = [f"      : {', '.join(outs)}", f"      : {', '.join(ins)}", f"      : {', '.join(clob)});", "  return exc != 0;", "}"]
