@@ -1,4 +1,4 @@
-// NTT over Fr (radix 2 butterflies, the wide stages two per memory pass) for the Laurent-polynomial product t(X,y) = r(X,1) * (r(X,y) + s(X,y))
+// NTT over Fr (radix 2 butterflies in generated assembly, the wide stages five or six per memory pass) for the Laurent-polynomial product t(X,y) = r(X,1) * (r(X,y) + s(X,y))
 // (src/Sonic/Constraints.hs:61, where poly-0.4.0.0 runs a sparse convolution whose coefficients
 // are themselves polynomials; evaluating Y := y first is a ring homomorphism, so the univariate
 // product is result-exact).  omega_n = 7^((r-1)/n); Fr has 2-adicity 32.
@@ -6,7 +6,8 @@
 // Forward = decimation in frequency (natural in, bit-reversed out); inverse = decimation in time
 // (bit-reversed in, natural out, scaled by 1/n): the product needs no permutation pass.
 // Stages whose butterfly span fits a 2048-element tile (64 KB of the CU's 160 KB LDS) run fused in
-// one kernel out of LDS; wider stages stream through HBM one stage per launch.
+// one kernel out of LDS (k_ntt_local); the wider ones run up to six at a time on blocks of rows x columns that
+// pass through LDS once per launch (k_ntt_wide): three passes over HBM for a 2^21- or 2^23-point transform.
 #include <algorithm>
 #include <stdlib.h>
 #include "internal.hpp"
