@@ -27,6 +27,16 @@
  *
  * Threading: an SRS handle is immutable after construction and may be shared; a prover handle
  * owns its stream and workspace and serves one call at a time.
+ *
+ * Devices (round 5): one host process may drive every GPU of the node.  Every handle -- SRS, prover, MSM lane -- lives on the GPU it
+ * was made on (the *_on constructors name it; the others use the default device: sonic_init, else LOCAL_RANK, else 0) and every
+ * call on a handle runs there, whatever the calling thread's current HIP device is (which the call leaves as it found it).
+ * sonic_prove_shared / sonic_prove_batch / sonic_msm_g1_srs_multi run ONE call over handles on several GPUs with one host thread
+ * per device inside the library: no launcher, no torch, no RCCL.
+ *
+ * ABI version: sonic_abi_version().  An entry point whose argument list or buffer sizes change gets a NEW symbol (…_v2); the old
+ * symbol keeps its old prototype and returns SONIC_ERR_INVALID_ARG, so that a caller built against an older header gets a status
+ * instead of a memory overwrite.
  */
 #ifndef SONIC_HIP_H
 #define SONIC_HIP_H
@@ -64,7 +74,12 @@ typedef struct sonic_srs sonic_srs_t;
 typedef struct sonic_prover sonic_prover_t;
 
 /* ---- library ---- */
-int sonic_init(int device_ordinal);                 /* select the GPU; idempotent */
+#define SONIC_ABI_VERSION 5
+/* the SONIC_ABI_VERSION the library was built as; no device needed.  History: 5 = round 5 (devices; sonic_msm_submit_dev_v2,
+ * sonic_msm_reduce_slices_dev_v2 and sonic_fs_challenges_v2 replace the symbols whose meaning changed in round 4; share format 2) */
+int sonic_abi_version(void);
+int sonic_init(int device_ordinal);                 /* choose the DEFAULT GPU (first call wins) and make it the thread's HIP device; idempotent */
+int sonic_device_count(int* out);                   /* GPUs this process can see; SONIC_ERR_NO_DEVICE (and 0) without one */
 int sonic_last_error(char* buf, size_t cap);        /* copies the calling thread's last message */
 int sonic_device_sync(void);
 /* HIP_VERSION the library was compiled against / hipRuntimeGetVersion of the runtime mapped into this process (major * 10^7 +
@@ -78,12 +93,27 @@ int sonic_hip_versions(int* build, int* runtime);
  * empty (g^alpha is not shared, SRS.hs:38).  gNegativeX[k] = basis0[-(k+1)], gPositiveX[k] =
  * basis0[k], gNegativeAlphaX[k] = basis1[-(k+1)], gPositiveAlphaX[k] = basis1[k+1]. */
 int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out);
+/* the same on a named GPU (SURVEY 8b proposed `sonic_srs_new(d, x, alpha, n_gpus)`: one replica per device, made by one call each --
+ * the calls may run on different host threads at once).  device < 0: the default device. */
+int sonic_srs_new_on(int device, int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out);
 /* the record constructor `SRS{..}`: caller-supplied points, (2d+1) * 96 bytes per basis.  Every point is checked to be
  * canonical, on the curve and in the prime-order subgroup G1 (r P = O, as the powers of a generator are): MSMs over an
  * SRS rely on it (scalars above r/2 run as r - s on the negated point).  SONIC_ERR_BAD_ENCODING otherwise. */
 int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out);
+int sonic_srs_from_points_on(int device, int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out);
+/* a replica of `srs` on another GPU of this process: the G1 bases and their window tables are copied device to device
+ * (hipMemcpyPeer; no re-validation, no table rebuild), the G2 half if the handle holds it; a handle that could still generate its
+ * G2 half hands its trapdoor on to the replica as well.  The replica runs the same MSM plans as the original (same tables), which
+ * sonic_prove_shared relies on. */
+int sonic_srs_replicate(const sonic_srs_t* srs, int device, sonic_srs_t** out);
 void sonic_srs_free(sonic_srs_t* srs);
 int64_t sonic_srs_d(const sonic_srs_t* srs);        /* srsD */
+int sonic_srs_device(const sonic_srs_t* srs);       /* the GPU the handle lives on (-1 for NULL) */
+/* srsPairing = e(g, h^alpha) (SRS.hs:21,42), the one record field that is neither a vector nor d: 576 bytes, the Fq12 element as
+ * its twelve Fq coefficients c[i][j][k] (i: the Fq6 half of Fq12 = Fq6[w]/(w^2 - v), j: the Fq2 coefficient of Fq6 = Fq2[v]/(v^3 - (1 + u)),
+ * k: real / imaginary part), 48-byte little-endian each -- the layout of oracle/pairing.py's nested tuples flattened.  Host pairing
+ * (pairing.hpp) of the generator with hPositiveAlphaX[0]; needs the G2 half. */
+int sonic_srs_pairing(const sonic_srs_t* srs, uint8_t out[576]);
 int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out);
 /* the G2 half (SRS.hs:35-36,40-41): basis 0 = h^{x^e}, basis 1 = h^{alpha x^e}, e in [-d, d]; hNegativeX[k] = basis0[-(k+1)],
  * hPositiveX[k] = basis0[k], hPositiveAlphaX[k] = basis1[k], hNegativeAlphaX[k] = basis1[-(k+1)].  G2 encoding: 192 bytes
@@ -105,6 +135,7 @@ int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2);
 /* 1 if the handle holds the G2 half or can still generate it (made by sonic_srs_new and not yet used), else 0 */
 int sonic_srs_has_g2(const sonic_srs_t* srs);
 int sonic_srs_load(const char* path, sonic_srs_t** out);
+int sonic_srs_load_on(int device, const char* path, sonic_srs_t** out);
 
 /* ---- Sonic.CommitmentScheme ---- */
 /* commitPoly :: SRS -> Int -> VLaurent Fr -> G1  (CommitmentScheme.hs:20-33) */
@@ -134,15 +165,20 @@ int sonic_msm_g1_srs_partial_dev(const sonic_srs_t* srs, int basis, int64_t e0, 
  * accumulation of the other.  d_scalars: canonical 32-byte Fr resident in HBM, untouched until collect. */
 typedef struct sonic_msm_lane sonic_msm_lane_t;
 int sonic_msm_lane_new(sonic_msm_lane_t** out);
+int sonic_msm_lane_new_on(int device, sonic_msm_lane_t** out);      /* a lane serves SRS handles of its own GPU (SONIC_ERR_INVALID_ARG otherwise) */
 void sonic_msm_lane_free(sonic_msm_lane_t* lane);
 int sonic_msm_submit(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n);
 int sonic_msm_collect(sonic_msm_lane_t* lane, uint8_t* out_g1, uint8_t* out_partial);
 /* a lane on a stream the caller owns (e.g. the stream its RCCL collectives are ordered on); the stream must outlive the lane */
 int sonic_msm_lane_new_on_stream(void* hip_stream, sonic_msm_lane_t** out);
 /* sonic_msm_submit that also leaves the un-normalised result (SONIC_G1_DEV_PARTIAL_BYTES) in device memory, queued on the lane's stream:
- * the operand of a cross-rank all-gather that never visits the host (ABI note: 192 bytes and window-table plans only up to round 3). */
+ * the operand of a cross-rank all-gather that never visits the host.  out_bytes: the size of d_partial_out, checked against
+ * SONIC_G1_DEV_PARTIAL_BYTES.  (sonic_msm_submit_dev, which wrote 192 bytes up to round 3 and 12304 in round 4 under one name, is
+ * retired: the symbol still links and returns SONIC_ERR_INVALID_ARG.) */
+int sonic_msm_submit_dev_v2(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
+                            void* d_partial_out, size_t out_bytes);
 int sonic_msm_submit_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
-                         void* d_partial_out);
+                         void* d_partial_out);      /* retired: SONIC_ERR_INVALID_ARG */
 /* ONE MSM strong-scaled over `world` GPUs by sharding its BUCKETS (the fold of CommitmentScheme.hs:25-29 / 45-48 split twice: by term
  * range for the accumulation, by bucket range for the reduction):
  *   layout      n_buckets of the shared bucket set and the slice length S (a multiple of 16384, world * S >= n_buckets)
@@ -155,14 +191,16 @@ int sonic_msm_submit_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int bas
 int sonic_msm_exchange_layout(const sonic_srs_t* srs, int world, int64_t* n_buckets, int64_t* slice_len);
 int sonic_msm_accumulate_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
                              void* d_buckets, int64_t capacity);
+int sonic_msm_reduce_slices_dev_v2(sonic_msm_lane_t* lane, const sonic_srs_t* srs, const void* d_slices, int k, int64_t slice_len,
+                                   int64_t bucket_base, void* d_partial_out, size_t out_bytes);
 int sonic_msm_reduce_slices_dev(sonic_msm_lane_t* lane, const sonic_srs_t* srs, const void* d_slices, int k, int64_t slice_len,
-                                int64_t bucket_base, void* d_partial_out);
+                                int64_t bucket_base, void* d_partial_out);      /* retired like sonic_msm_submit_dev: SONIC_ERR_INVALID_ARG */
 int sonic_msm_lane_sync(sonic_msm_lane_t* lane);
 /* curve addition of k partials (RCCL has no such reduction op) + normalisation */
 int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]);
 /* the same for k device-side results of SONIC_G1_DEV_PARTIAL_BYTES each (host only) */
 int sonic_g1_sum_dev_partials(const uint8_t* blobs, int k, uint8_t out_g1[96]);
-/* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n); 0 <= log2n <= 27 (SONIC_ERR_INVALID_ARG beyond) */
+/* in-place radix-2 NTT over Fr, natural order in and out; omega = 7^((r-1)/2^log2n); 0 <= log2n <= 28 (SONIC_ERR_INVALID_ARG beyond) */
 int sonic_ntt_fr(uint8_t* data, int log2n, int inverse);
 /* dense product of two coefficient arrays (the `*` at Constraints.hs:61): out has na+nb-1 Fr */
 int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out);
@@ -224,6 +262,38 @@ int sonic_proof_from_shares(int64_t Q, int world, const uint8_t* shares, const u
  * set and windows of the MSM plan (0, 0: 2^19 and 13, an SRS with window tables at d >= 2^21). */
 int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int rank, int64_t nb, int w, uint32_t* out_lo_hi, double* out_cost);
 
+/* ---- N GPUs from ONE host process (round 5) ----
+ * The reference's prove is one pure call in one process (Protocol.hs:47-52); these keep it that way on a node of GPUs.  Each takes an
+ * array of handles that live on the GPUs to use (one SRS replica per device: sonic_srs_new_on / sonic_srs_replicate; the same device
+ * may appear more than once, which is how the tests drive them on a one-GPU box) and runs one host thread per handle inside the
+ * library.  Nothing here needs torch, RCCL or a launcher; sonic_amd/distributed.py keeps the one-process-per-GPU form over RCCL.
+ *
+ *   sonic_prove_shared    ONE proof over `world` prover handles of the same circuit and assignment: handle r runs rank r's share
+ *                         (sonic_prover_set_share is applied by the call), the 3.3-KB shares are combined on the host
+ *                         (sonic_proof_from_shares).  Same bytes as sonic_prover_prove on one GPU.
+ *   sonic_prove_batch     K independent proofs over n_provers handles (the reference's `mapM prove`; BASELINE "batch of 64 independent
+ *                         proofs streamed over 8 GPUs"): proof i goes to handle i % n_provers, each handle proves its share of the
+ *                         list in order on a thread of its own; no collective.  Two handles per GPU stream that GPU's proofs (one
+ *                         proof's host tail under the next proof's kernels).  aL, aR, aO: K x n x 32 bytes each, or all NULL to keep
+ *                         every handle's resident assignment; transcripts: K x (8 + 2Q) x 32; out_proofs: K x sonic_proof_size(Q);
+ *                         out_status (may be NULL): K statuses.  Returns the first non-zero status in list order (all proofs are
+ *                         attempted).
+ *   sonic_msm_g1_srs_multi        ONE MSM sum_i s_i B[e0 + i] over `world` SRS replicas, scalars on the host (n x 32 bytes);
+ *   sonic_msm_g1_srs_multi_dev    the same with rank r's slice resident on srs[r]'s GPU: e0[r], d_scalars[r], n[r].
+ *                         mode 0 = by term range: every GPU runs a whole MSM over its slice, the host adds the `world` partial sums
+ *                         (CommitmentScheme.hs:25-29 is a fold over independent terms); mode 1 = by bucket range (strong scaling):
+ *                         every GPU accumulates its slice into a full bucket set, the GPUs pull their bucket range from each other
+ *                         (hipMemcpyPeerAsync: the all-to-all of sonic_msm_exchange_layout), each reduces 1/world of the buckets;
+ *                         needs the full window tables on every replica. */
+int sonic_prove_shared(sonic_prover_t* const* provers, int world, const uint8_t* transcript, uint8_t* out_proof);
+int sonic_prove_batch(sonic_prover_t* const* provers, int n_provers, int64_t K, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO,
+                      const uint8_t* transcripts, uint8_t* out_proofs, int* out_status);
+int sonic_msm_g1_srs_multi(const sonic_srs_t* const* srs, int world, int basis, int64_t e0, const uint8_t* scalars, int64_t n, int mode,
+                           uint8_t out_g1[96]);
+int sonic_msm_g1_srs_multi_dev(const sonic_srs_t* const* srs, int world, int basis, const int64_t* e0, const void* const* d_scalars,
+                               const int64_t* n, int mode, uint8_t out_g1[96]);
+int sonic_prover_device(const sonic_prover_t* p);   /* the GPU a prover handle lives on (its SRS's); -1 for NULL */
+
 /* ---- opt-in Fiat-Shamir transcript ----
  * The reference draws its challenges with `rnd` (Protocol.hs:58,66,76,84-85; Signature.hs:48,60) and hands y, z, (y_j, z_j) to the
  * verifier as RndOracle.  In this mode each draw is instead SHA-256 of everything that precedes it, in that order (exact
@@ -243,7 +313,9 @@ int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8
 int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], const uint8_t blinder_seed[32], uint8_t* out_proof,
                           uint8_t* out_transcript);
 int sonic_fs_srs_id(const sonic_srs_t* srs, uint8_t out[32]);
-int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t srs_id[32], const uint8_t* proof, uint8_t* out);
+int sonic_fs_challenges_v2(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t srs_id[32], const uint8_t* proof, uint8_t* out);
+/* retired (round 3's prototype, without srs_id; round 4 changed the argument list under this name): SONIC_ERR_INVALID_ARG */
+int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t* proof, uint8_t* out);
 int sonic_verify_fs(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                     const uint8_t* cs, const uint8_t* proof, int* accepted);
 
@@ -278,7 +350,8 @@ int sonic_hsc_verify_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t
                           int64_t m, const uint8_t* yzs, const uint8_t* hsc, int* accepted);
 
 /* ---- device memory for callers without a HIP binding ---- */
-int sonic_dev_alloc(size_t bytes, void** out);
+int sonic_dev_alloc(size_t bytes, void** out);                       /* on the default device */
+int sonic_dev_alloc_on(int device, size_t bytes, void** out);         /* free / upload / download find the pointer's device themselves */
 int sonic_dev_free(void* p);
 int sonic_dev_upload(void* dst, const void* src, size_t bytes);
 int sonic_dev_download(void* dst, const void* src, size_t bytes);

@@ -62,8 +62,22 @@ def lib() -> C.CDLL:
         "sonic_init": [i32],
         "sonic_last_error": [cp, C.c_size_t],
         "sonic_device_sync": [],
+        "sonic_device_count": [C.POINTER(i32)],
         "sonic_srs_new": [i64, cp, cp, C.POINTER(vp)],
+        "sonic_srs_new_on": [i32, i64, cp, cp, C.POINTER(vp)],
         "sonic_srs_from_points": [i64, vp, vp, C.POINTER(vp)],
+        "sonic_srs_from_points_on": [i32, i64, vp, vp, C.POINTER(vp)],
+        "sonic_srs_replicate": [vp, i32, C.POINTER(vp)],
+        "sonic_srs_device": [vp],
+        "sonic_srs_pairing": [vp, vp],
+        "sonic_srs_load_on": [i32, cp, C.POINTER(vp)],
+        "sonic_msm_lane_new_on": [i32, C.POINTER(vp)],
+        "sonic_prove_shared": [vp, i32, vp, vp],
+        "sonic_prove_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp],
+        "sonic_msm_g1_srs_multi": [vp, i32, i32, i64, vp, i64, i32, vp],
+        "sonic_msm_g1_srs_multi_dev": [vp, i32, i32, vp, vp, vp, i32, vp],
+        "sonic_prover_device": [vp],
+        "sonic_dev_alloc_on": [i32, C.c_size_t, C.POINTER(vp)],
         "sonic_srs_get_points": [vp, i32, i64, i64, vp],
         "sonic_srs_get_g2_points": [vp, i32, i64, i64, vp],
         "sonic_srs_save": [vp, cp, i32],
@@ -82,10 +96,10 @@ def lib() -> C.CDLL:
         "sonic_msm_submit": [vp, vp, i32, i64, vp, i64],
         "sonic_msm_collect": [vp, vp, vp],
         "sonic_msm_lane_new_on_stream": [vp, C.POINTER(vp)],
-        "sonic_msm_submit_dev": [vp, vp, i32, i64, vp, i64, vp],
+        "sonic_msm_submit_dev_v2": [vp, vp, i32, i64, vp, i64, vp, C.c_size_t],
         "sonic_msm_exchange_layout": [vp, i32, C.POINTER(i64), C.POINTER(i64)],
         "sonic_msm_accumulate_dev": [vp, vp, i32, i64, vp, i64, vp, i64],
-        "sonic_msm_reduce_slices_dev": [vp, vp, vp, i32, i64, i64, vp],
+        "sonic_msm_reduce_slices_dev_v2": [vp, vp, vp, i32, i64, i64, vp, C.c_size_t],
         "sonic_msm_lane_sync": [vp],
         "sonic_ntt_fr": [vp, i32, i32],
         "sonic_poly_mul_fr": [vp, i64, vp, i64, vp],
@@ -108,7 +122,7 @@ def lib() -> C.CDLL:
         "sonic_fs_circuit_digest": [i64, i64, vp, vp, vp, vp, vp],
         "sonic_prover_prove_fs": [vp, cp, cp, vp, vp],
         "sonic_fs_srs_id": [vp, vp],
-        "sonic_fs_challenges": [i64, i64, i64, cp, cp, vp, vp],
+        "sonic_fs_challenges_v2": [i64, i64, i64, cp, cp, vp, vp],
         "sonic_verify_fs": [vp, i64, i64, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "sonic_prover_hsc_prove": [vp, i64, vp, cp, cp, vp],
         "sonic_hsc_prove_poly": [vp, i64, vp, vp, vp, i64, vp, cp, cp, vp],
@@ -146,6 +160,16 @@ def lib() -> C.CDLL:
     L.sonic_hsc_proof_size.restype = C.c_size_t
     L.sonic_proof_share_size.argtypes = [i64]
     L.sonic_proof_share_size.restype = C.c_size_t
+    L.sonic_abi_version.argtypes = []
+    L.sonic_abi_version.restype = i32
+    if L.sonic_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.sonic_abi_version()}, this package binds version {ABI_VERSION}: rebuild it")
+    # the retired symbols still link (and refuse): bound with their old prototypes so that tests can check exactly that
+    L.sonic_msm_submit_dev.argtypes = [vp, vp, i32, i64, vp, i64, vp]
+    L.sonic_msm_reduce_slices_dev.argtypes = [vp, vp, vp, i32, i64, i64, vp]
+    L.sonic_fs_challenges.argtypes = [i64, i64, i64, cp, vp, vp]
+    for fn in (L.sonic_msm_submit_dev, L.sonic_msm_reduce_slices_dev, L.sonic_fs_challenges):
+        fn.restype = i32
     L.sonic_hip_versions.argtypes = [C.POINTER(i32), C.POINTER(i32)]
     L.sonic_hip_versions.restype = i32
     bv, rv = i32(), i32()
@@ -163,6 +187,7 @@ def lib() -> C.CDLL:
 
 
 HIP_RUNTIME_NOTE = None
+ABI_VERSION = 5          # SONIC_ABI_VERSION of include/sonic_hip.h
 
 
 def _hipver(v: int) -> str:
@@ -170,6 +195,9 @@ def _hipver(v: int) -> str:
 
 
 EXPORTED = [
+    "sonic_abi_version", "sonic_device_count", "sonic_srs_new_on", "sonic_srs_from_points_on", "sonic_srs_replicate", "sonic_srs_device", "sonic_srs_pairing",
+    "sonic_srs_load_on", "sonic_msm_lane_new_on", "sonic_msm_submit_dev_v2", "sonic_msm_reduce_slices_dev_v2", "sonic_fs_challenges_v2",
+    "sonic_prove_shared", "sonic_prove_batch", "sonic_msm_g1_srs_multi", "sonic_msm_g1_srs_multi_dev", "sonic_prover_device", "sonic_dev_alloc_on",
     "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_hip_versions", "sonic_srs_new", "sonic_srs_from_points",
     "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_has_g2", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",

@@ -62,13 +62,34 @@ def msm_g1_srs(srs: SRS, basis: int, e0: int, scalars) -> bytes:
     return out.raw
 
 
+def msm_g1_srs_multi(replicas, basis: int, e0: int, scalars, mode: int = 0, d_slices=None) -> bytes:
+    """ONE MSM sum_i s_i B[e0 + i] over several SRS replicas -- one per GPU, all in this process (sonic_msm_g1_srs_multi[_dev]).
+    mode 0: by term range (every GPU a whole MSM over its slice, the host adds the partial sums); mode 1: by bucket range (every GPU
+    accumulates its slice, the GPUs pull their bucket range from each other, each reduces 1/world of the buckets: strong scaling).
+    scalars: ints or uint8 [n, 32] on the host, split evenly; or d_slices = [(e0_r, device pointer, n_r)] per replica for slices
+    already resident on the replicas' GPUs (scalars is then ignored)."""
+    replicas = list(replicas)
+    arr = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+    out = C.create_string_buffer(96)
+    if d_slices is not None:
+        assert len(d_slices) == len(replicas)
+        e = (C.c_int64 * len(replicas))(*[int(t[0]) for t in d_slices])
+        ptrs = (C.c_void_p * len(replicas))(*[t[1].value if isinstance(t[1], C.c_void_p) else int(t[1]) for t in d_slices])
+        cnt = (C.c_int64 * len(replicas))(*[int(t[2]) for t in d_slices])
+        _lib.check(_lib.lib().sonic_msm_g1_srs_multi_dev(arr, len(replicas), basis, e, ptrs, cnt, mode, out))
+        return out.raw
+    sc = fr_array(scalars)
+    _lib.check(_lib.lib().sonic_msm_g1_srs_multi(arr, len(replicas), basis, e0, sc.ctypes.data, sc.shape[0], mode, out))
+    return out.raw
+
+
 class MsmLane:
     """One MSM at a time over an SRS slice with device-resident scalars, in two halves (sonic_msm_submit / sonic_msm_collect).
     Two lanes used in turn stream MSMs: the sort and the reduction of one run under the accumulation of the other."""
 
-    def __init__(self):
+    def __init__(self, device: int = -1):
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().sonic_msm_lane_new(C.byref(self._h)))
+        _lib.check(_lib.lib().sonic_msm_lane_new_on(device, C.byref(self._h)))
 
     def submit(self, srs: SRS, basis: int, e0: int, d_scalars, n: int) -> None:
         """d_scalars: device pointer (int / c_void_p) to n canonical 32-byte Fr; must stay untouched until collect()"""

@@ -2,8 +2,11 @@
 // the SRS handle and the standalone MSM / NTT entry points.  prove lives in prove.hip.
 #include <stdarg.h>
 #include <string.h>
-#include <vector>
+#include <condition_variable>
 #include <memory>
+#include <string>
+#include <thread>
+#include <vector>
 #include "internal.hpp"
 #include "endo.hpp"
 #include "g2.hpp"
@@ -36,38 +39,73 @@ void Profiler::collect() {
 }
 void Profiler::reset() { collect(); std::lock_guard<std::mutex> g(mu); totals.clear(); }
 
+// ---- devices ----------------------------------------------------------------------------------------------------------------------
 static std::mutex g_init_mu;
-static int g_device = -1;
-static hipStream_t g_stream = nullptr;
-static std::mutex g_call_mu;            // standalone entry points share one workspace
-static MsmWorkspace* g_msm_ws = nullptr;
+static int g_device = -1;                    // the default device: sonic_init, else LOCAL_RANK % count, else 0
+static int g_device_count = -1;
+static std::vector<DeviceCtx*> g_ctx;        // by ordinal; entries are made on first use and live as long as the process
+static thread_local DeviceCtx* t_ctx = nullptr;
 
-void require_device() {
-  std::lock_guard<std::mutex> g(g_init_mu);
-  if (g_device >= 0) { HIP_OK(hipSetDevice(g_device)); return; }
+static int device_count_locked() {
+  if (g_device_count >= 0) return g_device_count;
+  // one hardware queue per prover stream (the runtime's default of 4 makes streams queue behind each other); only effective when
+  // this is the process's first HIP call, harmless otherwise
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
     set_error("no HIP device available (%s): libsonic_hip has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
     throw HipFail{SONIC_ERR_NO_DEVICE};
   }
-  int dev = 0;
-  const char* lr = getenv("LOCAL_RANK");
-  if (lr) dev = atoi(lr) % n;
-  HIP_OK(hipSetDevice(dev));
-  HIP_OK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  g_device = dev;
+  g_device_count = n;
+  g_ctx.assign((size_t)n, nullptr);
+  return n;
 }
-hipStream_t default_stream() { return g_stream; }
-MsmWorkspace& shared_msm_ws() { if (!g_msm_ws) g_msm_ws = new MsmWorkspace(); return *g_msm_ws; }
-std::mutex& call_mutex() { return g_call_mu; }
+// caller holds g_init_mu and has made `dev` the thread's HIP device
+static DeviceCtx* ctx_locked(int dev) {
+  if (!g_ctx[(size_t)dev]) {
+    std::unique_ptr<DeviceCtx> c(new DeviceCtx());
+    c->dev = dev;
+    HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    g_ctx[(size_t)dev] = c.release();
+  }
+  return g_ctx[(size_t)dev];
+}
+int default_device_ordinal() { std::lock_guard<std::mutex> g(g_init_mu); return g_device; }
 
-static std::mutex g_pool_mu;
-static std::vector<CallCtx*> g_pool;
-CallLease::CallLease() : c_(nullptr) {
+DeviceScope::DeviceScope(int dev) : ctx_(nullptr), prev_ctx_(t_ctx), prev_dev_(-1) {
+  if (t_ctx && (dev < 0 || t_ctx->dev == dev)) { ctx_ = t_ctx; return; }      // nested call: a handle-less callee inherits the caller's device
+  std::lock_guard<std::mutex> g(g_init_mu);
+  const int n = device_count_locked();
+  if (dev < 0) {
+    if (g_device < 0) {
+      const char* lr = getenv("LOCAL_RANK");
+      g_device = lr ? atoi(lr) % n : 0;
+      if (g_device < 0) g_device = 0;
+    }
+    dev = g_device;
+  }
+  if (dev >= n) { set_error("device %d out of range (%d device%s)", dev, n, n == 1 ? "" : "s"); throw HipFail{SONIC_ERR_INVALID_ARG}; }
+  if (hipGetDevice(&prev_dev_) != hipSuccess) { (void)hipGetLastError(); prev_dev_ = -1; }
+  if (prev_dev_ != dev) HIP_OK(hipSetDevice(dev));
+  try { ctx_ = ctx_locked(dev); } catch (...) { if (prev_dev_ >= 0 && prev_dev_ != dev) (void)hipSetDevice(prev_dev_); throw; }
+  t_ctx = ctx_;
+}
+DeviceScope::~DeviceScope() {
+  if (ctx_ == prev_ctx_) return;                       // nested on the same device: nothing was changed
+  t_ctx = prev_ctx_;
+  if (prev_dev_ >= 0 && prev_dev_ != ctx_->dev) (void)hipSetDevice(prev_dev_);
+}
+DeviceCtx& current_ctx() {
+  if (!t_ctx) { set_error("internal: no device scope on this thread"); throw HipFail{SONIC_ERR_HIP}; }
+  return *t_ctx;
+}
+
+CallLease::CallLease() : c_(nullptr), owner_(&current_ctx()) {
   {
-    std::lock_guard<std::mutex> g(g_pool_mu);
-    if (!g_pool.empty()) { c_ = g_pool.back(); g_pool.pop_back(); }
+    std::lock_guard<std::mutex> g(owner_->pool_mu);
+    if (!owner_->pool.empty()) { c_ = owner_->pool.back(); owner_->pool.pop_back(); }
   }
   if (!c_) {
     std::unique_ptr<CallCtx> c(new CallCtx());
@@ -77,8 +115,8 @@ CallLease::CallLease() : c_(nullptr) {
 }
 CallLease::~CallLease() {
   (void)hipStreamSynchronize(c_->st);        // nothing of this call may still be running when the context is handed on
-  std::lock_guard<std::mutex> g(g_pool_mu);
-  g_pool.push_back(c_);
+  std::lock_guard<std::mutex> g(owner_->pool_mu);
+  owner_->pool.push_back(c_);
 }
 
 // ---- encodings ------------------------------------------------------------------------------
@@ -166,7 +204,9 @@ void msm_blocking(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArra
 
 using namespace sonic;
 
-#define API_BEGIN try { require_device();
+// every entry point runs inside a DeviceScope: API_BEGIN on the default device, API_BEGIN_ON(dev) on a handle's device
+#define API_BEGIN_ON(dev) try { ::sonic::DeviceScope _scope(dev);
+#define API_BEGIN API_BEGIN_ON(-1)
 #define API_END                                                        \
   } catch (const HipFail& f) { return f.code; }                        \
   catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; } \
@@ -174,6 +214,11 @@ using namespace sonic;
 
 struct sonic_srs {
   int64_t d;
+  int device = 0;             // the GPU that holds the handle's memory: every call that takes the handle runs there (DeviceScope)
+  // Fiat-Shamir id of the reference string (fs.hpp): constant for an SRS, made on first use (four point fetches) and cached
+  mutable std::once_flag id_once;
+  mutable int id_rc = 0;
+  mutable uint8_t id[32] = {0};
   // basis b, window table w, exponent e  ->  tab[b][w * (2d+1) + e + d] = 2^(msm_even_shift(tab_W, w)) * g^{(alpha^b) x^e}
   // (w = 0 is the basis itself; tab_W = 1 when the window tables are switched off)
   int tab_c = 0, tab_W = 1;
@@ -199,6 +244,14 @@ struct sonic_srs {
 namespace sonic {
 PointArray srs_basis(const sonic_srs* s, int b) { return s->basis(b); }
 int64_t srs_d(const sonic_srs* s) { return s->d; }
+int srs_device(const sonic_srs* s) { return s ? s->device : -1; }
+int srs_cached_id(const sonic_srs* s, int (*make)(const sonic_srs*, uint8_t*), uint8_t out[32]) {
+  // (a failed first attempt -- e.g. the device went away -- is remembered with its status: the id of a handle never changes)
+  std::call_once(s->id_once, [&] { s->id_rc = make(s, s->id); });
+  if (s->id_rc) return s->id_rc;
+  memcpy(out, s->id, 32);
+  return SONIC_OK;
+}
 int srs_tab_c(const sonic_srs* s) { return s->tab_c; }
 int srs_tab_W(const sonic_srs* s) { return s->tab_W; }
 bool srs_tab_endo(const sonic_srs* s) { return s->tab_endo; }
@@ -208,6 +261,7 @@ bool srs_tab_endo(const sonic_srs* s) { return s->tab_endo; }
 sonic_srs* srs_alloc(int64_t d) {
   sonic_srs* s = new sonic_srs();
   s->d = d;
+  s->device = current_ctx().dev;
   const size_t n = (size_t)(2 * d + 1);
   int lg = 0;
   while ((2L << lg) <= d) lg++;                 // floor(log2 d)
@@ -260,21 +314,22 @@ int sonic_init(int device_ordinal) {
   try {
     {
       std::lock_guard<std::mutex> g(g_init_mu);
-      if (g_device < 0 && device_ordinal >= 0) {
-        // one hardware queue per prover stream (the runtime's default of 4 makes streams queue behind each other);
-        // only effective when this is the process's first HIP call, harmless otherwise
-        setenv("GPU_MAX_HW_QUEUES", "8", 0);
-        int n = 0;
-        hipError_t e = hipGetDeviceCount(&n);
-        if (e != hipSuccess || n <= 0) { set_error("no HIP device available: libsonic_hip has no CPU fallback"); return SONIC_ERR_NO_DEVICE; }
-        if (device_ordinal >= n) { set_error("device %d out of range (%d devices)", device_ordinal, n); return SONIC_ERR_INVALID_ARG; }
-        HIP_OK(hipSetDevice(device_ordinal));
-        HIP_OK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-        g_device = device_ordinal;
-      }
+      const int n = device_count_locked();
+      if (device_ordinal >= n) { set_error("device %d out of range (%d device%s)", device_ordinal, n, n == 1 ? "" : "s"); return SONIC_ERR_INVALID_ARG; }
+      if (g_device < 0 && device_ordinal >= 0) g_device = device_ordinal;       // the first choice of a default device stands
     }
-    require_device();
+    int dev;
+    { DeviceScope scope(-1); dev = scope.ctx().dev; }
+    // the default device stays the calling thread's HIP device after sonic_init (a caller with a HIP binding of its own, e.g. torch
+    // tensors handed to the _dev entry points, allocates there)
+    HIP_OK(hipSetDevice(dev));
   } catch (const HipFail& f) { return f.code; }
+  return SONIC_OK;
+}
+
+int sonic_device_count(int* out) {
+  if (!out) return SONIC_ERR_INVALID_ARG;
+  try { std::lock_guard<std::mutex> g(g_init_mu); *out = device_count_locked(); } catch (const HipFail& f) { *out = 0; return f.code; }
   return SONIC_OK;
 }
 
@@ -296,7 +351,10 @@ int sonic_last_error(char* buf, size_t cap) {
 int sonic_device_sync(void) { API_BEGIN HIP_OK(hipStreamSynchronize(default_stream())); HIP_OK(hipDeviceSynchronize()); API_END }
 
 int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out) {
-  API_BEGIN
+  return sonic_srs_from_points_on(-1, d, basis0, basis1, out);
+}
+int sonic_srs_from_points_on(int device, int64_t d, const uint8_t* basis0, const uint8_t* basis1, sonic_srs_t** out) {
+  API_BEGIN_ON(device)
   if (d < 1 || !basis0 || !basis1 || !out) { set_error("sonic_srs_from_points: bad argument"); return SONIC_ERR_INVALID_ARG; }
   std::lock_guard<std::mutex> g(call_mutex());
   hipStream_t st = default_stream();
@@ -323,11 +381,15 @@ int sonic_srs_from_points(int64_t d, const uint8_t* basis0, const uint8_t* basis
   API_END
 }
 
-void sonic_srs_free(sonic_srs_t* srs) { delete srs; }
+void sonic_srs_free(sonic_srs_t* srs) {
+  if (!srs) return;
+  try { DeviceScope scope(srs->device); delete srs; } catch (const HipFail&) { delete srs; }
+}
 int64_t sonic_srs_d(const sonic_srs_t* srs) { return srs ? srs->d : -1; }
+int sonic_srs_device(const sonic_srs_t* srs) { return srs ? srs->device : -1; }
 
 int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || !out || n < 0) return SONIC_ERR_INVALID_ARG;
   if (e0 < -srs->d || e0 + n - 1 > srs->d) { set_error("sonic_srs_get_points: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
   if (n == 0) return SONIC_OK;
@@ -362,7 +424,7 @@ static int srs_ensure_g2(const sonic_srs_t* srs, hipStream_t st, const char* who
 }
 
 int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || !out || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
   if (e0 < -srs->d || e0 + n - 1 > srs->d) { set_error("sonic_srs_get_g2_points: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
   std::lock_guard<std::mutex> g(call_mutex());
@@ -378,7 +440,7 @@ int sonic_srs_get_g2_points(const sonic_srs_t* srs, int basis, int64_t e0, int64
 }
 
 int sonic_srs_set_g2_points(sonic_srs_t* srs, const uint8_t* basis0, const uint8_t* basis1) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || !basis0 || !basis1) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(call_mutex());
   hipStream_t st = default_stream();
@@ -413,7 +475,7 @@ int sonic_srs_has_g2(const sonic_srs_t* srs) {
 // [h basis0, h basis1: (2d+1) x 192 B], canonical affine encodings.  The reference has no persistence at all; this
 // amortises SRS.new across runs, and with the G2 half a loaded SRS verifies as well as proves -- without the trapdoor.
 int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || !path || with_g2 < 0 || with_g2 > 2) return SONIC_ERR_INVALID_ARG;
   if (with_g2 == 2) with_g2 = sonic_srs_has_g2(srs) ? 1 : 0;          // "if the handle has (or can generate) it"
   if (with_g2) {
@@ -440,8 +502,9 @@ int sonic_srs_save(const sonic_srs_t* srs, const char* path, int with_g2) {
   API_END
 }
 
-int sonic_srs_load(const char* path, sonic_srs_t** out) {
-  API_BEGIN
+int sonic_srs_load(const char* path, sonic_srs_t** out) { return sonic_srs_load_on(-1, path, out); }
+int sonic_srs_load_on(int device, const char* path, sonic_srs_t** out) {
+  API_BEGIN_ON(device)
   if (!path || !out) return SONIC_ERR_INVALID_ARG;
   SrsFile file;
   std::string why;
@@ -455,12 +518,43 @@ int sonic_srs_load(const char* path, sonic_srs_t** out) {
   if (rc) return rc;
   if (flags & 1u) {
     rc = sonic_srs_set_g2_points(s, h0.data(), h1.data());
-    if (rc) { delete s; return rc; }
+    if (rc) { sonic_srs_free(s); return rc; }
   }
   *out = s;
   API_END
 }
 
+// A replica of an SRS on another GPU of this process, copied device to device: both G1 bases with their window tables (so that the
+// replica plans every MSM exactly like the original: sonic_prove_shared's ranks must agree on NB and W), the G2 half if present, the
+// trapdoor if the G2 half has not been generated yet.  hipMemcpyPeer goes over xGMI where the GPUs are linked and through the host
+// otherwise; nothing is validated again (the source was) and no table is rebuilt.
+int sonic_srs_replicate(const sonic_srs_t* srs, int device, sonic_srs_t** out) {
+  API_BEGIN_ON(device)
+  if (!srs || !out) return SONIC_ERR_INVALID_ARG;
+  DeviceCtx& ctx = current_ctx();
+  std::lock_guard<std::mutex> g(ctx.call_mu);
+  std::unique_ptr<sonic_srs> r(new sonic_srs());
+  r->d = srs->d; r->device = ctx.dev;
+  r->tab_c = srs->tab_c; r->tab_W = srs->tab_W; r->tab_endo = srs->tab_endo;
+  r->g.alloc(srs->g.bytes); r->ga.alloc(srs->ga.bytes);
+  HIP_OK(hipMemcpyPeer(r->g.p, ctx.dev, srs->g.p, srs->device, srs->g.bytes));
+  HIP_OK(hipMemcpyPeer(r->ga.p, ctx.dev, srs->ga.p, srs->device, srs->ga.bytes));
+  {
+    std::lock_guard<std::mutex> g2(srs->g2_mu);
+    if (srs->h.p) {
+      r->h.alloc(srs->h.bytes); r->ha.alloc(srs->ha.bytes);
+      HIP_OK(hipMemcpyPeer(r->h.p, ctx.dev, srs->h.p, srs->device, srs->h.bytes));
+      HIP_OK(hipMemcpyPeer(r->ha.p, ctx.dev, srs->ha.p, srs->device, srs->ha.bytes));
+    } else if (srs->have_trapdoor) {
+      r->have_trapdoor = true; r->x_std = srs->x_std; r->alpha_std = srs->alpha_std;
+    }
+  }
+  HIP_OK(hipDeviceSynchronize());
+  *out = r.release();
+  API_END
+}
+
+int sonic_abi_version(void) { return SONIC_ABI_VERSION; }
 int sonic_msm_set_window(int c) { msm_set_window_override(c); return SONIC_OK; }
 int sonic_srs_point_bytes(void) { return SONIC_SRS_POINT_BYTES; }
 
@@ -501,6 +595,7 @@ int sonic_msm_g1(const uint8_t* points, const uint8_t* scalars, int64_t n, uint8
 // check, sort, accumulation and reduction and returns; collect waits, finishes on the host.  Two lanes used in turn keep the
 // chip busy across consecutive MSMs: the sort and the (latency-bound) reduction of one run under the accumulation of the other.
 struct sonic_msm_lane {
+  int device = 0;                // the GPU the lane's stream and workspace live on; it serves SRS handles of that device
   hipStream_t st = nullptr;
   MsmWorkspace ws;
   DevBuf slot, err;
@@ -521,10 +616,12 @@ struct sonic_msm_lane {
   }
 };
 
-int sonic_msm_lane_new(sonic_msm_lane_t** out) {
-  API_BEGIN
+int sonic_msm_lane_new(sonic_msm_lane_t** out) { return sonic_msm_lane_new_on(-1, out); }
+int sonic_msm_lane_new_on(int device, sonic_msm_lane_t** out) {
+  API_BEGIN_ON(device)
   if (!out) return SONIC_ERR_INVALID_ARG;
   std::unique_ptr<sonic_msm_lane> l(new sonic_msm_lane());
+  l->device = current_ctx().dev;
   HIP_OK(hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking));
   l->slot.alloc(sizeof(MsmSlot));
   l->err.alloc(4);
@@ -537,9 +634,13 @@ int sonic_msm_lane_new(sonic_msm_lane_t** out) {
 // RCCL collectives on the bucket / partial buffers and the caller's copies are ordered by the stream and need no host
 // synchronisation in between.  The stream must outlive the lane.
 int sonic_msm_lane_new_on_stream(void* hip_stream, sonic_msm_lane_t** out) {
-  API_BEGIN
+  // the lane lives on the stream's device (the null stream belongs to whatever device is current: the default device then)
+  int sdev = -1;
+  if (hip_stream && hipStreamGetDevice(static_cast<hipStream_t>(hip_stream), &sdev) != hipSuccess) { (void)hipGetLastError(); sdev = -1; }
+  API_BEGIN_ON(sdev)
   if (!out) return SONIC_ERR_INVALID_ARG;
   std::unique_ptr<sonic_msm_lane> l(new sonic_msm_lane());
+  l->device = current_ctx().dev;
   l->st = static_cast<hipStream_t>(hip_stream);
   l->own_stream = false;
   l->segment = 8;               // ordered on the caller's stream, such a lane runs one MSM at a time: shortest chain
@@ -550,7 +651,16 @@ int sonic_msm_lane_new_on_stream(void* hip_stream, sonic_msm_lane_t** out) {
   *out = l.release();
   API_END
 }
-void sonic_msm_lane_free(sonic_msm_lane_t* l) { delete l; }
+void sonic_msm_lane_free(sonic_msm_lane_t* l) {
+  if (!l) return;
+  try { DeviceScope scope(l->device); delete l; } catch (const HipFail&) { delete l; }
+}
+// a lane and an SRS handle meet in one call: both must live on the same GPU
+static bool same_device(const sonic_msm_lane_t* l, const sonic_srs_t* srs, const char* who) {
+  if (l->device == srs->device) return true;
+  set_error("%s: the lane lives on device %d, the SRS on device %d", who, l->device, srs->device);
+  return false;
+}
 
 static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, void* d_partial_out);
 int sonic_msm_submit(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n) {
@@ -559,13 +669,23 @@ int sonic_msm_submit(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int
 // the same with the un-normalised 192-byte sum ALSO left in device memory (d_partial_out), queued on the lane's stream: the
 // operand of a cross-rank all-gather that never visits the host.  Only plans that leave one window sum (window tables) can do
 // that -- others need the host's Horner fold -- SONIC_ERR_INVALID_ARG otherwise (use sonic_msm_collect's out_partial then).
-int sonic_msm_submit_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, void* d_partial_out) {
+int sonic_msm_submit_dev_v2(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, void* d_partial_out,
+                            size_t out_bytes) {
   if (!d_partial_out) return SONIC_ERR_INVALID_ARG;
+  if (out_bytes < sizeof(MsmSlot)) { set_error("sonic_msm_submit_dev_v2: the result takes %zu bytes of device memory (SONIC_G1_DEV_PARTIAL_BYTES), the buffer has %zu", sizeof(MsmSlot), out_bytes); return SONIC_ERR_INVALID_ARG; }
   return msm_submit_common(l, srs, basis, e0, d_scalars, n, d_partial_out);
 }
+// Retired symbols keep their OLD prototypes and refuse: up to round 3 these wrote 192 bytes to d_partial_out, since round 4 the result
+// is SONIC_G1_DEV_PARTIAL_BYTES (12304) -- a caller built against the old header must get an error, not 12 KB written over its 192-byte
+// buffer.  The _v2 forms take the buffer's size.
+int sonic_msm_submit_dev(sonic_msm_lane_t*, const sonic_srs_t*, int, int64_t, const void*, int64_t, void*) {
+  set_error("sonic_msm_submit_dev is retired (its result grew from 192 to %d bytes): use sonic_msm_submit_dev_v2, which takes the buffer size", SONIC_G1_DEV_PARTIAL_BYTES);
+  return SONIC_ERR_INVALID_ARG;
+}
 static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n, void* d_partial_out) {
-  API_BEGIN
+  API_BEGIN_ON(l ? l->device : -1)
   if (!l || !srs || n < 0 || (n > 0 && !d_scalars) || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
+  if (!same_device(l, srs, "sonic_msm_submit")) return SONIC_ERR_INVALID_ARG;
   if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
   std::lock_guard<std::mutex> g(l->mu);
   if (l->in_flight) { set_error("sonic_msm_submit: the lane's previous MSM has not been collected"); return SONIC_ERR_INVALID_ARG; }
@@ -587,7 +707,7 @@ static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
 }
 
 int sonic_msm_collect(sonic_msm_lane_t* l, uint8_t* out_g1, uint8_t* out_partial) {
-  API_BEGIN
+  API_BEGIN_ON(l ? l->device : -1)
   if (!l) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(l->mu);
   if (!l->in_flight) { set_error("sonic_msm_collect: nothing was submitted"); return SONIC_ERR_INVALID_ARG; }
@@ -603,31 +723,29 @@ int sonic_msm_collect(sonic_msm_lane_t* l, uint8_t* out_g1, uint8_t* out_partial
 // the blocking entry points run on one shared lane (pinned result slot, one host synchronisation per call)
 static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, const uint8_t* h_scalars,
                           int64_t n, uint8_t* out96, uint8_t* out192) {
-  try { require_device(); } catch (const HipFail& f) { return f.code; }
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
-  // a lane per call from a pool (the blocking MSMs of different host threads run side by side)
-  static std::mutex lanes_mu;
-  static std::vector<sonic_msm_lane_t*> lanes;
+  // a lane per call from the device's pool (the blocking MSMs of different host threads run side by side)
+  DeviceCtx& ctx = current_ctx();
   sonic_msm_lane_t* lane = nullptr;
   {
-    std::lock_guard<std::mutex> g(lanes_mu);
-    if (!lanes.empty()) { lane = lanes.back(); lanes.pop_back(); }
+    std::lock_guard<std::mutex> g(ctx.pool_mu);
+    if (!ctx.lanes.empty()) { lane = static_cast<sonic_msm_lane_t*>(ctx.lanes.back()); ctx.lanes.pop_back(); }
   }
-  if (!lane) { int rc = sonic_msm_lane_new(&lane); if (rc) return rc; lane->segment = 8; }     // one MSM at a time: shortest chain
-  struct Back { sonic_msm_lane_t* l; std::mutex& mu; std::vector<sonic_msm_lane_t*>& v; ~Back() { std::lock_guard<std::mutex> g(mu); v.push_back(l); } } back{lane, lanes_mu, lanes};
+  if (!lane) { int rc = sonic_msm_lane_new_on(ctx.dev, &lane); if (rc) return rc; lane->segment = 8; }     // one MSM at a time: shortest chain
+  struct Back { sonic_msm_lane_t* l; DeviceCtx& c; ~Back() { std::lock_guard<std::mutex> g(c.pool_mu); c.lanes.push_back(l); } } back{lane, ctx};
   DevBuf sc;
   const void* dsc = d_scalars;
-  try {
-    if (h_scalars && n > 0) {
-      sc.alloc(32 * n);
-      HIP_OK(hipMemcpyAsync(sc.p, h_scalars, 32 * n, hipMemcpyHostToDevice, lane->st));
-      dsc = sc.p;
-    }
-  } catch (const HipFail& f) { return f.code; }
+  if (h_scalars && n > 0) {
+    sc.alloc(32 * n);
+    HIP_OK(hipMemcpyAsync(sc.p, h_scalars, 32 * n, hipMemcpyHostToDevice, lane->st));
+    dsc = sc.p;
+  }
   if (n > 0 && !dsc) return SONIC_ERR_INVALID_ARG;
   int rc = sonic_msm_submit(lane, srs, basis, e0, dsc, n);
   if (rc) { (void)hipStreamSynchronize(lane->st); return rc; }       // (the upload of `sc` may still be in flight)
   return sonic_msm_collect(lane, out96, out192);       // waits for the stream: `sc` may go out of scope afterwards
+  API_END
 }
 
 int sonic_msm_g1_srs(const sonic_srs_t* srs, int basis, int64_t e0, const uint8_t* scalars, int64_t n, uint8_t out_g1[96]) {
@@ -658,8 +776,9 @@ int sonic_msm_exchange_layout(const sonic_srs_t* srs, int world, int64_t* n_buck
 
 int sonic_msm_accumulate_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, int64_t n,
                              void* d_buckets, int64_t capacity) {
-  API_BEGIN
+  API_BEGIN_ON(l ? l->device : -1)
   if (!l || !srs || n < 0 || (n > 0 && !d_scalars) || (basis != 0 && basis != 1) || !d_buckets) return SONIC_ERR_INVALID_ARG;
+  if (!same_device(l, srs, "sonic_msm_accumulate_dev")) return SONIC_ERR_INVALID_ARG;
   if (n > 0 && (e0 < -srs->d || e0 + n - 1 > srs->d)) { set_error("msm over SRS: exponent range [%ld, %ld] outside [-%ld, %ld]", (long)e0, (long)(e0 + n - 1), (long)srs->d, (long)srs->d); return SONIC_ERR_SRS_INDEX; }
   if (srs->tab_W <= 1 || srs->tab_endo) { set_error("sonic_msm_accumulate_dev needs the full window tables of the SRS"); return SONIC_ERR_INVALID_ARG; }
   const int64_t NB = 1LL << (srs->tab_c - 1);
@@ -679,10 +798,16 @@ int sonic_msm_accumulate_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
   API_END
 }
 
-int sonic_msm_reduce_slices_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, const void* d_slices, int k, int64_t slice_len, int64_t bucket_base,
-                                void* d_partial_out) {
-  API_BEGIN
+int sonic_msm_reduce_slices_dev(sonic_msm_lane_t*, const sonic_srs_t*, const void*, int, int64_t, int64_t, void*) {
+  set_error("sonic_msm_reduce_slices_dev is retired (its result grew from 192 to %d bytes): use sonic_msm_reduce_slices_dev_v2, which takes the buffer size", SONIC_G1_DEV_PARTIAL_BYTES);
+  return SONIC_ERR_INVALID_ARG;
+}
+int sonic_msm_reduce_slices_dev_v2(sonic_msm_lane_t* l, const sonic_srs_t* srs, const void* d_slices, int k, int64_t slice_len, int64_t bucket_base,
+                                   void* d_partial_out, size_t out_bytes) {
+  API_BEGIN_ON(l ? l->device : -1)
   if (!l || !srs || !d_slices || k < 1 || !d_partial_out || slice_len < 1 || bucket_base < 0) return SONIC_ERR_INVALID_ARG;
+  if (out_bytes < sizeof(MsmSlot)) { set_error("sonic_msm_reduce_slices_dev_v2: the result takes %zu bytes of device memory (SONIC_G1_DEV_PARTIAL_BYTES), the buffer has %zu", sizeof(MsmSlot), out_bytes); return SONIC_ERR_INVALID_ARG; }
+  if (!same_device(l, srs, "sonic_msm_reduce_slices_dev_v2")) return SONIC_ERR_INVALID_ARG;
   if (slice_len % MSM_SLICE_QUANTUM || bucket_base % MSM_SLICE_QUANTUM) { set_error("sonic_msm_reduce_slices_dev: slice length and base must be multiples of %ld (sonic_msm_exchange_layout)", (long)MSM_SLICE_QUANTUM); return SONIC_ERR_INVALID_ARG; }
   std::lock_guard<std::mutex> g(l->mu);
   hipStream_t st = l->st;
@@ -693,12 +818,131 @@ int sonic_msm_reduce_slices_dev(sonic_msm_lane_t* l, const sonic_srs_t* srs, con
 
 // waits for what the lane has queued (accumulate / reduce / submit_dev) and reports a non-canonical scalar
 int sonic_msm_lane_sync(sonic_msm_lane_t* l) {
-  API_BEGIN
+  API_BEGIN_ON(l ? l->device : -1)
   if (!l) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(l->mu);
   HIP_OK(hipStreamSynchronize(l->st));
   if (*l->h_err) { *l->h_err = 0; set_error("msm over SRS: non-canonical scalar"); return SONIC_ERR_BAD_ENCODING; }
   API_END
+}
+
+// ---- ONE MSM over several GPUs of this process (include/sonic_hip.h, "N GPUs from ONE host process") -------------------------------
+// One host thread per replica; thread r owns a lane on srs[r]'s GPU.  mode 0: every GPU a whole MSM over its term range, the host adds
+// the partial sums.  mode 1: every GPU accumulates its term range into a full bucket set, waits for the others at a host barrier, pulls
+// ITS bucket range from every peer (hipMemcpyPeerAsync on its own lane's stream: xGMI is point to point, the world - 1 pulls of a GPU
+// run on world - 1 links), adds the slices, reduces 1/world of the buckets and reports its device-side result; the host adds those.
+namespace {
+struct HostBarrier {
+  std::mutex mu; std::condition_variable cv; int n, waiting = 0, phase = 0;
+  explicit HostBarrier(int n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> l(mu);
+    const int ph = phase;
+    if (++waiting == n) { waiting = 0; phase++; cv.notify_all(); return; }
+    cv.wait(l, [&] { return phase != ph; });
+  }
+};
+}
+static int msm_multi(const sonic_srs_t* const* srs, int world, int basis, const int64_t* e0, const void* const* d_scalars, const uint8_t* const* h_scalars,
+                     const int64_t* n, int mode, uint8_t out_g1[96]) {
+  if (!srs || world < 1 || world > 64 || !out_g1 || (basis != 0 && basis != 1) || (mode != 0 && mode != 1)) return SONIC_ERR_INVALID_ARG;
+  for (int r = 0; r < world; r++) {
+    if (!srs[r] || n[r] < 0 || (n[r] > 0 && !(d_scalars ? d_scalars[r] : (const void*)h_scalars[r]))) return SONIC_ERR_INVALID_ARG;
+    if (srs[r]->d != srs[0]->d) { set_error("sonic_msm_g1_srs_multi: replica %d has d = %ld, replica 0 d = %ld", r, (long)srs[r]->d, (long)srs[0]->d); return SONIC_ERR_INVALID_ARG; }
+  }
+  int64_t NB = 0, S = 0;
+  if (mode == 1 && world > 1) {
+    for (int r = 0; r < world; r++) {
+      int64_t nb_r = 0, s_r = 0;
+      int rc = sonic_msm_exchange_layout(srs[r], world, &nb_r, &s_r);
+      if (rc) return rc;
+      if (r == 0) { NB = nb_r; S = s_r; }
+      else if (nb_r != NB || s_r != S) { set_error("sonic_msm_g1_srs_multi: replica %d runs another MSM plan than replica 0 (window tables differ)", r); return SONIC_ERR_INVALID_ARG; }
+    }
+  }
+  const bool exchange = mode == 1 && world > 1;
+  std::vector<int> rcs((size_t)world, SONIC_OK);
+  std::vector<std::string> errs((size_t)world);
+  std::vector<G1XYZZ> partial((size_t)world, G1XYZZ::inf());
+  std::vector<uint8_t> blobs(exchange ? sizeof(MsmSlot) * (size_t)world : 0);
+  std::vector<void*> bucket_ptr((size_t)world, nullptr);       // each rank's full bucket set (mode 1), read by its peers
+  HostBarrier bar(world);
+  auto body = [&](int r) {
+    int rc = SONIC_OK;
+    sonic_msm_lane_t* lane = nullptr;
+    void *dsc = nullptr, *buckets = nullptr, *slices = nullptr, *dpart = nullptr;
+    const int dev = srs[r]->device;
+    bool at_barrier_1 = false, at_barrier_2 = false;
+    auto fail = [&](int code) { rc = code; char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)r] = b; };
+    do {
+      if ((rc = sonic_msm_lane_new_on(dev, &lane))) { fail(rc); break; }
+      const void* sc = d_scalars ? d_scalars[r] : nullptr;
+      if (!d_scalars && n[r] > 0) {
+        if ((rc = sonic_dev_alloc_on(dev, 32 * (size_t)n[r], &dsc)) || (rc = sonic_dev_upload(dsc, h_scalars[r], 32 * (size_t)n[r]))) { fail(rc); break; }
+        sc = dsc;
+      }
+      if (!exchange) {
+        uint8_t part[192];
+        if ((rc = sonic_msm_submit(lane, srs[r], basis, e0[r], sc, n[r])) || (rc = sonic_msm_collect(lane, nullptr, part))) { fail(rc); break; }
+        memcpy(&partial[(size_t)r], part, 192);
+        break;
+      }
+      const size_t cap = (size_t)world * (size_t)S;
+      if ((rc = sonic_dev_alloc_on(dev, cap * sizeof(G1XYZZ), &buckets)) || (rc = sonic_dev_alloc_on(dev, cap * sizeof(G1XYZZ), &slices)) ||
+          (rc = sonic_dev_alloc_on(dev, sizeof(MsmSlot), &dpart))) { fail(rc); break; }
+      if ((rc = sonic_msm_accumulate_dev(lane, srs[r], basis, e0[r], sc, n[r], buckets, (int64_t)cap)) || (rc = sonic_msm_lane_sync(lane))) { fail(rc); }
+      bucket_ptr[(size_t)r] = rc ? nullptr : buckets;
+      bar.wait(); at_barrier_1 = true;                           // every rank's buckets are complete (or it has failed)
+      bool all = true;
+      for (int q = 0; q < world; q++) all = all && bucket_ptr[(size_t)q] != nullptr;
+      if (all) {
+        try {
+          DeviceScope scope(dev);
+          for (int q = 0; q < world; q++)                        // slice r of rank q -> slot q of my [world][S] buffer
+            HIP_OK(hipMemcpyPeerAsync(static_cast<G1XYZZ*>(slices) + (size_t)q * S, dev, static_cast<const G1XYZZ*>(bucket_ptr[(size_t)q]) + (size_t)r * S,
+                                      srs[q]->device, (size_t)S * sizeof(G1XYZZ), lane->st));
+        } catch (const HipFail& f) { fail(f.code); }
+        if (!rc && ((rc = sonic_msm_reduce_slices_dev_v2(lane, srs[r], slices, world, S, (int64_t)r * S, dpart, sizeof(MsmSlot))) || (rc = sonic_msm_lane_sync(lane)) ||
+                    (rc = sonic_dev_download(&blobs[sizeof(MsmSlot) * (size_t)r], dpart, sizeof(MsmSlot))))) fail(rc);
+      } else if (!rc) { rc = SONIC_ERR_HIP; errs[(size_t)r] = "a peer rank failed before the bucket exchange"; }
+      bar.wait(); at_barrier_2 = true;                           // nobody frees its buckets while a peer still reads them
+    } while (false);
+    if (exchange) { if (!at_barrier_1) bar.wait(); if (!at_barrier_2) bar.wait(); }
+    if (lane) sonic_msm_lane_free(lane);
+    for (void* pz : {dsc, buckets, slices, dpart}) if (pz) sonic_dev_free(pz);
+    rcs[(size_t)r] = rc;
+  };
+  if (world == 1) body(0);
+  else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; r++) th.emplace_back(body, r);
+    for (auto& t : th) t.join();
+  }
+  for (int r = 0; r < world; r++)
+    if (rcs[(size_t)r]) { set_error("sonic_msm_g1_srs_multi, rank %d (device %d): %s", r, srs[r]->device, errs[(size_t)r].c_str()); return rcs[(size_t)r]; }
+  if (exchange) return sonic_g1_sum_dev_partials(blobs.data(), world, out_g1);
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int r = 0; r < world; r++) acc = g1_add(acc, partial[(size_t)r]);
+  g1_canonical_bytes_host(acc, out_g1);
+  return SONIC_OK;
+}
+
+int sonic_msm_g1_srs_multi_dev(const sonic_srs_t* const* srs, int world, int basis, const int64_t* e0, const void* const* d_scalars, const int64_t* n, int mode,
+                               uint8_t out_g1[96]) {
+  if (!e0 || !d_scalars || !n) return SONIC_ERR_INVALID_ARG;
+  try { return msm_multi(srs, world, basis, e0, d_scalars, nullptr, n, mode, out_g1); }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
+}
+int sonic_msm_g1_srs_multi(const sonic_srs_t* const* srs, int world, int basis, int64_t e0, const uint8_t* scalars, int64_t n, int mode, uint8_t out_g1[96]) {
+  if (world < 1 || world > 64 || n < 0 || (n > 0 && !scalars)) return SONIC_ERR_INVALID_ARG;
+  std::vector<int64_t> e((size_t)world), cnt((size_t)world);
+  std::vector<const uint8_t*> hs((size_t)world);
+  for (int r = 0; r < world; r++) {                              // contiguous term ranges, as even as possible
+    const int64_t lo = n * r / world, hi = n * (r + 1) / world;
+    e[(size_t)r] = e0 + lo; cnt[(size_t)r] = hi - lo; hs[(size_t)r] = scalars + 32 * (size_t)lo;
+  }
+  try { return msm_multi(srs, world, basis, e.data(), nullptr, hs.data(), cnt.data(), mode, out_g1); }
+  catch (const std::exception& e2) { set_error("%s", e2.what()); return SONIC_ERR_HIP; }
 }
 
 // the device-side partials of sonic_msm_submit_dev / sonic_msm_reduce_slices_dev (SONIC_G1_DEV_PARTIAL_BYTES each: what the bulk kernels
@@ -725,10 +969,18 @@ int sonic_g1_sum_partials(const uint8_t* partials, int k, uint8_t out_g1[96]) {
   return SONIC_OK;
 }
 
-int sonic_dev_alloc(size_t bytes, void** out) { API_BEGIN if (!out) return SONIC_ERR_INVALID_ARG; HIP_OK(hipMalloc(out, bytes ? bytes : 16)); API_END }
-int sonic_dev_free(void* p) { API_BEGIN HIP_OK(hipFree(p)); API_END }
-int sonic_dev_upload(void* dst, const void* src, size_t bytes) { API_BEGIN HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); API_END }
-int sonic_dev_download(void* dst, const void* src, size_t bytes) { API_BEGIN HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); API_END }
+// device memory for callers without a HIP binding: _on allocates on a named GPU; free / upload / download find the pointer's device
+static int device_of_pointer(const void* p) {
+  hipPointerAttribute_t a;
+  if (p && hipPointerGetAttributes(&a, p) == hipSuccess) return a.device;
+  (void)hipGetLastError();
+  return -1;
+}
+int sonic_dev_alloc(size_t bytes, void** out) { return sonic_dev_alloc_on(-1, bytes, out); }
+int sonic_dev_alloc_on(int device, size_t bytes, void** out) { API_BEGIN_ON(device) if (!out) return SONIC_ERR_INVALID_ARG; HIP_OK(hipMalloc(out, bytes ? bytes : 16)); API_END }
+int sonic_dev_free(void* p) { API_BEGIN_ON(device_of_pointer(p)) HIP_OK(hipFree(p)); API_END }
+int sonic_dev_upload(void* dst, const void* src, size_t bytes) { API_BEGIN_ON(device_of_pointer(dst)) HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); API_END }
+int sonic_dev_download(void* dst, const void* src, size_t bytes) { API_BEGIN_ON(device_of_pointer(src)) HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); API_END }
 
 int sonic_profile_enable(int on) { profiler().on = on != 0; return SONIC_OK; }
 int sonic_profile_reset(void) { profiler().reset(); return SONIC_OK; }

@@ -71,8 +71,7 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// the library must fail loudly when there is no GPU: every entry point goes through this
-void require_device();
+// the library must fail loudly when there is no GPU: every entry point goes through a DeviceScope (internal.hpp)
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

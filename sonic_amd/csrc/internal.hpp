@@ -8,13 +8,48 @@ struct sonic_srs;
 
 namespace sonic {
 
-hipStream_t default_stream();
-MsmWorkspace& shared_msm_ws();
-// serialises the calls that CHANGE shared state (SRS construction, the lazy G2 half, the shared NTT tables); the read-only
-// entry points over an SRS (commitPoly, openPoly, hscProve, the blocking MSMs, srs_get_points) run on a leased context instead
-std::mutex& call_mutex();
+struct NttTables;
+
+// ---- devices (api.hip) ------------------------------------------------------------------------------------------------------------
+// One host process may drive every GPU of the node (round 5): each handle -- SRS, prover, MSM lane -- is bound to the device it was
+// made on, and what used to be process-wide state (the default stream, the mutex of the state-changing calls, the leased call
+// contexts, the pool of blocking-MSM lanes, the twiddle tables and scratch of the stand-alone NTT entry points, per-device kernel
+// attributes) lives in a DeviceCtx per ordinal.  Every entry point opens a DeviceScope: it makes the handle's device the calling
+// thread's HIP device (hipSetDevice is per thread) for the duration of the call and puts the previous one back afterwards.
+struct CallCtx;
+struct DeviceCtx {
+  int dev = -1;
+  hipStream_t stream = nullptr;          // the device's default stream for the serialised (state-changing) calls
+  std::mutex call_mu;                    // SRS construction, the lazy G2 half, the shared NTT tables of the stand-alone entry points
+  std::mutex pool_mu;
+  std::vector<CallCtx*> pool;            // leased call contexts (CallLease)
+  std::vector<void*> lanes;              // idle lanes of the blocking MSM entry points (sonic_msm_lane*, under pool_mu)
+  NttTables* ntt = nullptr;              // sonic_ntt_fr / sonic_poly_mul_fr[_dev] (under call_mu)
+  DevBuf mul_a, mul_b, mul_flags;        // scratch of sonic_poly_mul_fr_dev (under call_mu)
+  int sort_staged = -1;                  // msm.hip: the LDS-staged sort passes got their dynamic-LDS attribute on this device (-1: not asked yet)
+};
+// dev < 0: the process's default device (sonic_init, else LOCAL_RANK % device count, else 0).  Throws HipFail{SONIC_ERR_NO_DEVICE}
+// without a GPU -- the library has no CPU fallback -- and HipFail{SONIC_ERR_INVALID_ARG} for an ordinal the node does not have.
+class DeviceScope {
+ public:
+  explicit DeviceScope(int dev = -1);
+  ~DeviceScope();
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+  DeviceCtx& ctx() const { return *ctx_; }
+ private:
+  DeviceCtx* ctx_;
+  DeviceCtx* prev_ctx_;
+  int prev_dev_;
+};
+DeviceCtx& current_ctx();                 // the innermost DeviceScope of the calling thread
+int default_device_ordinal();             // -1 before the first call that needed a device
+inline hipStream_t default_stream() { return current_ctx().stream; }
+// serialises the calls that CHANGE shared state on the current device; the read-only entry points over an SRS (commitPoly, openPoly,
+// hscProve, the blocking MSMs, srs_get_points) run on a leased context instead
+inline std::mutex& call_mutex() { return current_ctx().call_mu; }
 // A stream + MSM workspace of its own for the duration of one call: read-only calls on a shared SRS are re-entrant.
-// Contexts are pooled and grow with the number of host threads that are inside the library at once.
+// Contexts are pooled per device and grow with the number of host threads that are inside the library at once.
 struct CallCtx { hipStream_t st = nullptr; MsmWorkspace ws; };
 class CallLease {
  public:
@@ -26,13 +61,17 @@ class CallLease {
   MsmWorkspace& ws() const { return c_->ws; }
  private:
   CallCtx* c_;
+  DeviceCtx* owner_;
 };
 
 // SRS handle internals (api.hip)
 PointArray srs_basis(const sonic_srs* s, int b);            // table 0 of a basis, slot e + d; window table w follows at + w (2d+1)
 PointArrayMut srs_basis_mut(sonic_srs* s, int b);
 int64_t srs_d(const sonic_srs* s);
+int srs_device(const sonic_srs* s);          // -1 for a null handle (= the default device: the null check then reports the argument)
 sonic_srs* srs_alloc(int64_t d);
+// the handle's Fiat-Shamir id (fs.hpp), made once by `make` and kept in the handle
+int srs_cached_id(const sonic_srs* s, int (*make)(const sonic_srs*, uint8_t*), uint8_t out[32]);
 
 // encodings (api.hip)
 void fr_to_mont_enqueue(hipStream_t st, Fr* d, long n, int* d_err);

@@ -26,7 +26,7 @@
 // the kernel is integer-issue bound (v_mad_u64_u32), not HBM bound -- see DESIGN.md.
 #include <string.h>
 #include <stdexcept>
-#include "msm.hpp"
+#include "internal.hpp"
 #include "g1_quad.hpp"
 #include "endo.hpp"
 
@@ -1006,15 +1006,17 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     LAUNCH(k_scan_tile_sums, ht, 256, 0, st, (const uint32_t*)hist, hn, tiles);
     LAUNCH(k_scan_top, 1, 256, 0, st, tiles, ht, total);
     LAUNCH(k_scan_apply, ht, 256, 0, st, (const uint32_t*)hist, hn, (const uint32_t*)tiles, hbase);
-    // the LDS-staged passes need more dynamic LDS than the 64-KB default: asked for once per process (thread-safe static); a runtime that
-    // refuses keeps the direct kernels instead of failing the MSM
-    static const bool staged_on = [] {
-      if (getenv("SONIC_SORT_STAGED") && atoi(getenv("SONIC_SORT_STAGED")) == 0) return false;
+    // the LDS-staged passes need more dynamic LDS than the 64-KB default: asked for once per DEVICE (a function attribute belongs to the
+    // device that is current when it is set; two threads racing here set the same values); a runtime that refuses keeps the direct
+    // kernels instead of failing the MSM
+    DeviceCtx& dctx = current_ctx();
+    if (dctx.sort_staged < 0) {
       const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_STAGE_MAX_LDS);
       const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
-      if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return false; }
-      return true;
-    }();
+      if (e1 != hipSuccess || e2 != hipSuccess) (void)hipGetLastError();
+      dctx.sort_staged = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : 0;
+    }
+    const bool staged_on = dctx.sort_staged == 1;
     const size_t stage_lds = (size_t)P * 8 + (size_t)PART_TILE * pl.W * 10;
     if (staged_on && stage_lds <= SORT_STAGE_MAX_LDS && P <= 65535) {
       LAUNCH(k_part_scatter_staged, pgrid, 256, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,

@@ -236,9 +236,11 @@ __global__ void k_fr_inv_pow2(Fr* out) {   // out[k] = (2^k)^-1 in Montgomery fo
   out[k] = fp_inv(fp_pow_u64(two, (uint64_t)k));
 }
 
-// The butterfly routines address a stage's twiddles with a 32-bit byte offset from the stage's base: 2^(log2n - 1) x 32 B in the first
-// stage, so transforms stop at 2^27 points (4 GB of data; the prover's n = 2^24 would need 2^27).
-static constexpr int NTT_MAX_LOG2N = 27;
+// The butterfly routines address a stage's twiddles as a 64-bit SGPR base + a 32-bit UNSIGNED byte offset in a VGPR (global_load with
+// saddr zero-extends the offset) + 16 for the second half: the first stage of a 2^L-point transform holds 2^(L-1) twiddles, the last of
+// them at (2^(L-1) - 1) x 32 B, so L = 28 (largest offset 2^32 - 32) is the limit -- 8 GB of data, 16 GB of stage-major tables; the
+// prover's n = 2^24 (7n + 9 coefficients) needs 2^27.  (Round 4 stopped one bit early, at 2^27.)
+static constexpr int NTT_MAX_LOG2N = 28;
 void NttTables::ensure(hipStream_t st, int need) {
   if (need > NTT_MAX_LOG2N) { set_error("NTT of 2^%d points: at most 2^%d are supported", need, NTT_MAX_LOG2N); throw HipFail{SONIC_ERR_INVALID_ARG}; }
   if (need <= log2n) return;

@@ -18,6 +18,7 @@
 #include <memory>
 #include <thread>
 #include <numeric>
+#include <string>
 #include <vector>
 #include "internal.hpp"
 #include "poly.hpp"
@@ -166,6 +167,7 @@ constexpr int N_LANES = 6;
 
 struct sonic_prover {
   const sonic_srs* srs = nullptr;
+  int device = 0;                            // the SRS's GPU: the handle's streams, buffers and every call on it live there
   long n = 0, Q = 0;
   hipStream_t st = nullptr;
   hipStream_t ts = nullptr;                  // the t(X,y) product (NTT) runs beside the hscProve polynomials
@@ -211,6 +213,7 @@ struct sonic_prover {
   int share_rank = 0, share_world = 0;
   SharePlan share;
   bool share_planned_prepared = false, share_planned = false;
+  int32_t share_plan_tag = 0;                // hash of the plan's inputs (share header: ranks must have planned alike)
   std::vector<uint8_t> slot_ran;             // per slot (7 + 5Q): the last enqueue queued an MSM for it
   std::vector<uint8_t> fr_valid;             // per evaluation (3 + 2Q): the last enqueue computed it
   uint8_t witness_digest[32] = {0};          // SHA-256 of the assignment (Fiat-Shamir blinders, fs.hpp), made on first use
@@ -240,7 +243,8 @@ struct sonic_prover {
   }
 };
 
-#define API_BEGIN try { require_device();
+#define API_BEGIN_ON(dev) try { ::sonic::DeviceScope _scope(dev);
+#define API_BEGIN API_BEGIN_ON(-1)
 #define API_END                                                        \
   } catch (const HipFail& f) { return f.code; }                        \
   catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; } \
@@ -270,8 +274,9 @@ static int flags_to_status(int f, const char* who) {
 
 extern "C" {
 
-int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out) {
-  API_BEGIN
+int sonic_srs_new(int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out) { return sonic_srs_new_on(-1, d, x, alpha, out); }
+int sonic_srs_new_on(int device, int64_t d, const uint8_t x[32], const uint8_t alpha[32], sonic_srs_t** out) {
+  API_BEGIN_ON(device)
   if (d < 1 || !x || !alpha || !out) { set_error("sonic_srs_new: bad argument"); return SONIC_ERR_INVALID_ARG; }
   Fr xs, as;
   memcpy(xs.l, x, 32); memcpy(as.l, alpha, 32);
@@ -289,7 +294,7 @@ size_t sonic_proof_size(int64_t Q) { return (size_t)((7 + 4 * Q) * 96 + (5 + 2 *
 
 int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                      const uint8_t* cs, sonic_prover_t** out) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !out) { set_error("sonic_prover_new: bad argument (need n >= 1, Q >= 1)"); return SONIC_ERR_INVALID_ARG; }
   if (srs_d(srs) < 7 * n) {                                                   // Protocol.hs:54-55
     set_error("Parameter d is not large enough: %ld should be greater than %ld", (long)srs_d(srs), (long)(7 * n));
@@ -297,6 +302,7 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   }
   std::unique_ptr<sonic_prover> p(new sonic_prover());
   p->srs = srs; p->n = n; p->Q = Q;
+  p->device = srs_device(srs);
   HIP_OK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&p->ts, hipStreamNonBlocking));
   hipStream_t st = p->st;
@@ -351,7 +357,7 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
 }
 
 int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO) {
-  API_BEGIN
+  API_BEGIN_ON(p ? p->device : -1)
   if (!p || !aL || !aR || !aO) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   if (p->in_flight) { set_error("sonic_prover_set_assignment: a submitted proof is still reading the current assignment (collect it first)"); return SONIC_ERR_INVALID_ARG; }
@@ -375,7 +381,7 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
 // proof i + 1 is already running on the other (its polynomial building and sorts fill the first proof's reduction tail).
 // Both run under p->mu.
 static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
-  API_BEGIN
+  API_BEGIN_ON(p->device)
   p->t_begin = std::chrono::steady_clock::now();
   const long n = p->n, Q = p->Q;
   const sonic_srs* srs = p->srs;
@@ -385,7 +391,19 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     if (bytes_are_zero(transcript + 32 * k, 32)) { set_error("prove: transcript element %ld is zero: Laurent evaluation at 0 divides by zero", k); return SONIC_ERR_INEXACT_DIVISION; }
   if (p->share_world > 1 && (!p->share_planned || p->share_planned_prepared != p->prepared)) {
     const MsmPlan mp = srs_msm_plan(srs, 3 * n);
-    p->share = share_plan(n, Q, p->prepared, p->share_world, mp.NB, mp.W, ShareCosts::from_env());
+    const ShareCosts costs = ShareCosts::from_env();
+    p->share = share_plan(n, Q, p->prepared, p->share_world, mp.NB, mp.W, costs);
+    // what the plan was computed from, as a 32-bit tag in the share header: the plan is a pure function of these, but NB and W come from
+    // the rank's own SRS handle (window tables or not: free memory at SRS construction) and the cost constants from its environment --
+    // ranks that disagree would report pieces that do not fit together, and sonic_proof_from_shares says so instead of "do not cover"
+    {
+      uint64_t h = 1469598103934665603ull;
+      auto mix = [&](uint64_t v) { for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
+      auto mixd = [&](double d) { uint64_t v; memcpy(&v, &d, 8); mix(v); };
+      mix((uint64_t)n); mix((uint64_t)Q); mix(p->prepared ? 1 : 0); mix((uint64_t)p->share_world); mix((uint64_t)mp.NB); mix((uint64_t)mp.W);
+      mixd(costs.per_job_buckets); mixd(costs.r1); mixd(costs.sy); mixd(costs.su); mixd(costs.tprod);
+      p->share_plan_tag = (int32_t)(uint32_t)(h ^ (h >> 32));
+    }
     p->share_planned = true; p->share_planned_prepared = p->prepared;
   }
   if (p->share_world > 1 && p->phases != PH_ALL) { set_error("prove: a shared proof runs with a caller-supplied transcript only"); return SONIC_ERR_INVALID_ARG; }
@@ -647,7 +665,8 @@ static void proof_layout(long Q, const uint8_t* pts, const uint8_t* frs, const u
 // share = header (32 B) | K x {lo, hi} pieces (8 B each) | K x 192-B un-normalised partial sums (infinity where the rank has no
 // piece) | (3 + 2Q) x 32-B evaluations a, b, s, s_j, s'_j (standard form; zeros unless reported) | (3 + 2Q) x int32 reported
 namespace {
-struct ShareHeader { uint32_t magic, version; int32_t rank, world; int64_t Q; int32_t flags, pad; };
+struct ShareHeader { uint32_t magic, version; int32_t rank, world; int64_t Q; int32_t flags, plan_tag; };
+constexpr uint32_t SHARE_VERSION = 2;      // 2 (round 5): plan_tag in what was padding
 constexpr uint32_t SHARE_MAGIC = 0x48534e53u;      // "SNSH"
 }
 extern "C" size_t sonic_proof_share_size(int64_t Q) {
@@ -656,7 +675,7 @@ extern "C" size_t sonic_proof_share_size(int64_t Q) {
 }
 
 static int prove_finish_share(sonic_prover_t* p, uint8_t* out_share) {
-  API_BEGIN
+  API_BEGIN_ON(p->device)
   const long Q = p->Q;
   const int K = (int)(7 + 4 * Q), F = (int)(3 + 2 * Q);
   HIP_OK(hipStreamSynchronize(p->st));
@@ -667,7 +686,7 @@ static int prove_finish_share(sonic_prover_t* p, uint8_t* out_share) {
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->t_enq).count());
   const MsmSlot* hs = p->h_slots;
   memset(out_share, 0, sonic_proof_share_size(Q));
-  ShareHeader h{SHARE_MAGIC, 1, p->share_rank, p->share_world > 1 ? p->share_world : 1, Q, *p->h_flags, 0};
+  ShareHeader h{SHARE_MAGIC, SHARE_VERSION, p->share_rank, p->share_world > 1 ? p->share_world : 1, Q, *p->h_flags, p->share_world > 1 ? p->share_plan_tag : 0};
   memcpy(out_share, &h, sizeof h);
   uint8_t* o = out_share + sizeof h;
   for (int i = 0; i < K; i++) {
@@ -696,10 +715,17 @@ extern "C" int sonic_proof_from_shares(int64_t Q, int world, const uint8_t* shar
   const size_t sz = sonic_proof_share_size(Q);
   std::vector<const uint8_t*> by_rank((size_t)world, nullptr);
   int flags = 0;
+  int32_t tag0 = 0;
   for (int r = 0; r < world; r++) {
     ShareHeader h;
     memcpy(&h, shares + sz * r, sizeof h);
-    if (h.magic != SHARE_MAGIC || h.version != 1 || h.Q != Q || h.world != world || h.rank < 0 || h.rank >= world || by_rank[(size_t)h.rank]) {
+    if (r == 0) tag0 = h.plan_tag;
+    if (h.magic == SHARE_MAGIC && h.version == SHARE_VERSION && h.plan_tag != tag0) {
+      set_error("sonic_proof_from_shares: the ranks planned the proof with different parameters (share %d: tag %08x, share 0: %08x) -- their SRS handles "
+                "run different MSM plans (window tables built on one GPU and not on another?) or their SONIC_SHARE_COST_* environments differ", r, (unsigned)h.plan_tag, (unsigned)tag0);
+      return SONIC_ERR_INVALID_ARG;
+    }
+    if (h.magic != SHARE_MAGIC || h.version != SHARE_VERSION || h.Q != Q || h.world != world || h.rank < 0 || h.rank >= world || by_rank[(size_t)h.rank]) {
       set_error("sonic_proof_from_shares: share %d is not one of %d distinct shares of a Q = %ld proof", r, world, (long)Q); return SONIC_ERR_INVALID_ARG; }
     by_rank[(size_t)h.rank] = shares + sz * r;
     flags |= h.flags;
@@ -740,7 +766,7 @@ extern "C" int sonic_proof_from_shares(int64_t Q, int world, const uint8_t* shar
 }
 
 static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
-  API_BEGIN
+  API_BEGIN_ON(p->device)
   const long Q = p->Q;
   const int K = (int)(7 + 4 * Q);
   hipStream_t st = p->st;
@@ -834,7 +860,7 @@ int sonic_prover_collect(sonic_prover_t* p, uint8_t* out_proof) {
 // prove_share) with the same transcript; the shares are all-gathered (a few KB) and sonic_proof_from_shares turns them into the
 // proof on every rank.  world <= 1 restores the whole proof.
 int sonic_prover_set_share(sonic_prover_t* p, int rank, int world) {
-  API_BEGIN
+  API_BEGIN_ON(p ? p->device : -1)
   if (!p || (world > 1 && (rank < 0 || rank >= world))) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   if (p->in_flight) { set_error("sonic_prover_set_share: a submitted proof has not been collected yet"); return SONIC_ERR_INVALID_ARG; }
@@ -895,15 +921,22 @@ int sonic_fs_circuit_digest(int64_t n, int64_t Q, const uint8_t* wL, const uint8
   return SONIC_OK;
 }
 
-int sonic_fs_challenges(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t srs_id[32], const uint8_t* proof, uint8_t* out) {
+int sonic_fs_challenges_v2(int64_t n, int64_t Q, int64_t d, const uint8_t circuit_digest[32], const uint8_t srs_id[32], const uint8_t* proof, uint8_t* out) {
   if (n < 1 || Q < 1 || d < 1 || !circuit_digest || !srs_id || !proof || !out) return SONIC_ERR_INVALID_ARG;
   fs_challenges_of_proof(n, Q, d, circuit_digest, srs_id, proof, out);
   return SONIC_OK;
+}
+// retired with round 3's prototype: round 4 put srs_id in the middle of the argument list under the same name, so a caller built against
+// the older header passed its proof pointer where the srs id is read
+int sonic_fs_challenges(int64_t, int64_t, int64_t, const uint8_t*, const uint8_t*, uint8_t*) {
+  set_error("sonic_fs_challenges is retired (the transcript binds the SRS since round 4): use sonic_fs_challenges_v2, which takes the srs id");
+  return SONIC_ERR_INVALID_ARG;
 }
 
 int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], const uint8_t blinder_seed[32], uint8_t* out_proof,
                           uint8_t* out_transcript) {
   if (!p || !circuit_digest || !blinder_seed || !out_proof) return SONIC_ERR_INVALID_ARG;
+  API_BEGIN_ON(p->device)
   std::lock_guard<std::mutex> g(p->mu);
   int rc = prove_args_ok(p, "sonic_prover_prove_fs");
   if (!rc) rc = whole_proof_only(p, "sonic_prover_prove_fs");
@@ -967,14 +1000,14 @@ int sonic_prover_prove_fs(sonic_prover_t* p, const uint8_t circuit_digest[32], c
   if ((rc = pass(PH_QV))) return rc;
   memcpy(out_proof, pf.data(), pf.size());
   if (out_transcript) memcpy(out_transcript, tr.data(), tr.size());
-  return SONIC_OK;
+  API_END
 }
 
 // Circuit-only precomputation for handles that prove more than once: C_q = Commit(d, P_q), P_q the q-th constraint's
 // weight polynomial.  Afterwards S_j = Commit(d, s(X, y_j)) (Signature.hs:42) is assembled as
 // sum_q y_j^{n+q} C_q + Commit(d, diagonal part): the same group element from an n-term MSM instead of a 3n-term one.
 int sonic_prover_prepare(sonic_prover_t* p) {
-  API_BEGIN
+  API_BEGIN_ON(p ? p->device : -1)
   if (!p) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   if (p->prepared) return SONIC_OK;
@@ -1041,7 +1074,10 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   API_END
 }
 
-void sonic_prover_free(sonic_prover_t* p) { delete p; }
+void sonic_prover_free(sonic_prover_t* p) {
+  if (!p) return;
+  try { DeviceScope scope(p->device); delete p; } catch (const HipFail&) { delete p; }
+}
 
 // hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof (Signature.hs:32-72) on its own, for the s(X,Y) of the handle's
 // circuit (Constraints.hs:34-53) and ANY number m of (y_j, z_j) pairs -- inside prove() m is the number of linear constraints,
@@ -1051,7 +1087,7 @@ void sonic_prover_free(sonic_prover_t* p) { delete p; }
 size_t sonic_hsc_proof_size(int64_t m) { return (size_t)((2 + 4 * m) * 96 + (2 + 2 * m) * 32); }
 
 int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out) {
-  API_BEGIN
+  API_BEGIN_ON(p ? p->device : -1)
   if (!p || m < 0 || (m > 0 && !yzs) || !u || !v || !out) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(p->mu);
   if (p->in_flight) { set_error("sonic_prover_hsc_prove: a submitted proof has not been collected yet"); return SONIC_ERR_INVALID_ARG; }
@@ -1181,7 +1217,7 @@ static void biv_eval_enqueue(hipStream_t st, const BivTerms& t, const Fr* pair, 
 
 int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t* x_exps, const int64_t* y_exps, const uint8_t* coeffs,
                          int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || n_terms < 0 || (n_terms > 0 && (!x_exps || !y_exps || !coeffs)) || m < 0 || (m > 0 && !yzs) || !u || !v || !out) return SONIC_ERR_INVALID_ARG;
   CallLease lease;
   hipStream_t st = lease.st();
@@ -1290,6 +1326,89 @@ int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL,
   return rc;
 }
 
+// ---- N GPUs from ONE host process: one proof shared by several handles, a batch of proofs over several handles ------------------
+// (include/sonic_hip.h).  One host thread per handle; a handle carries its device, so the threads need no set-up of their own.
+int sonic_prover_device(const sonic_prover_t* p) { return p ? p->device : -1; }
+
+int sonic_prove_shared(sonic_prover_t* const* provers, int world, const uint8_t* transcript, uint8_t* out_proof) {
+  if (!provers || world < 1 || world > 1024 || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
+  for (int r = 0; r < world; r++) {
+    if (!provers[r]) return SONIC_ERR_INVALID_ARG;
+    if (provers[r]->n != provers[0]->n || provers[r]->Q != provers[0]->Q) { set_error("sonic_prove_shared: handle %d proves another circuit shape (n, Q) than handle 0", r); return SONIC_ERR_INVALID_ARG; }
+    for (int q = 0; q < r; q++) if (provers[q] == provers[r]) { set_error("sonic_prove_shared: handle %d appears twice (one handle runs one share at a time)", r); return SONIC_ERR_INVALID_ARG; }
+  }
+  if (world == 1) {
+    // one handle: the whole proof (a handle left in share mode by an earlier call goes back first)
+    if (provers[0]->share_world > 1) { int rc = sonic_prover_set_share(provers[0], 0, 1); if (rc) return rc; }
+    return sonic_prover_prove(provers[0], transcript, out_proof);
+  }
+  const long Q = provers[0]->Q;
+  const size_t ssz = sonic_proof_share_size(Q);
+  std::vector<uint8_t> shares(ssz * (size_t)world);
+  std::vector<int> rcs((size_t)world, SONIC_OK);
+  std::vector<std::string> errs((size_t)world);
+  auto body = [&](int r) {
+    sonic_prover_t* p = provers[r];
+    int rc = SONIC_OK;
+    bool placed;
+    { std::lock_guard<std::mutex> g(p->mu); placed = p->share_world == world && p->share_rank == r; }
+    if (!placed) rc = sonic_prover_set_share(p, r, world);          // (clears the slots of pieces the handle no longer runs; once per change)
+    if (!rc) rc = sonic_prover_prove_share(p, transcript, &shares[ssz * (size_t)r]);
+    if (rc) { char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)r] = b; }
+    rcs[(size_t)r] = rc;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int r = 1; r < world; r++) th.emplace_back(body, r);
+    body(0);                                                       // the calling thread is rank 0's
+    for (auto& t : th) t.join();
+  }
+  for (int r = 0; r < world; r++)
+    if (rcs[(size_t)r]) { set_error("sonic_prove_shared, rank %d (device %d): %s", r, provers[r]->device, errs[(size_t)r].c_str()); return rcs[(size_t)r]; }
+  return sonic_proof_from_shares(Q, world, shares.data(), transcript, out_proof);
+}
+
+int sonic_prove_batch(sonic_prover_t* const* provers, int n_provers, int64_t K, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO,
+                      const uint8_t* transcripts, uint8_t* out_proofs, int* out_status) {
+  if (!provers || n_provers < 1 || n_provers > 1024 || K < 0 || (K > 0 && (!transcripts || !out_proofs))) return SONIC_ERR_INVALID_ARG;
+  const bool per_proof = aL || aR || aO;
+  if (per_proof && !(aL && aR && aO)) { set_error("sonic_prove_batch: aL, aR, aO must be given together (or all NULL: the handles' resident assignments)"); return SONIC_ERR_INVALID_ARG; }
+  for (int i = 0; i < n_provers; i++) {
+    if (!provers[i]) return SONIC_ERR_INVALID_ARG;
+    if (provers[i]->n != provers[0]->n || provers[i]->Q != provers[0]->Q) { set_error("sonic_prove_batch: handle %d proves another circuit shape (n, Q) than handle 0", i); return SONIC_ERR_INVALID_ARG; }
+    if (provers[i]->share_world > 1) { set_error("sonic_prove_batch: handle %d runs one rank's share of a proof (sonic_prover_set_share)", i); return SONIC_ERR_INVALID_ARG; }
+    for (int q = 0; q < i; q++) if (provers[q] == provers[i]) { set_error("sonic_prove_batch: handle %d appears twice", i); return SONIC_ERR_INVALID_ARG; }
+  }
+  const long n = provers[0]->n, Q = provers[0]->Q;
+  const size_t psz = sonic_proof_size(Q), tsz = 32 * (size_t)(8 + 2 * Q), asz = 32 * (size_t)n;
+  std::vector<int> status((size_t)K, SONIC_OK);
+  std::vector<std::string> errs((size_t)n_provers);
+  std::vector<int64_t> first_bad((size_t)n_provers, -1);
+  auto body = [&](int h) {
+    for (int64_t i = h; i < K; i += n_provers) {
+      int rc = SONIC_OK;
+      if (per_proof) rc = sonic_prover_set_assignment(provers[h], aL + asz * (size_t)i, aR + asz * (size_t)i, aO + asz * (size_t)i);
+      if (!rc) rc = sonic_prover_prove(provers[h], transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
+      status[(size_t)i] = rc;
+      if (rc && first_bad[(size_t)h] < 0) { first_bad[(size_t)h] = i; char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)h] = b; }
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int h = 1; h < n_provers && h < K; h++) th.emplace_back(body, h);
+    body(0);
+    for (auto& t : th) t.join();
+  }
+  if (out_status) for (int64_t i = 0; i < K; i++) out_status[i] = status[(size_t)i];
+  for (int64_t i = 0; i < K; i++)
+    if (status[(size_t)i]) {
+      const int h = (int)(i % n_provers);
+      set_error("sonic_prove_batch, proof %ld (handle %d, device %d): %s", (long)i, h, provers[h]->device, errs[(size_t)h].c_str());
+      return status[(size_t)i];
+    }
+  return SONIC_OK;
+}
+
 // ---- commitPoly / openPoly on caller-supplied sparse polynomials ------------------------------
 struct DensePoly { DevBuf c; long lo = 0, len = 0; };
 
@@ -1319,7 +1438,7 @@ static int densify(hipStream_t st, const sonic_srs* srs, int64_t nt, const int64
 }
 
 int sonic_commit_poly(const sonic_srs_t* srs, int64_t max, int64_t n_terms, const int64_t* exps, const uint8_t* coeffs, uint8_t out_g1[96]) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || n_terms < 0 || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
   CallLease lease;
   hipStream_t st = lease.st();
@@ -1340,7 +1459,7 @@ int sonic_commit_poly(const sonic_srs_t* srs, int64_t max, int64_t n_terms, cons
 
 int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms, const int64_t* exps, const uint8_t* coeffs,
                     uint8_t out_fz[32], uint8_t out_g1[96]) {
-  API_BEGIN
+  API_BEGIN_ON(srs_device(srs))
   if (!srs || !z || n_terms < 0 || !out_fz || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
   CallLease lease;
   hipStream_t st = lease.st();
@@ -1369,11 +1488,12 @@ int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms
 }
 
 // ---- NTT / dense product -----------------------------------------------------------------------
-static NttTables& shared_ntt() { static NttTables* t = new NttTables(); return *t; }
+// the twiddle tables of the stand-alone transforms: one set per device, used under that device's call mutex
+static NttTables& shared_ntt() { DeviceCtx& c = current_ctx(); if (!c.ntt) c.ntt = new NttTables(); return *c.ntt; }
 
 int sonic_ntt_fr(uint8_t* data, int log2n, int inverse) {
   API_BEGIN
-  if (!data || log2n < 0 || log2n > 27) return SONIC_ERR_INVALID_ARG;
+  if (!data || log2n < 0 || log2n > 28) return SONIC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(call_mutex());
   hipStream_t st = default_stream();
   const long n = 1L << log2n;
@@ -1435,8 +1555,9 @@ int sonic_poly_mul_fr_dev(const void* d_a, int64_t na, const void* d_b, int64_t 
   int lg = 0;
   while ((1L << lg) < rl) lg++;
   const long M = 1L << lg;
-  static DevBuf* fa = new DevBuf(); static DevBuf* fb = new DevBuf(); static DevBuf* flags = new DevBuf(4);
-  fa->ensure(sizeof(Fr) * M); fb->ensure(sizeof(Fr) * M);
+  DeviceCtx& dctx = current_ctx();
+  DevBuf *fa = &dctx.mul_a, *fb = &dctx.mul_b, *flags = &dctx.mul_flags;       // the device's product scratch (under its call mutex)
+  fa->ensure(sizeof(Fr) * M); fb->ensure(sizeof(Fr) * M); flags->ensure(4);
   HIP_OK(hipMemsetAsync(flags->p, 0, 4, st));
   HIP_OK(hipMemsetAsync(fa->p, 0, sizeof(Fr) * M, st));
   HIP_OK(hipMemsetAsync(fb->p, 0, sizeof(Fr) * M, st));

@@ -243,9 +243,9 @@ int sonic_verify(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL
 }
 
 // what ties a Fiat-Shamir transcript to ONE reference string (fs.hpp): four G1 elements that determine x and alpha
-int sonic_fs_srs_id(const sonic_srs_t* srs, uint8_t out[32]) {
+// (constant for a handle: computed on first use -- four point fetches from the device -- and cached in the handle, srs_cached_id)
+static int make_srs_id(const sonic_srs* srs, uint8_t out[32]) {
   try {
-    if (!srs || !out) return SONIC_ERR_INVALID_ARG;
     uint8_t pts[4 * 96];
     int rc = sonic_srs_get_points(srs, 0, 1, 1, pts);                 // g^x            gPositiveX[1]
     if (!rc) rc = sonic_srs_get_points(srs, 1, 1, 1, pts + 96);       // g^{alpha x}    gPositiveAlphaX[0]
@@ -253,6 +253,47 @@ int sonic_fs_srs_id(const sonic_srs_t* srs, uint8_t out[32]) {
     if (!rc) rc = sonic_srs_get_points(srs, 1, -1, 1, pts + 288);     // g^{alpha/x}    gNegativeAlphaX[0]
     if (rc) return rc;
     fs_srs_id_of_points(srs_d(srs), pts, out);
+    return SONIC_OK;
+  } catch (const HipFail& f) { return f.code; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }
+}
+int sonic_fs_srs_id(const sonic_srs_t* srs, uint8_t out[32]) {
+  if (!srs || !out) return SONIC_ERR_INVALID_ARG;
+  return srs_cached_id(srs, &make_srs_id, out);
+}
+
+// srsPairing = pairing gen (hPositiveAlphaX !! 0) = e(g, h^alpha) (SRS.hs:21,42): the reduced ate pairing
+// f_{x, Q}(P)^((q^12 - 1)/r) with the (negative) curve parameter x.  The verifier's own pairing (pairing.hpp) computes
+// v = f_{|x|, Q}(P)^(3 (q^12 - 1)/r) -- any non-degenerate bilinear map serves its equality tests -- so the record field is derived
+// from it exactly: v lies in the order-r subgroup, v^(1/3 mod r) = f_{|x|,Q}(P)^((q^12-1)/r), and the sign of x turns that into its
+// inverse, which in the cyclotomic subgroup is the conjugate.  (Which representative pairing-1.0.0 itself returns is [dep, unverified]:
+// the package is not in the reference tree; this is the textbook definition.)
+int sonic_srs_pairing(const sonic_srs_t* srs, uint8_t out[576]) {
+  try {
+    if (!srs || !out) return SONIC_ERR_INVALID_ARG;
+    G2Affine ha;
+    int rc = fetch_g2(srs, 1, 0, ha);                                  // hPositiveAlphaX[0] = h^alpha
+    if (rc) return rc;
+    using namespace pairing;
+    const F12 v = final_exponentiation(miller_loop(g1_gen_host(), ha));
+    // 1/3 mod r as an integer: Fr arithmetic of the limb headers
+    Fr three = fp_add(fp_add(Fr::one(), Fr::one()), Fr::one());
+    const Fr e = fp_from_mont(fp_inv(three));
+    F12 acc = F12::one();
+    for (int i = 255; i >= 0; i--) {
+      acc = f12_sqr(acc);
+      if ((e.l[i >> 5] >> (i & 31)) & 1) acc = f12_mul(acc, v);
+    }
+    const F12 res = f12_conj(acc);
+    const F6* halves[2] = {&res.c0, &res.c1};
+    uint8_t* o = out;
+    for (int i = 0; i < 2; i++) {
+      const Fq2* cs[3] = {&halves[i]->a0, &halves[i]->a1, &halves[i]->a2};
+      for (int j = 0; j < 3; j++) {
+        const Fq c0 = fp_from_mont(cs[j]->c0), c1 = fp_from_mont(cs[j]->c1);
+        memcpy(o, c0.l, 48); memcpy(o + 48, c1.l, 48); o += 96;
+      }
+    }
     return SONIC_OK;
   } catch (const HipFail& f) { return f.code; }
   catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; }

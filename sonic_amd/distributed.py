@@ -151,7 +151,7 @@ class ShardedMsm:
         submitted = False
         with self.torch.cuda.stream(self.stream):
             if n > 0:
-                _lib.check(L.sonic_msm_submit_dev(self._lane, self.srs._h, basis, e0, d_scalars, n, C.c_void_p(self.part.data_ptr())))
+                _lib.check(L.sonic_msm_submit_dev_v2(self._lane, self.srs._h, basis, e0, d_scalars, n, C.c_void_p(self.part.data_ptr()), DEV_PARTIAL_BYTES))
                 submitted = True
             else:
                 self.part.zero_()               # W = 0: the empty sum
@@ -200,8 +200,8 @@ class ShardedMsm:
                 self.recv.copy_(dst)
             else:
                 self.recv.copy_(self.buckets)
-            _lib.check(L.sonic_msm_reduce_slices_dev(self._lane, self.srs._h, C.c_void_p(self.recv.data_ptr()), self.world, S,
-                                                     self.rank * S, C.c_void_p(self.part.data_ptr())))
+            _lib.check(L.sonic_msm_reduce_slices_dev_v2(self._lane, self.srs._h, C.c_void_p(self.recv.data_ptr()), self.world, S,
+                                                        self.rank * S, C.c_void_p(self.part.data_ptr()), DEV_PARTIAL_BYTES))
             return self._gather_and_sum()
 
     def run_buckets_emulated(self, basis: int, e0: int, d_scalars, n: int, world_emul: int, rank_emul: int = 0) -> None:
@@ -216,8 +216,8 @@ class ShardedMsm:
             _lib.check(L.sonic_msm_accumulate_dev(self._lane, self.srs._h, basis, e0, d_scalars, n,
                                                   C.c_void_p(self.buckets.data_ptr()), world_emul * S))
             self.recv.copy_(self.buckets)
-            _lib.check(L.sonic_msm_reduce_slices_dev(self._lane, self.srs._h, C.c_void_p(self.recv.data_ptr()), world_emul, S,
-                                                     rank_emul * S, C.c_void_p(self.part.data_ptr())))
+            _lib.check(L.sonic_msm_reduce_slices_dev_v2(self._lane, self.srs._h, C.c_void_p(self.recv.data_ptr()), world_emul, S,
+                                                        rank_emul * S, C.c_void_p(self.part.data_ptr()), DEV_PARTIAL_BYTES))
             self.part.cpu()
         _lib.check(L.sonic_msm_lane_sync(self._lane))
 

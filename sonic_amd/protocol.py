@@ -250,6 +250,57 @@ def share_plan(n: int, Q: int, prepared: bool, world: int, nb: int = 0, w: int =
     return out
 
 
+def device_count() -> int:
+    """GPUs this process can drive (sonic_device_count)"""
+    n = C.c_int(0)
+    _lib.check(_lib.lib().sonic_device_count(C.byref(n)))
+    return n.value
+
+
+def _handle_array(provers):
+    arr = (C.c_void_p * len(provers))(*[p._h for p in provers])
+    return arr
+
+
+def prove_shared(provers, transcript) -> bytes:
+    """ONE proof made by several prover handles of the same circuit and assignment, one per GPU (or several on one GPU), from this
+    one process: sonic_prove_shared runs handle r as rank r of len(provers) on a host thread of its own and combines the shares on
+    the host.  Byte-identical to Prover.prove_bytes on one GPU.  No torch, no RCCL (the one-process-per-GPU form is
+    sonic_amd.distributed.ShardedProver)."""
+    provers = list(provers)
+    Q = provers[0].Q
+    tr = fr_array(transcript)
+    assert tr.shape[0] == transcript_len(Q)
+    out = C.create_string_buffer(_lib.lib().sonic_proof_size(Q))
+    _lib.check(_lib.lib().sonic_prove_shared(_handle_array(provers), len(provers), tr.ctypes.data, out))
+    return out.raw
+
+
+def prove_batch(provers, transcripts, assignments=None) -> List[bytes]:
+    """`mapM prove` over K statements of one circuit, spread over several prover handles (sonic_prove_batch: proof i on handle
+    i % len(provers), one host thread per handle, no collective): the throughput mode of BASELINE's "batch of 64 independent proofs
+    streamed over 8 GPUs".  assignments: K Assignment objects, or None to prove every statement with the handles' resident
+    assignment (then only the transcripts differ)."""
+    provers = list(provers)
+    Q, n = provers[0].Q, provers[0].n
+    K = len(transcripts)
+    tr = np.ascontiguousarray(np.stack([fr_array(t) for t in transcripts]) if K else np.zeros((0, transcript_len(Q), 32), np.uint8))
+    assert tr.shape[1] == transcript_len(Q)
+    psz = _lib.lib().sonic_proof_size(Q)
+    out = np.zeros((max(K, 1), psz), np.uint8)
+    status = (C.c_int * max(K, 1))()
+    aL = aR = aO = None
+    if assignments is not None:
+        assert len(assignments) == K
+        aL = np.ascontiguousarray(np.stack([fr_array(a.aL) for a in assignments]))
+        aR = np.ascontiguousarray(np.stack([fr_array(a.aR) for a in assignments]))
+        aO = np.ascontiguousarray(np.stack([fr_array(a.aO) for a in assignments]))
+        assert aL.shape[1] == n and aR.shape == aL.shape and aO.shape == aL.shape
+    ptr = lambda a: None if a is None else a.ctypes.data       # noqa: E731
+    _lib.check(_lib.lib().sonic_prove_batch(_handle_array(provers), len(provers), K, ptr(aL), ptr(aR), ptr(aO), tr.ctypes.data, out.ctypes.data, status))
+    return [out[i].tobytes() for i in range(K)]
+
+
 class ProverPipeline:
     """`mapM prove` over a stream of statements of one circuit, from one host thread: `depth` prover handles used in turn, so that
     while proof i is being waited for and finished, proof i + 1 is already running (its polynomial building and sorts fill the
@@ -333,13 +384,13 @@ def fs_srs_id(srs: SRS) -> bytes:
 
 
 def fs_challenges(srs: SRS, circuit: ArithCircuit, proof: Proof) -> RndOracle:
-    """the RndOracle a Fiat-Shamir proof determines (sonic_fs_challenges)"""
+    """the RndOracle a Fiat-Shamir proof determines (sonic_fs_challenges_v2)"""
     wL, wR, wO, cs, n, Q = _circuit_arrays(circuit)
     raw = proof.to_bytes()
     if len(raw) != _lib.lib().sonic_proof_size(Q):
         raise ValueError("fs_challenges: the proof does not have Q entries in its hsc lists")
     out = C.create_string_buffer(32 * (4 + 2 * Q))
-    _lib.check(_lib.lib().sonic_fs_challenges(n, Q, srs.srsD, fs_circuit_digest(circuit), fs_srs_id(srs), raw, out))
+    _lib.check(_lib.lib().sonic_fs_challenges_v2(n, Q, srs.srsD, fs_circuit_digest(circuit), fs_srs_id(srs), raw, out))
     v = [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(4 + 2 * Q)]
     return RndOracle(v[0], v[1], list(zip(v[2:2 + Q], v[2 + Q:2 + 2 * Q])))
 

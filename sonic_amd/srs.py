@@ -21,21 +21,41 @@ class SRS:
         self.srsD = d
 
     @classmethod
-    def new(cls, d: int, x: int, alpha: int) -> "SRS":
-        """SRS.new :: Int -> Fr -> Fr -> SRS (SRS.hs:27-43), generated on the GPU."""
+    def new(cls, d: int, x: int, alpha: int, device: int = -1) -> "SRS":
+        """SRS.new :: Int -> Fr -> Fr -> SRS (SRS.hs:27-43), generated on the GPU `device` (-1: the default device)."""
         h = C.c_void_p()
-        _lib.check(_lib.lib().sonic_srs_new(d, fr_to_bytes(x), fr_to_bytes(alpha), C.byref(h)))
+        _lib.check(_lib.lib().sonic_srs_new_on(device, d, fr_to_bytes(x), fr_to_bytes(alpha), C.byref(h)))
         return cls(h, d)
 
     @classmethod
-    def from_points(cls, d: int, basis0: np.ndarray, basis1: np.ndarray) -> "SRS":
+    def from_points(cls, d: int, basis0: np.ndarray, basis1: np.ndarray, device: int = -1) -> "SRS":
         """The record constructor: caller-supplied points, uint8 [(2d+1), 96] per basis."""
         b0 = np.ascontiguousarray(basis0, np.uint8)
         b1 = np.ascontiguousarray(basis1, np.uint8)
         assert b0.size == 96 * (2 * d + 1) and b1.size == 96 * (2 * d + 1)
         h = C.c_void_p()
-        _lib.check(_lib.lib().sonic_srs_from_points(d, b0.ctypes.data, b1.ctypes.data, C.byref(h)))
+        _lib.check(_lib.lib().sonic_srs_from_points_on(device, d, b0.ctypes.data, b1.ctypes.data, C.byref(h)))
         return cls(h, d)
+
+    def replicate(self, device: int) -> "SRS":
+        """a replica of this SRS on another GPU of the process, copied device to device with its window tables (sonic_srs_replicate)"""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sonic_srs_replicate(self._h, device, C.byref(h)))
+        return SRS(h, self.srsD)
+
+    @property
+    def device(self) -> int:
+        """the GPU the handle lives on"""
+        return int(_lib.lib().sonic_srs_device(self._h))
+
+    @property
+    def srsPairing(self):
+        """srsPairing = e(g, h^alpha) (SRS.hs:21,42): the Fq12 element as nested tuples ((c00, c01, c02), (c10, c11, c12)) of Fq2
+        pairs -- Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - (1 + u)) -- from sonic_srs_pairing (host pairing; needs the G2 half)"""
+        out = C.create_string_buffer(576)
+        _lib.check(_lib.lib().sonic_srs_pairing(self._h, out))
+        v = [int.from_bytes(out.raw[48 * i:48 * i + 48], "little") for i in range(12)]
+        return tuple(tuple((v[6 * i + 2 * j], v[6 * i + 2 * j + 1]) for j in range(3)) for i in range(2))
 
     def set_g2_points(self, basis0: np.ndarray, basis1: np.ndarray) -> None:
         """attach the verifier half to a handle built from G1 points: uint8 [(2d+1), 192] per basis, validated"""
@@ -55,9 +75,9 @@ class SRS:
         _lib.check(_lib.lib().sonic_srs_save(self._h, str(path).encode(), 2 if g2 is None else (1 if g2 else 0)))
 
     @classmethod
-    def load(cls, path: str) -> "SRS":
+    def load(cls, path: str, device: int = -1) -> "SRS":
         h = C.c_void_p()
-        _lib.check(_lib.lib().sonic_srs_load(str(path).encode(), C.byref(h)))
+        _lib.check(_lib.lib().sonic_srs_load_on(device, str(path).encode(), C.byref(h)))
         return cls(h, int(_lib.lib().sonic_srs_d(h)))
 
     def points(self, basis: int, e0: int, n: int) -> np.ndarray:

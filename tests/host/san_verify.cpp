@@ -3,7 +3,8 @@
 // code over pairing.hpp), linked against stand-ins for the three things it takes from the device side: the SRS handle's degree, its
 // G2 elements (computed here from a known trapdoor with the same host group code) and the error slot.
 //   san_verify <case file>      case file (written by tests/test_sanitizers.py from tests/golden/prove_small.json):
-//       i64 n, Q, d | x, alpha (32 B each) | wL, wR, wO (Q n x 32 B each) | cs (Q x 32) | proof | y, z (32 each) | yzs (Q x 64)
+//       i64 n, Q, d | x, alpha (32 B each) | wL, wR, wO (Q n x 32 B each) | cs (Q x 32) | proof | y, z (32 each) | yzs (Q x 64) |
+//       srsPairing = e(g, h^alpha) as oracle/pairing.py computes it, in sonic_srs_pairing's layout (576 B)
 // Runs sonic_verify on the golden proof (must accept), on proofs with one byte changed in every field (must reject or report a bad
 // encoding), with other challenges, sonic_pc_v on a hand-made opening, and sonic_verify_fs.  Prints "san_verify ok".
 #include <stdarg.h>
@@ -18,6 +19,7 @@ namespace sonic {
 static char g_msg[512];
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_msg, sizeof g_msg, fmt, ap); va_end(ap); }
 int64_t srs_d(const sonic_srs* s) { return s->d; }
+int srs_cached_id(const sonic_srs* s, int (*make)(const sonic_srs*, uint8_t*), uint8_t out[32]) { return make(s, out); }      // (the handle's cache lives in api.hip)
 }  // namespace sonic
 using namespace sonic;
 
@@ -93,9 +95,9 @@ int main(int argc, char** argv) {
   const int64_t n = hdr[0], Q = hdr[1], d = hdr[2];
   auto rd = [&](size_t bytes) { std::vector<uint8_t> v(bytes); if (fread(v.data(), 1, bytes, f) != bytes) v.clear(); return v; };
   std::vector<uint8_t> xb = rd(32), ab = rd(32), wL = rd(32 * Q * n), wR = rd(32 * Q * n), wO = rd(32 * Q * n), cs = rd(32 * Q),
-                       proof = rd(sonic_proof_size(Q)), y = rd(32), z = rd(32), yzs = rd(64 * Q);
+                       proof = rd(sonic_proof_size(Q)), y = rd(32), z = rd(32), yzs = rd(64 * Q), want_pairing = rd(576);
   fclose(f);
-  CHECK(!yzs.empty() && !proof.empty(), "case file complete");
+  CHECK(!yzs.empty() && !proof.empty() && !want_pairing.empty(), "case file complete");
   sonic_srs srs;
   srs.d = d;
   CHECK(load_fr(xb.data(), srs.x) && load_fr(ab.data(), srs.alpha), "trapdoor canonical");
@@ -127,6 +129,13 @@ int main(int argc, char** argv) {
   CHECK(sonic_hsc_verify(&srs, n, Q, wL.data(), wR.data(), wO.data(), Q, yzs.data(), &proof[576], &ok) == 0 && ok == 1, "hscVerify accepts");
   // the Fiat-Shamir verifier on a proof made with drawn challenges: its u, v are not its transcript's -> rejected, no pairing needed
   CHECK(sonic_verify_fs(&srs, n, Q, wL.data(), wR.data(), wO.data(), cs.data(), proof.data(), &ok) == 0 && ok == 0, "verify_fs rejects a proof with foreign challenges");
+  // srsPairing (SRS.hs:21,42) against the python oracle's pairing of the same two points
+  {
+    uint8_t got[576];
+    CHECK(sonic_srs_pairing(&srs, got) == 0, "sonic_srs_pairing");
+    CHECK(memcmp(got, want_pairing.data(), 576) == 0, "srsPairing equals the oracle's e(g, h^alpha)");
+    CHECK(sonic_srs_pairing(nullptr, got) == SONIC_ERR_INVALID_ARG, "null handle");
+  }
   printf("san_verify ok\n");
   return 0;
 }

@@ -62,10 +62,10 @@ def test_product_never_touches_oracle():
                     assert not re.search(pat, src), (f, pat)
 
 
-def _build_harness(tmp_path):
-    exe = str(tmp_path / "abi_harness")
+def _build_harness(tmp_path, name="abi_harness"):
+    exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "host", "abi_harness.c"), "-L" + os.path.join(ROOT, "sonic_amd", "csrc"), "-lsonic_hip",
+                           os.path.join(ROOT, "tests", "host", name + ".c"), "-L" + os.path.join(ROOT, "sonic_amd", "csrc"), "-lsonic_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "sonic_amd", "csrc"), "-o", exe])
     return exe
 
@@ -76,3 +76,27 @@ def test_c99_harness_builds_and_refuses_without_gpu(built, tmp_path):
     the header is C99-clean, every entry point the harness binds links, and without a GPU the first call says so (exit 77)"""
     out = subprocess.run([_build_harness(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 77 and "SONIC_ERR_NO_DEVICE" in out.stderr and "no CPU fallback" in out.stderr
+
+
+@pytest.mark.skipif(_have_gpu(), reason="this box has a GPU: tests/test_gpu_multi.py runs the harness to the end")
+def test_c99_multi_harness_builds_and_refuses_without_gpu(built, tmp_path):
+    """the multi-device entry points (sonic_srs_new_on, sonic_prove_shared, sonic_prove_batch, sonic_msm_g1_srs_multi ...) bind from
+    plain C99; without a GPU the first call refuses"""
+    case = tmp_path / "none.bin"
+    case.write_bytes(b"")
+    out = subprocess.run([_build_harness(tmp_path, "multi_harness"), str(case), "0,0,0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 77 and "SONIC_ERR_NO_DEVICE" in out.stderr
+
+
+def test_abi_version_and_retired_symbols(built):
+    """an entry point whose meaning changed got a new symbol; the old ones still link with their old prototypes and refuse
+    (no device needed for that), and the library reports the ABI version the header declares"""
+    import ctypes as C
+    import re as _re
+    L = built.lib()
+    hdr = open(os.path.join(ROOT, "include", "sonic_hip.h")).read()
+    assert L.sonic_abi_version() == int(_re.search(r"#define SONIC_ABI_VERSION (\d+)", hdr).group(1)) == built.ABI_VERSION
+    out = C.create_string_buffer(96)
+    assert L.sonic_fs_challenges(1, 1, 8, bytes(32), out, out) == 7 and "retired" in built.last_error()
+    assert L.sonic_msm_submit_dev(None, None, 0, 0, None, 0, None) == 7 and "sonic_msm_submit_dev_v2" in built.last_error()
+    assert L.sonic_msm_reduce_slices_dev(None, None, None, 1, 16384, 0, None) == 7 and "retired" in built.last_error()

@@ -67,7 +67,7 @@ def test_product_transcript_code_matches_python(ref):
         assert L.sonic_fs_circuit_digest(b["n"], b["Q"], aL.ctypes.data, aR.ctypes.data, aO.ctypes.data, acs.ctypes.data, out) == 0
         assert out.raw.hex() == c["circuit_digest"]
         ch = C.create_string_buffer(32 * (4 + 2 * b["Q"]))
-        assert L.sonic_fs_challenges(b["n"], b["Q"], b["d"], out.raw, bytes.fromhex(c["srs_id"]), bytes.fromhex(c["proof"]), ch) == 0
+        assert L.sonic_fs_challenges_v2(b["n"], b["Q"], b["d"], out.raw, bytes.fromhex(c["srs_id"]), bytes.fromhex(c["proof"]), ch) == 0
         got = [int.from_bytes(ch.raw[32 * i:32 * i + 32], "little") for i in range(4 + 2 * b["Q"])]
         assert got == [int(t, 16) for t in c["transcript"]][4:]
 

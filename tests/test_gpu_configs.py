@@ -101,8 +101,8 @@ def test_msm_2p22_sharded_on_one_gpu(sonic, orc, big_srs, kind, world):
         for r in range(world):
             # what rank r's all-to-all would deliver: slice r of every rank's bucket set, laid out [world][S]
             recv = torch.cat([full[s][r * S * 192:(r + 1) * S * 192] for s in range(world)])
-            _lib.check(L.sonic_msm_reduce_slices_dev(sh._lane, srs._h, C.c_void_p(recv.data_ptr()), world, S, r * S,
-                                                     C.c_void_p(parts2.data_ptr() + sd.DEV_PARTIAL_BYTES * r)))
+            _lib.check(L.sonic_msm_reduce_slices_dev_v2(sh._lane, srs._h, C.c_void_p(recv.data_ptr()), world, S, r * S,
+                                                        C.c_void_p(parts2.data_ptr() + sd.DEV_PARTIAL_BYTES * r), sd.DEV_PARTIAL_BYTES))
             torch.cuda.current_stream().synchronize()
         host = parts2.cpu().numpy()
     _lib.check(L.sonic_msm_lane_sync(sh._lane))
@@ -139,14 +139,21 @@ def test_bucket_exchange_uneven_world_and_errors(sonic, orc):
                                                   C.c_void_p(full[r].data_ptr()), world * S))
         for r in range(world):
             recv = torch.cat([full[s][r * S * 192:(r + 1) * S * 192] for s in range(world)])
-            _lib.check(L.sonic_msm_reduce_slices_dev(sh._lane, srs._h, C.c_void_p(recv.data_ptr()), world, S, r * S,
-                                                     C.c_void_p(parts.data_ptr() + sd.DEV_PARTIAL_BYTES * r)))
+            _lib.check(L.sonic_msm_reduce_slices_dev_v2(sh._lane, srs._h, C.c_void_p(recv.data_ptr()), world, S, r * S,
+                                                        C.c_void_p(parts.data_ptr() + sd.DEV_PARTIAL_BYTES * r), sd.DEV_PARTIAL_BYTES))
             torch.cuda.current_stream().synchronize()
         host = parts.cpu().numpy()
     assert sd.sum_dev_partials(host, world) == want
     # contract: capacity, quantum, SRS range, non-canonical scalars
     assert L.sonic_msm_accumulate_dev(sh._lane, srs._h, 1, -d, dsc, N, C.c_void_p(full[0].data_ptr()), NB - 1) == 7
-    assert L.sonic_msm_reduce_slices_dev(sh._lane, srs._h, C.c_void_p(full[0].data_ptr()), 1, S - 1, 0, C.c_void_p(parts.data_ptr())) == 7
+    assert L.sonic_msm_reduce_slices_dev_v2(sh._lane, srs._h, C.c_void_p(full[0].data_ptr()), 1, S - 1, 0, C.c_void_p(parts.data_ptr()), sd.DEV_PARTIAL_BYTES) == 7
+    # ABI: a buffer of the old 192 bytes is refused, and so are the retired symbols, which a caller built against an older
+    # header would still bind -- a status, never 12 KB written over a 192-byte buffer
+    assert L.sonic_msm_reduce_slices_dev_v2(sh._lane, srs._h, C.c_void_p(full[0].data_ptr()), 1, S, 0, C.c_void_p(parts.data_ptr()), 192) == 7
+    assert "12304" in _lib.last_error() or "SONIC_G1_DEV_PARTIAL_BYTES" in _lib.last_error()
+    assert L.sonic_msm_submit_dev_v2(sh._lane, srs._h, 1, -d, dsc, N, C.c_void_p(parts.data_ptr()), 192) == 7
+    assert L.sonic_msm_reduce_slices_dev(sh._lane, srs._h, C.c_void_p(full[0].data_ptr()), 1, S, 0, C.c_void_p(parts.data_ptr())) == 7
+    assert L.sonic_msm_submit_dev(sh._lane, srs._h, 1, -d, dsc, N, C.c_void_p(parts.data_ptr())) == 7 and "retired" in _lib.last_error()
     assert L.sonic_msm_accumulate_dev(sh._lane, srs._h, 1, d - 5, dsc, N, C.c_void_p(full[0].data_ptr()), world * S) == 2      # leaves [-d, d]
     bad = sc.copy()
     bad[7, :] = 0xff

@@ -22,6 +22,22 @@ def built():
     return HOST
 
 
+def srs_pairing_bytes(alpha: int) -> bytes:
+    """srsPairing = e(g, h^alpha) (SRS.hs:21,42) from the python oracle, in the layout of sonic_srs_pairing (include/sonic_hip.h): the
+    reduced ate pairing for the NEGATIVE curve parameter is the inverse of the oracle's f_{|x|}^((q^12-1)/r); its polynomial-basis
+    coefficients over Fq[w]/(w^12 - 2 w^6 + 2) become the tower's Fq2 coefficients through u = w^6 - 1: the coefficient of w^i is
+    (c_i + c_{i+6}) + c_{i+6} u, and w^i sits at [i % 2][i // 2] of Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - (1 + u))"""
+    from oracle import pairing as pr
+    from oracle.sonic_ref import G1_GEN, Q as FQ
+    e = pr.f12_inv(pr.pairing(G1_GEN, pr.g2_mul(pr.G2_GEN, alpha)))
+    out = b""
+    for i in range(2):
+        for j in range(3):
+            k = 2 * j + i
+            out += ((e[k] + e[k + 6]) % FQ).to_bytes(48, "little") + (e[k + 6] % FQ).to_bytes(48, "little")
+    return out
+
+
 def _fr(hexes):
     return b"".join(int(h, 16).to_bytes(32, "little") for h in hexes)
 
@@ -39,7 +55,7 @@ def test_verifier_host_path(built, tmp_path, name):
     flat = lambda w: _fr([v for r in w for v in r])    # noqa: E731
     yzs = b"".join(_fr([tr[6 + j]]) + _fr([tr[6 + Q + j]]) for j in range(Q))
     blob = struct.pack("<qqq", n, Q, d) + _fr([c["x"], c["alpha"]]) + flat(c["wL"]) + flat(c["wR"]) + flat(c["wO"]) + _fr(c["cs"]) + \
-        bytes.fromhex(c["proof"]) + _fr([tr[4], tr[5]]) + yzs
+        bytes.fromhex(c["proof"]) + _fr([tr[4], tr[5]]) + yzs + srs_pairing_bytes(int(c["alpha"], 16))
     path = tmp_path / "case.bin"
     path.write_bytes(blob)
     out = subprocess.run([os.path.join(built, "san_verify"), str(path)], capture_output=True, text=True, timeout=900, env=ENV)

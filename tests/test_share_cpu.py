@@ -58,10 +58,10 @@ def fr_owner_slot(i, Q):
     return [2, 3, 4][i] if i < 3 else (6 + 2 * (i - 3) if i < 3 + Q else 6 + 2 * Q + 2 * (i - 3 - Q))
 
 
-def synth_share(proof: bytes, Q: int, rank: int, world: int, pieces, flags: int = 0) -> bytes:
+def synth_share(proof: bytes, Q: int, rank: int, world: int, pieces, flags: int = 0, plan_tag: int = 0x1234, version: int = 2) -> bytes:
     K, F = 7 + 4 * Q, 3 + 2 * Q
     pts, frs = proof_parts(proof, Q)
-    out = struct.pack("<IIiiqii", 0x48534E53, 1, rank, world, Q, flags, 0)
+    out = struct.pack("<IIiiqii", 0x48534E53, version, rank, world, Q, flags, plan_tag)
     out += b"".join(struct.pack("<II", lo, hi) for lo, hi in pieces)
     out += b"".join(_partial(pts[i]) if (pieces[i][1] > pieces[i][0] and pieces[i][0] == 0) else bytes(192) for i in range(K))
     valid = [int(pieces[fr_owner_slot(i, Q)][1] > 0 and pieces[fr_owner_slot(i, Q)][0] == 0) for i in range(F)]
@@ -154,6 +154,16 @@ def test_combine_synthetic_shares(world):
     # garbage is refused, not read
     with pytest.raises(_lib.SonicError):
         sonic_amd.proof_from_shares(Q, [bytes(len(shares[0]))] * world, tr)
+    # ranks that planned with different parameters (another MSM plan on one GPU, another SONIC_SHARE_COST_* environment) carry
+    # different plan tags: the combine names the cause instead of "do not cover" 
+    if world > 1:
+        mixed = [synth_share(want, Q, r, world, plan[r][0], plan_tag=0x1234 + (r == world - 1)) for r in range(world)]
+        with pytest.raises(_lib.SonicError) as e:
+            sonic_amd.proof_from_shares(Q, mixed, tr)
+        assert e.value.code == 7 and "planned" in e.value.message and "different parameters" in e.value.message
+    # a share in the round-4 format (version 1) is refused
+    with pytest.raises(_lib.SonicError):
+        sonic_amd.proof_from_shares(Q, [synth_share(want, Q, r, world, plan[r][0], version=1) for r in range(world)], tr)
 
 
 def _worker(rank, world, port, q):
