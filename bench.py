@@ -2,30 +2,37 @@
 """bench.py -- prove() proofs/s and G1 MSM scalar-muls/s on MI355X (BASELINE.json metric).
 
   python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     (the driver's form)
+  python bench.py --gpus N ...            without RANK in the environment and N > 1: starts those N ranks itself as child processes
+                                          (before this process touches the GPU), relays rank 0's JSON line and exits with their code
+  python bench.py --gpus N --in-process   ONE process drives the N GPUs through the C ABI alone (sonic_prove_batch,
+                                          sonic_prove_shared, sonic_msm_g1_srs_multi: no torch.distributed, no RCCL)
 
 A "step" is one pass of the hot path over one batch of synthetic input: one full prove()
 (Sonic.Protocol.prove incl. hscProve) on a synthetic random circuit (the reference's rndCircuit
 generator at scale), circuit + assignment + SRS already resident in HBM when the timed region starts.
 The K steps are streamed -- one host thread, two prover handles per GPU used in turn (sonic_prover_submit /
 sonic_prover_collect), nothing synchronised between steps, all K proofs complete (and byte-identical to the
-one-at-a-time proofs) at the closing barrier; `value` = K / that time.  The strictly sequential rate (each
-prove() finished before the next begins = the latency of one proof) is reported beside it as `sequential`.
+one-at-a-time proofs) at the closing barrier; `value` = K / that time.  Beside it, in the same line: the strictly sequential
+rate (`sequential`), the same stream WITHOUT the per-circuit precomputation (`resident_unprepared`) and the reference's own call
+shape -- circuit, assignment and transcript handed over as host buffers per call (`one_shot`).
 Workload (BASELINE.json configs[2], "n=2^18, d=2^20"): the reference rejects d < 7n
 (src/Sonic/Protocol.hs:54-55), so prove() runs at the stated n = 2^18 with d = 8n = 2^21 and the
-standalone MSM runs at exactly N = d = 2^20 terms (run A).  Q = 2.
+standalone MSM runs at exactly N = d = 2^20 terms (run A); the other reading -- the stated d = 2^20 with
+n = d/8 = 2^17 -- and the Q / seed sensitivities of SURVEY 8d are in `sensitivities`.  Q = 2.
 
 N > 1: one process per GPU, SRS replicated.
   * prove() shards by proof (each rank proves its own proofs: no data-path collective)            -> `value`, weak scaling
-  * `msm`: each rank one 2^20-term slice of an N*2^20-term MSM, 192-byte partials all-gathered    -> weak scaling
+  * `msm`: each rank one 2^20-term slice of an N*2^20-term MSM, partials all-gathered             -> weak scaling
   * `msm_strong`: ONE fixed 2^22-term MSM (BASELINE.json configs[3]) split over the N ranks: term ranges for the
-    accumulation, then an all-to-all of bucket ranges so that each rank reduces 1/N of the buckets, then the 192-byte
-    gather                                                                                          -> strong scaling
+    accumulation, then an all-to-all of bucket ranges so that each rank reduces 1/N of the buckets   -> strong scaling
+  * `prove_strong`: ONE n = 2^20 proof shared by the N ranks (3.3-KB shares all-gathered)             -> strong scaling
+  * `in_process` (rank 0, the other ranks idle on the store): the same three through the C ABI from one process
 All collectives run over RCCL on device tensors (sonic_amd/distributed.py); a process group of ONE rank (launched under
 torch.distributed.run with N = 1) still executes them.
 
 Every number of the roofline objects can be recomputed from the files they name under profiles/.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0; exits non-zero if any leg failed (`leg_errors`).
 """
 from __future__ import annotations
 
@@ -34,6 +41,8 @@ import ctypes as C
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,7 +54,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-ROUND = "r04"
+XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: 7 point-to-point links x ~153 GB/s per GPU
+ROUND = "r05"
 
 
 def log(*a):
@@ -87,7 +97,26 @@ def effective_cores():
     return n
 
 
-def main():
+def scalar_muls_reference(n, Q):
+    """terms of the 7 + 4Q MSMs as the reference runs them (27n + 28 + 2Q + Q(11n + Q))"""
+    return 27 * n + 28 + 2 * Q + Q * (11 * n + Q)
+
+
+def scalar_muls_executed(n, Q, prepared):
+    """terms the kernels actually run per proof (sonic_amd/csrc/share_plan.hpp, share_line): T 7n+9, W_t 7n+8, R / W_a / W_b 3n+4 each,
+    per j: S_j (n + a Q-term MSM over the committed rows when the handle is prepared, else 3n+1), W_j 3n, W'_j 3n; C 2n+Q+1,
+    Q_j 2n+Q each, Q_v 2n+Q"""
+    per_j = ((n + Q) if prepared else (3 * n + 1)) + 3 * n + 3 * n + (2 * n + Q)
+    return (7 * n + 9) + (7 * n + 8) + 3 * (3 * n + 4) + Q * per_j + (2 * n + Q + 1) + (2 * n + Q)
+
+
+def xgmi_exchange_ms(bytes_per_pair, efficiency=0.7, fixed_ms=0.02):
+    """MODEL of an all-to-all / all-gather step between GPUs of one node: every pair has its own xGMI link, so the step takes one
+    message over one link; `efficiency` of the link rate assumed attainable + a fixed launch / synchronisation cost"""
+    return 1e3 * bytes_per_pair / (efficiency * XGMI_LINK_GBS * 1e9) + fixed_ms
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -97,8 +126,8 @@ def main():
     ap.add_argument("--msm-log2", type=int, default=20)
     ap.add_argument("--msm-strong-log2", type=int, default=22, help="terms of the ONE MSM that is split over all ranks (BASELINE configs[3]); capped by the SRS")
     ap.add_argument("--msm-strong", action="store_true", help="only the strong-scaling MSM leg")
-    ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) time one rank's share of the strong-scaling MSM as if there were this many "
-                                                                "ranks: 1/E of the terms, a device copy in place of the all-to-all, 1/E of the buckets")
+    ap.add_argument("--emulate-world", type=int, default=8, help="(1 GPU) also time one rank's share of the strong-scaling MSM as if there were this many "
+                                                                "ranks: 1/E of the terms, a device copy in place of the all-to-all, 1/E of the buckets (0: off)")
     ap.add_argument("--cpu-log2n", type=int, default=0, help="n of the CPU-baseline proof (0: the bench's own n if a probe says it fits --cpu-budget-s, else the largest that does)")
     ap.add_argument("--cpu-budget-s", type=float, default=75.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -110,29 +139,97 @@ def main():
     ap.add_argument("--strong-log2n", type=int, default=20, help="n = 2^this of the ONE proof that all ranks share (north_star: n = 2^20, d = 2^23; BASELINE configs[3] "
                                                                  "as a single instance); 0: skip the leg")
     ap.add_argument("--strong-emulate", type=int, default=8, help="(1 GPU) also time every rank's share of that proof as if there were this many ranks (0: off)")
-    ap.add_argument("--north-star-cpu", action="store_true", help="also time the CPU port on the SAME n = 2^strong-log2n proof (minutes; one-off runs for profiles/)")
+    ap.add_argument("--no-north-star-cpu", action="store_true", help="skip the CPU port on the SAME n = 2^strong-log2n proof (~55 s of the run)")
+    ap.add_argument("--north-star-cpu", action="store_true", help=argparse.SUPPRESS)       # (round 4's opt-in; the leg is on by default now)
     ap.add_argument("--prove-only", action="store_true", help="nothing but the proofs (PMC pass for the per-kernel instruction budget of a proof)")
-    args = ap.parse_args()
+    ap.add_argument("--no-sensitivities", action="store_true", help="skip the second reading (n = d/8) and the Q / seed sensitivities")
+    ap.add_argument("--in-process", action="store_true", help="N > 1 from ONE process through the C ABI (no torch.distributed)")
+    ap.add_argument("--devices", default="", help="(--in-process) comma-separated ordinals instead of 0..N-1; an ordinal may repeat (tests on one GPU)")
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: the N ranks as child processes of torch.distributed.run -- started here, before
+    this process has touched HIP or torch.cuda -- rank 0's JSON line relayed, the children's exit code handed on.  Never a world-1
+    measurement labelled N."""
+    try:
+        import torch
+        have = torch.cuda.device_count()           # (counting does not initialise the GPU on this image)
+    except Exception:
+        have = 0
+    if have < args.gpus and args.backend == "nccl":
+        log(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); not measuring something else under that label")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("bench.py: no RANK in the environment, starting the ranks: " + " ".join(cmd))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line:
+        print(line, flush=True)
+    return proc.returncode if proc.returncode else (0 if line else 4)
+
+
+class Ctx:
+    """what every leg needs: the library, the process group (if any), the default SRS, timing helpers"""
+
+
+def kernel_times(L, K):
+    names = C.create_string_buffer(16384)
+    L.sonic_profile_names(names, 16384)
+    out = {}
+    for nm in names.value.decode().split():
+        ms, cnt = C.c_double(), C.c_int64()
+        L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
+        out[nm] = (ms.value, cnt.value)
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # under torch.distributed.run: a process group even for N = 1
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    if args.gpus > 1 and not launched and not args.in_process:
+        sys.exit(spawn_ranks(args, argv))
+    if args.in_process and launched:
+        log("bench.py: --in-process drives all GPUs from ONE process; do not start it under torch.distributed.run")
+        sys.exit(2)
+
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if launched and world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: refusing to label a {world}-rank measurement as {args.gpus}")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
     ndev = max(1, torch.cuda.device_count())
-    dev_index = local_rank % ndev
+    inproc_devices = None
+    if args.in_process:
+        inproc_devices = [int(v) for v in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        if len(inproc_devices) != args.gpus or any(v < 0 or v >= ndev for v in inproc_devices):
+            log(f"bench.py: --in-process --gpus {args.gpus} needs {args.gpus} device ordinals below {ndev} (got {inproc_devices})")
+            sys.exit(2)
+    dev_index = inproc_devices[0] if inproc_devices else local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     use_nccl = args.backend == "nccl"
     if launched:
+        import datetime
+        # a rank that fails between collectives leaves the others waiting: minutes, not the default half hour, then the run fails loudly
+        tmo = datetime.timedelta(seconds=600)
         if use_nccl:
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=tmo)
     pg = launched
     coll_dev = device if use_nccl else torch.device("cpu")
 
@@ -148,6 +245,7 @@ def main():
     strong_n = min(1 << args.msm_strong_log2, 2 * d)
     K, W = args.steps, args.warmup
     only_strong = args.msm_strong
+    leg_errors = {}
 
     def barrier():
         if pg:
@@ -161,27 +259,64 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t.tolist()]
 
+    def agree(ok: bool) -> bool:
+        """every rank reports whether its side of a phase worked; all continue only if all did (a rank that raised must not
+        leave the others inside the next collective).  One 4-byte all-reduce."""
+        if not pg:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def run_leg(name, body):
+        """body() -> result dict.  An exception on this rank is recorded; the ranks then agree, and a leg that failed anywhere is a
+        failed leg everywhere (its collectives are over: body() either finished them or raised before / between them -- a rank stuck
+        INSIDE a collective is what the process group's timeout is for)."""
+        res, err = None, None
+        try:
+            res = body()
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        if not agree(err is None):
+            leg_errors[name] = err or "failed on another rank"
+            return {"error": leg_errors[name]}
+        return res
+
     # ---------------- setup (untimed): SRS on the GPU, circuit resident in HBM ----------------
     t0 = time.time()
     seed_rng = np.random.default_rng(0)
     x = int.from_bytes(rand_fr_array(seed_rng, 1)[0].tobytes(), "little") | 1
     alpha = int.from_bytes(rand_fr_array(seed_rng, 1)[0].tobytes(), "little") | 1
-    srs = sonic_amd.SRS.new(d, x, alpha)
+    srs = sonic_amd.SRS.new(d, x, alpha, device=dev_index)
     t_srs = time.time() - t0
     pipe = circ = None
     do_prove = not (args.msm_only or only_strong)
     depth = 1 if (args.kernel_table or args.no_pipeline) else 2
+
+    def make_transcripts(seed, count, q=Q):
+        rng_ = np.random.default_rng(seed)
+        out = [rand_fr_array(rng_, 8 + 2 * q) for _ in range(count)]
+        for t in out:
+            t[:, 0] |= 1                                   # evaluation points must be non-zero
+        return out
+
+    circuit = asg = None
     if do_prove:       # --msm-only launches nothing but the stand-alone MSMs (so that a rocprofv3 summary of it is about them)
         circ = big_circuit(1000 + rank, n, Q)
         circuit = sonic_amd.ArithCircuit(sonic_amd.GateWeights(circ["wL"], circ["wR"], circ["wO"]), circ["cs"])
+        asg = sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"])
         pipe = sonic_amd.ProverPipeline(srs, circuit, depth=depth)
-        pipe.set_assignment(sonic_amd.Assignment(circ["aL"], circ["aR"], circ["aO"]))
-    tr_rng = np.random.default_rng(77 + rank)
-    transcripts = [rand_fr_array(tr_rng, 8 + 2 * Q) for _ in range(K + W)]
-    for t in transcripts:
-        t[:, 0] |= 1                                   # evaluation points must be non-zero
+        pipe.set_assignment(asg)
+    transcripts = make_transcripts(77 + rank, K + W)
     if rank == 0:
         log(f"setup: SRS.new(d=2^{args.log2n + 3}) {t_srs:.1f}s, circuit n=2^{args.log2n} Q={Q} resident")
+
+    # ---------------- the whole line from ONE process (--in-process) ----------------
+    if args.in_process:
+        line = in_process_line(args, sonic_amd, L, _lib, srs, x, alpha, circuit, asg, circ, transcripts, inproc_devices, n, Q, d, msm_n, strong_n, K, W,
+                               make_transcripts, rand_fr_array, big_circuit)
+        print(json.dumps(line), flush=True)
+        sys.exit(3 if line.get("leg_errors") else 0)
 
     # ---------------- timed: K x prove() ----------------
     # The K proofs are streamed: one host thread, two prover handles used in turn (sonic_prover_submit / sonic_prover_collect), so
@@ -190,6 +325,15 @@ def main():
     # the next begins: the latency of one proof) is measured right after and reported beside it as "sequential".
     proof = b""
     dt_prove, proofs_per_s, sequential = 1.0, 0.0, None
+
+    def stream_timed(pp, trs_warm, trs_timed):
+        pp.prove_all(trs_warm)
+        barrier()
+        t0_ = time.perf_counter()
+        outs_ = pp.prove_all(trs_timed)
+        barrier()
+        return time.perf_counter() - t0_, outs_
+
     if do_prove:
         pipe.prove_all(transcripts[:max(W, depth)])           # warm-up (also grows every handle's workspaces)
         barrier()
@@ -204,13 +348,7 @@ def main():
         dt_prove = max_over_ranks([dt])[0]
         proofs_per_s = world * K / dt_prove
         if args.kernel_table and rank == 0:
-            names = C.create_string_buffer(8192)
-            L.sonic_profile_names(names, 8192)
-            rows = []
-            for nm in names.value.decode().split():
-                ms, cnt = C.c_double(), C.c_int64()
-                L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
-                rows.append((ms.value, cnt.value, nm))
+            rows = [(ms, cnt, nm) for nm, (ms, cnt) in kernel_times(L, K).items()]
             tot = sum(r[0] for r in rows)
             for ms, cnt, nm in sorted(rows, reverse=True):
                 log(f"  {nm:28s} {ms:10.2f} ms {cnt:7d} launches {100 * ms / tot:5.1f}%")
@@ -227,6 +365,82 @@ def main():
                           "same_bytes_as_streamed": seq_proof == proof}
         for px in pipe.provers[1:]:
             px.close()
+    barrier()
+
+    # ---------------- rank 0: the same proofs without the per-circuit precomputation, and as the reference's one-shot call ----------------
+    # `value` streams over handles that hold circuit and assignment and have committed the constraint rows once (sonic_prover_prepare).
+    # The reference's  prove srs assignment circuit  (Protocol.hs:47-52) hands all of that over per call:
+    #   resident_unprepared  the same stream over handles without prepared rows (every S_j a 3n-term MSM)
+    #   one_shot             sonic_prove: circuit, assignment, transcript as HOST buffers per call (PCIe-inclusive; the library re-uses
+    #                        the shell of the previous one-shot call: streams, workspaces, twiddle tables), one call after the other
+    resident_unprepared = one_shot = batch_c_abi = None
+    if do_prove and rank == 0 and not args.prove_only and not args.kernel_table:
+        def unprepared():
+            pp = sonic_amd.ProverPipeline(srs, circuit, depth=depth, prepare=False)
+            pp.set_assignment(asg)
+            pp.prove_all(transcripts[:max(W, depth)])
+            L.sonic_device_sync()
+            t0_ = time.perf_counter()
+            outs_ = pp.prove_all(transcripts[W:W + K])
+            L.sonic_device_sync()
+            dt_ = time.perf_counter() - t0_
+            pp.close()
+            return {"proofs_per_s_per_gpu": round(K / dt_, 4), "ms_per_proof": round(1e3 * dt_ / K, 2), "same_bytes_as_prepared": outs_[-1] == proof,
+                    "scalar_muls_executed_per_proof": scalar_muls_executed(n, Q, False)}
+
+        def oneshot():
+            psz = L.sonic_proof_size(Q)
+            out = C.create_string_buffer(psz)
+            ptr = lambda a: a.ctypes.data       # noqa: E731
+
+            def call(tr):
+                _lib.check(L.sonic_prove(srs._h, n, Q, ptr(circ["wL"]), ptr(circ["wR"]), ptr(circ["wO"]), ptr(circ["cs"]), ptr(circ["aL"]), ptr(circ["aR"]),
+                                         ptr(circ["aO"]), tr.ctypes.data, out))
+                return out.raw
+            t0_ = time.perf_counter()
+            call(transcripts[0])
+            first_ms = 1e3 * (time.perf_counter() - t0_)
+            for i in range(1, max(1, W)):
+                call(transcripts[i])
+            L.sonic_device_sync()
+            t0_ = time.perf_counter()
+            for i in range(K):
+                last = call(transcripts[W + i])
+            dt_ = time.perf_counter() - t0_
+            host_mb = (3 * Q * n + Q + 3 * n + 8 + 2 * Q) * 32 / 1e6
+            return {"ms_per_proof": round(1e3 * dt_ / K, 2), "proofs_per_s_per_gpu": round(K / dt_, 4), "first_call_ms": round(first_ms, 1),
+                    "host_bytes_per_call_MB": round(host_mb, 1), "same_bytes_as_streamed": last == proof,
+                    "what": "sonic_prove(srs, n, Q, wL, wR, wO, cs, aL, aR, aO, transcript) with host buffers, one finished call after the other: "
+                            "the reference's prove srs assignment circuit (Protocol.hs:47-52); PCIe upload of circuit and assignment inside every call; "
+                            "first_call_ms includes making the handle (streams, workspaces, twiddle tables), which later calls re-use"}
+
+        def batch():
+            # the C entry point of the throughput mode (sonic_prove_batch over two handles on this GPU): the headline's stream without
+            # the Python pipeline around it
+            hs = [sonic_amd.Prover(srs, circuit, prepare=True) for _ in range(2)]
+            for h in hs:
+                h.set_assignment(asg)
+            sonic_amd.prove_batch(hs, transcripts[:max(W, 2)])
+            L.sonic_device_sync()
+            t0_ = time.perf_counter()
+            outs_ = sonic_amd.prove_batch(hs, transcripts[W:W + K])
+            dt_ = time.perf_counter() - t0_
+            for h in hs:
+                h.close()
+            return {"proofs_per_s_per_gpu": round(K / dt_, 4), "ms_per_proof": round(1e3 * dt_ / K, 2), "handles": 2, "same_bytes_as_streamed": outs_[-1] == proof,
+                    "what": "sonic_prove_batch(provers[2], K transcripts): one host thread per handle inside the library"}
+        for nm, fn in (("resident_unprepared", unprepared), ("one_shot", oneshot), ("batch_c_abi", batch)):
+            try:
+                res = fn()
+            except Exception as e:      # noqa: BLE001  (rank-0-only legs: no collective inside)
+                leg_errors[nm] = repr(e)
+                res = {"error": repr(e)}
+            if nm == "resident_unprepared":
+                resident_unprepared = res
+            elif nm == "one_shot":
+                one_shot = res
+            else:
+                batch_c_abi = res
     barrier()
 
     # ---------------- NTT product alone on the chip (rank 0; roofline_ntt) ----------------
@@ -267,7 +481,7 @@ def main():
                "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
                "traffic": (pmc_ntt or {}).get("hbm_bytes_per_product") if M == (pmc_ntt or {}).get("M") else None, "traffic_source": pmc_ntt_src,
                "rocprof_ms_per_product": (pmc_ntt or {}).get("rocprof_ms_per_product"),
-               "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS (round 4) the transforms "
+               "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS the transforms "
                        "are bound by VALU issue: ~356 instructions per butterfly in the generated assembly routines sonic_ntt_bfly2_fwd / _inv (DESIGN.md section 5)"}
         for ptr in (da, db, do):
             L.sonic_dev_free(ptr)
@@ -278,8 +492,10 @@ def main():
     _lib.check(L.sonic_dev_alloc(32 * sc.shape[0], C.byref(dsc)))
     _lib.check(L.sonic_dev_upload(dsc, sc.ctypes.data, 32 * sc.shape[0]))
     msm = roofline = int_roofline = None
-    accum_ms, kern_total = 0.0, 0.0
-    if not only_strong and not args.prove_only:
+    accum = {"ms": 0.0}
+
+    def msm_leg():
+        kern_total = 0.0
         basis, e0 = sd.msm_shard(rank, world, d, msm_n)
         # (1) one MSM after the other, every launch bracketed by HIP events: the dominant kernel's duration for the roofline
         #     (alone on the chip, as in the rocprofv3 summary of --msm-only) and the latency of one MSM.  The partial stays on
@@ -290,18 +506,18 @@ def main():
         barrier()
         L.sonic_profile_reset()
         L.sonic_profile_enable(1)
-        t0 = time.perf_counter()
+        t0_ = time.perf_counter()
         for _ in range(K):
             seq_result = one.run_terms(basis, e0, dsc, msm_n)
         barrier()
-        dt_seq = time.perf_counter() - t0
+        dt_seq = time.perf_counter() - t0_
         L.sonic_profile_enable(0)
         one.close()
         # (2) the same K MSMs streamed over NL lanes: MSM i + 1 is queued before MSM i is collected, so the sort and the
         #     latency-bound reduction of one run under the accumulation of the other; each MSM's partial still goes through the
         #     all-gather and the curve additions.  `msm.value` is this throughput.
         NL = max(0, args.msm_lanes)
-        lanes = [sonic_amd.MsmLane() for _ in range(NL)]
+        lanes = [sonic_amd.MsmLane(dev_index) for _ in range(NL)]
 
         def msm_stream(count):
             res = b""
@@ -320,235 +536,260 @@ def main():
         if NL > 0:
             msm_stream(max(W, NL))
             barrier()
-            t0 = time.perf_counter()
+            t0_ = time.perf_counter()
             stream_result = msm_stream(K)
             barrier()
-            dt = time.perf_counter() - t0
+            dt_ = time.perf_counter() - t0_
         else:
-            stream_result, dt = seq_result, dt_seq
-        dt_msm, dt_msm_seq = max_over_ranks([dt, dt_seq])
+            stream_result, dt_ = seq_result, dt_seq
+        dt_msm, dt_msm_seq = max_over_ranks([dt_, dt_seq])
         msm_per_s = world * msm_n * K / dt_msm
         for ln in lanes:
             ln.close()
-        ms, cnt = C.c_double(), C.c_int64()
-        L.sonic_profile_get(b"k_bucket_accum", C.byref(ms), C.byref(cnt))
-        accum_ms = ms.value / max(1, cnt.value)
-        names = C.create_string_buffer(8192)
-        L.sonic_profile_names(names, 8192)
+        kt = kernel_times(L, K)
+        accum["ms"] = kt.get("k_bucket_accum", (0.0, 0))[0] / max(1, kt.get("k_bucket_accum", (0.0, 1))[1])
         per_kernel = {}
-        for nm in names.value.decode().split():
-            m2, c2 = C.c_double(), C.c_int64()
-            L.sonic_profile_get(nm.encode(), C.byref(m2), C.byref(c2))
-            kern_total += m2.value
-            per_kernel[nm] = round(m2.value / max(1, K), 4)
+        for nm, (m2, c2) in kt.items():
+            kern_total += m2
+            per_kernel[nm] = round(m2 / max(1, K), 4)
             if args.kernel_table and rank == 0:
-                log(f"  [msm] {nm:24s} {m2.value / max(1, c2.value):9.3f} ms/launch x{c2.value}")
-        msm = {"metric": "G1 MSM scalar-muls/sec", "value": round(msm_per_s, 1), "unit": "scalar-muls/s", "N_per_gpu": msm_n, "scaling": "weak",
-               "ms_per_msm": round(1e3 * dt_msm / K, 3),
-               "streaming": (f"K MSMs streamed over {NL} lanes per GPU (submit / collect); one at a time in `sequential`" if NL > 0 else "none (--msm-lanes 0): one MSM at a time"),
-               "sequential": {"scalar_muls_per_s": round(world * msm_n * K / dt_msm_seq, 1), "ms_per_msm": round(1e3 * dt_msm_seq / K, 3),
-                              "kernel_ms_per_msm": round(kern_total / K, 3), "kernel_ms": per_kernel, "same_result_as_streamed": seq_result == stream_result}}
+                log(f"  [msm] {nm:24s} {m2 / max(1, c2):9.3f} ms/launch x{c2}")
+        return {"metric": "G1 MSM scalar-muls/sec", "value": round(msm_per_s, 1), "unit": "scalar-muls/s", "N_per_gpu": msm_n, "scaling": "weak",
+                "ms_per_msm": round(1e3 * dt_msm / K, 3),
+                "streaming": (f"K MSMs streamed over {NL} lanes per GPU (submit / collect); one at a time in `sequential`" if NL > 0 else "none (--msm-lanes 0): one MSM at a time"),
+                "sequential": {"scalar_muls_per_s": round(world * msm_n * K / dt_msm_seq, 1), "ms_per_msm": round(1e3 * dt_msm_seq / K, 3),
+                               "kernel_ms_per_msm": round(kern_total / K, 3), "kernel_ms": per_kernel, "same_result_as_streamed": seq_result == stream_result}}
 
-    # Secondary legs must not take the headline down with them: nothing below has run on more than one GPU before the driver's own
-    # multi-GPU run, so a leg that raises is recorded as {"error": ...} (every rank takes the same path through a leg, so a rank that
-    # fails before a collective fails on all ranks alike; a one-sided failure would surface as the collective's timeout).
-    leg_errors = {}
+    if not only_strong and not args.prove_only:
+        msm = run_leg("msm", msm_leg)
+    accum_ms = accum["ms"]
 
     # ---------------- timed: ONE 2^22-term MSM split over all ranks (strong scaling; BASELINE configs[3]) ----------------
+    def msm_strong_leg():
+        sh = sd.ShardedMsm(srs, rank, world, device)
+        lo, hi = sd.split_range(strong_n, world, rank)
+        dmine = C.c_void_p(dsc.value + 32 * lo)
+        e_lo = -d + lo
+        try:
+            sd.exchange_layout(srs, world)
+            exchange = world > 1
+        except _lib.SonicError:            # an SRS without window tables (SONIC_MSM_TABLES=0, or d too large for them): term ranges only
+            exchange = False
+        if exchange:
+            run = lambda: sh.run_buckets(0, e_lo, dmine, hi - lo)             # noqa: E731
+        elif world > 1:
+            run = lambda: sh.run_terms(0, e_lo, dmine, hi - lo)               # noqa: E731
+        else:
+            run = lambda: sh.run_terms(0, -d, dsc, strong_n)                  # noqa: E731  (one rank: the plain MSM is the baseline of the curve)
+        for _ in range(max(1, W)):
+            res_strong = run()
+        check = sh.run_terms(0, e_lo, dmine, hi - lo)                          # the same sum by term-range partials (every rank its slice)
+        barrier()
+        t0_ = time.perf_counter()
+        for _ in range(K):
+            res_strong = run()
+        barrier()
+        dt_strong = max_over_ranks([time.perf_counter() - t0_])[0]
+        out = {"metric": "one G1 MSM split over all ranks", "N_total": strong_n, "scaling": "strong", "n_gpus": world,
+               "ms_per_msm": round(1e3 * dt_strong / K, 3), "value": round(strong_n * K / dt_strong, 1), "unit": "scalar-muls/s",
+               "method": ("term ranges accumulated per rank, all-to-all of bucket ranges (RCCL), 1/N of the buckets reduced per rank, all-gather of the device-side results"
+                          if exchange else ("term ranges, all-gather (no window tables on this SRS)" if world > 1 else
+                                            "single rank: the plain MSM (baseline of the strong-scaling curve)")),
+               "same_result_as_term_range_sharding": res_strong == check}
+        if args.emulate_world > 1 and world == 1:
+            E = args.emulate_world
+            lo_e, hi_e = sd.split_range(strong_n, E, 0)
+            for _ in range(max(1, W)):
+                sh.run_buckets_emulated(0, -d, dsc, hi_e - lo_e, E)
+            L.sonic_device_sync()
+            L.sonic_profile_reset()
+            L.sonic_profile_enable(1)
+            t0_ = time.perf_counter()
+            for _ in range(K):
+                sh.run_buckets_emulated(0, -d, dsc, hi_e - lo_e, E)
+            L.sonic_device_sync()
+            dte = time.perf_counter() - t0_
+            L.sonic_profile_enable(0)
+            perk = {nm: round(m2 / K, 4) for nm, (m2, _) in kernel_times(L, K).items()}
+            # the exchange the emulation leaves out is a MODELLED term and it is INSIDE the speed-up: each rank sends one slice to each of
+            # the E - 1 peers, every pair on its own xGMI link, so the all-to-all takes one slice over one link (xgmi_exchange_ms)
+            _, S_e = sd.exchange_layout(srs, E)
+            slice_bytes = S_e * 192
+            xch_ms = xgmi_exchange_ms(slice_bytes)
+            share_ms = 1e3 * dte / K
+            out["emulated_share"] = {"world": E, "terms": hi_e - lo_e, "ms_per_share_kernels_only": round(share_ms, 3), "kernel_ms": perk,
+                                     "exchange_model": {"bytes_per_pair": slice_bytes, "link_GBps": XGMI_LINK_GBS, "assumed_efficiency": 0.7, "fixed_ms": 0.02,
+                                                        "ms": round(xch_ms, 3)},
+                                     "ms_per_share": round(share_ms + xch_ms, 3),
+                                     "speedup_vs_single": round(1e3 * (dt_strong / K) / (share_ms + xch_ms), 2),
+                                     "speedup_without_the_exchange": round((dt_strong / K) / (dte / K), 2),
+                                     "note": "UNMEASURED ON MULTI-GPU HARDWARE: one GPU doing one rank's work, device copy instead of the xGMI all-to-all; "
+                                             "ms_per_share and speedup_vs_single INCLUDE the modelled exchange (a model, not a measurement)"}
+        sh.close()
+        return out
+
     msm_strong = None
     if not args.msm_only and not args.prove_only:
+        msm_strong = run_leg("msm_strong", msm_strong_leg)
+
+    # ---------------- stand-alone MSM with protocol-shaped scalars (rank 0) ----------------
+    msm_protocol = None
+    if rank == 0 and not args.msm_only and not args.prove_only and not only_strong and not args.no_sensitivities:
         try:
-            sh = sd.ShardedMsm(srs, rank, world, device)
-            lo, hi = sd.split_range(strong_n, world, rank)
-            dmine = C.c_void_p(dsc.value + 32 * lo)
-            e_lo = -d + lo
-            try:
-                sd.exchange_layout(srs, world)
-                exchange = world > 1
-            except _lib.SonicError:            # an SRS without window tables (SONIC_MSM_TABLES=0, or d too large for them): term ranges only
-                exchange = False
-            if exchange:
-                run = lambda: sh.run_buckets(0, e_lo, dmine, hi - lo)             # noqa: E731
-            elif world > 1:
-                run = lambda: sh.run_terms(0, e_lo, dmine, hi - lo)               # noqa: E731
-            else:
-                run = lambda: sh.run_terms(0, -d, dsc, strong_n)                  # noqa: E731  (one rank: the plain MSM is the baseline of the curve)
-            for _ in range(max(1, W)):
-                res_strong = run()
-            check = sh.run_terms(0, e_lo, dmine, hi - lo)                          # the same sum by term-range partials (every rank its slice)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(K):
-                res_strong = run()
-            barrier()
-            dt_strong = max_over_ranks([time.perf_counter() - t0])[0]
-            msm_strong = {"metric": "one G1 MSM split over all ranks", "N_total": strong_n, "scaling": "strong", "n_gpus": world,
-                          "ms_per_msm": round(1e3 * dt_strong / K, 3), "value": round(strong_n * K / dt_strong, 1), "unit": "scalar-muls/s",
-                          "method": ("term ranges accumulated per rank, all-to-all of bucket ranges (RCCL), 1/N of the buckets reduced per rank, 192-B all-gather"
-                                     if exchange else ("term ranges, 192-B all-gather (no window tables on this SRS)" if world > 1 else
-                                                       "single rank: the plain MSM (baseline of the strong-scaling curve)")),
-                          "same_result_as_term_range_sharding": res_strong == check}
-            if args.emulate_world > 1 and world == 1:
-                E = args.emulate_world
-                lo_e, hi_e = sd.split_range(strong_n, E, 0)
-                for _ in range(max(1, W)):
-                    sh.run_buckets_emulated(0, -d, dsc, hi_e - lo_e, E)
-                L.sonic_device_sync()
-                L.sonic_profile_reset()
-                L.sonic_profile_enable(1)
-                t0 = time.perf_counter()
-                for _ in range(K):
-                    sh.run_buckets_emulated(0, -d, dsc, hi_e - lo_e, E)
-                L.sonic_device_sync()
-                dte = time.perf_counter() - t0
-                L.sonic_profile_enable(0)
-                names = C.create_string_buffer(8192)
-                L.sonic_profile_names(names, 8192)
-                perk = {}
-                for nm in names.value.decode().split():
-                    m2, c2 = C.c_double(), C.c_int64()
-                    L.sonic_profile_get(nm.encode(), C.byref(m2), C.byref(c2))
-                    perk[nm] = round(m2.value / K, 4)
-                # the exchange the emulation leaves out, as a modelled term: each rank sends one slice to each of the E - 1 peers, every pair on
-                # its own xGMI link (point-to-point, 7 links x ~153 GB/s per GPU: MI355X_MICROARCH.md), so the all-to-all takes one slice over
-                # one link; 70 % of the link rate assumed attainable + 20 us for the collective's launch and synchronisation
-                _, S_e = sd.exchange_layout(srs, E)
-                slice_bytes = S_e * 192
-                xch_ms = 1e3 * slice_bytes / (0.7 * 153e9) + 0.02
-                share_ms = 1e3 * dte / K
-                msm_strong["emulated_share"] = {"world": E, "terms": hi_e - lo_e, "ms_per_share": round(share_ms, 3), "kernel_ms": perk,
-                                                "speedup_vs_single": round((dt_strong / K) / (dte / K), 2),
-                                                "exchange_model": {"bytes_per_pair": slice_bytes, "link_GBps": 153, "assumed_efficiency": 0.7, "fixed_ms": 0.02,
-                                                                   "ms": round(xch_ms, 3)},
-                                                "ms_per_share_with_modelled_exchange": round(share_ms + xch_ms, 3),
-                                                "speedup_with_modelled_exchange": round(1e3 * (dt_strong / K) / (share_ms + xch_ms), 2),
-                                                "note": "UNMEASURED ON MULTI-GPU HARDWARE: one GPU doing one rank's work, device copy instead of the xGMI all-to-all "
-                                                        "(its time is the modelled term, not a measurement)"}
-            sh.close()
+            msm_protocol = protocol_shaped_msm(sonic_amd, L, _lib, x, alpha, K, max(1, W))
         except Exception as e:      # noqa: BLE001
-            leg_errors["msm_strong"] = repr(e)
-            msm_strong = {"error": repr(e)}
+            leg_errors["msm_protocol_shaped"] = repr(e)
+            msm_protocol = {"error": repr(e)}
     L.sonic_dev_free(dsc)
+    barrier()
+
+    # ---------------- second reading and sensitivities (rank 0) ----------------
+    sensitivities = None
+    if do_prove and rank == 0 and not args.prove_only and not args.no_sensitivities and not args.kernel_table:
+        try:
+            sensitivities = sensitivity_legs(sonic_amd, L, srs, x, alpha, n, Q, d, K, max(1, W), make_transcripts, big_circuit)
+        except Exception as e:      # noqa: BLE001
+            leg_errors["sensitivities"] = repr(e)
+            sensitivities = {"error": repr(e)}
+    barrier()
 
     # ---------------- timed: ONE proof at the north_star size shared by all ranks (strong scaling of prove()) ----------------
     # Every rank holds the same circuit, assignment and transcript over its replica of the SRS, runs its cost-balanced piece of the
     # proof's 7 + 4Q MSMs (sonic_prover_set_share) and the ranks all-gather their shares (a few KB).  One rank: the plain sequential
     # prove() -- the north_star's "prove() wall-clock at n = 2^20 on 1 MI355X".
+    ns_state = {}
+
+    def prove_strong_leg():
+        ns_lg = args.strong_log2n
+        ns_n, ns_d = 1 << ns_lg, 8 << ns_lg
+        t0_ = time.time()
+        srs_ns = srs if ns_d == d else sonic_amd.SRS.new(ns_d, x, alpha, device=dev_index)
+        t_srs_ns = time.time() - t0_
+        c_ns = circ if (ns_n == n and world == 1) else big_circuit(2000, ns_n, Q)           # the same statement on every rank
+        circuit_ns = sonic_amd.ArithCircuit(sonic_amd.GateWeights(c_ns["wL"], c_ns["wR"], c_ns["wO"]), c_ns["cs"])
+        asg_ns = sonic_amd.Assignment(c_ns["aL"], c_ns["aR"], c_ns["aO"])
+        sp = sd.ShardedProver(srs_ns, circuit_ns, rank, world, device)
+        sp.set_assignment(asg_ns)
+        ns_tr = make_transcripts(4242, K + max(1, W))
+        for i in range(max(1, W)):
+            sp.prove_bytes(ns_tr[i])
+        barrier()
+        t0_ = time.perf_counter()
+        for i in range(K):
+            ns_proof = sp.prove_bytes(ns_tr[max(1, W) + i])
+        barrier()
+        dt_ns = max_over_ranks([time.perf_counter() - t0_])[0]
+        # what every rank spends on its own share (no collective in the timed part): the slowest and the mean over the ranks show how
+        # well the plan balances on real hardware, next to the end-to-end time above
+        share_stats = None
+        if world > 1:
+            t_sh = []
+            for _ in range(3):
+                L.sonic_device_sync()
+                t0_ = time.perf_counter()
+                sp.prove_share(ns_tr[max(1, W) + K - 1])
+                t_sh.append(time.perf_counter() - t0_)
+            mine_ms = 1e3 * min(t_sh)
+            t = torch.tensor([mine_ms], dtype=torch.float64, device=coll_dev)
+            tmax, tsum = t.clone(), t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            share_stats = {"slowest_share_ms": round(float(tmax.item()), 3), "mean_share_ms": round(float(tsum.item()) / world, 3)}
+        same_ns = None
+        if rank == 0 and world > 1:       # the same proof made by this GPU alone (untimed): the bytes must not depend on the sharing
+            alone = sonic_amd.Prover(srs_ns, circuit_ns, prepare=False)
+            alone.set_assignment(asg_ns)
+            same_ns = alone.prove_bytes(ns_tr[max(1, W) + K - 1]) == ns_proof
+            alone.close()
+        share_bytes = L.sonic_proof_share_size(Q)
+        out = {"metric": "ONE prove() shared by all ranks", "n": ns_n, "Q": Q, "d": ns_d, "scaling": "strong", "n_gpus": world,
+               "ms_per_proof": round(1e3 * dt_ns / K, 3), "value": round(K / dt_ns, 4), "unit": "proofs/s",
+               "method": ("every rank builds the polynomials its pieces read and runs a contiguous, cost-balanced piece of the proof's 7+4Q MSMs "
+                          "(cuts inside an MSM split its term range); one all-gather of %d-byte shares; sonic_proof_from_shares on every rank"
+                          % share_bytes) if world > 1 else "single rank: the plain sequential prove() (baseline of the curve)",
+               "same_bytes_as_one_gpu_alone": same_ns, "proof_bytes": len(ns_proof), "srs_new_s": round(t_srs_ns, 2), "shares": share_stats}
+        if world == 1 and args.strong_emulate > 1:
+            E = args.strong_emulate
+            tr_e = ns_tr[max(1, W) + K - 1]
+            ms_e, shares_e = [], []
+            for r in range(E):
+                sp.set_emulated_rank(r, E)
+                sp.prove_share(tr_e)
+                L.sonic_device_sync()
+                t0_ = time.perf_counter()
+                for _ in range(3):
+                    sh_e = sp.prove_share(tr_e)
+                ms_e.append(1e3 * (time.perf_counter() - t0_) / 3)
+                shares_e.append(sh_e)
+            t0_ = time.perf_counter()
+            comb = sonic_amd.proof_from_shares(Q, shares_e, tr_e)
+            t_comb = 1e3 * (time.perf_counter() - t0_)
+            gather_ms = xgmi_exchange_ms(share_bytes)           # the all-gather of the shares, MODELLED like the MSM's exchange and counted
+            plan_e = sonic_amd.share_plan(ns_n, Q, True, E)
+            t_ranks = sum(1 for pieces, _ in plan_e if pieces[1][1] > pieces[1][0] or pieces[4][1] > pieces[4][0])
+            out["emulated_shares"] = {"world": E, "ms_per_share": [round(v, 2) for v in ms_e], "slowest_ms": round(max(ms_e), 2),
+                                      "combine_ms_host": round(t_comb, 3), "allgather_model_ms": round(gather_ms, 3),
+                                      "combined_equals_whole_proof": comb == ns_proof,
+                                      "speedup_vs_one_gpu": round((1e3 * dt_ns / K) / (max(ms_e) + t_comb + gather_ms), 2),
+                                      "ranks_that_repeat_the_t_product": t_ranks,
+                                      "note": "UNMEASURED ON MULTI-GPU HARDWARE: this one GPU ran every rank's share in turn; speedup_vs_one_gpu INCLUDES the host "
+                                              "combine and a MODELLED all-gather of %d bytes per rank (one small message per xGMI link + 20 us)" % share_bytes}
+        ns_state.update(dt_ns=dt_ns, ns_n=ns_n, ns_d=ns_d, srs_ns=srs_ns, c_ns=c_ns, ns_tr=ns_tr, ns_proof=ns_proof, sp=sp)
+        return out
+
     prove_strong = north_star = None
     if do_prove and not args.prove_only and args.strong_log2n > 0:
-        try:
-            ns_lg = args.strong_log2n
-            ns_n, ns_d = 1 << ns_lg, 8 << ns_lg
-            t0 = time.time()
-            srs_ns = srs if ns_d == d else sonic_amd.SRS.new(ns_d, x, alpha)
-            t_srs_ns = time.time() - t0
-            c_ns = circ if (ns_n == n and world == 1) else big_circuit(2000, ns_n, Q)           # the same statement on every rank
-            circuit_ns = sonic_amd.ArithCircuit(sonic_amd.GateWeights(c_ns["wL"], c_ns["wR"], c_ns["wO"]), c_ns["cs"])
-            asg_ns = sonic_amd.Assignment(c_ns["aL"], c_ns["aR"], c_ns["aO"])
-            sp = sd.ShardedProver(srs_ns, circuit_ns, rank, world, device)
-            sp.set_assignment(asg_ns)
-            ns_rng = np.random.default_rng(4242)
-            ns_tr = [rand_fr_array(ns_rng, 8 + 2 * Q) for _ in range(K + max(1, W))]
-            for t in ns_tr:
-                t[:, 0] |= 1
-            for i in range(max(1, W)):
-                sp.prove_bytes(ns_tr[i])
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(K):
-                ns_proof = sp.prove_bytes(ns_tr[max(1, W) + i])
-            barrier()
-            dt_ns = max_over_ranks([time.perf_counter() - t0])[0]
-            # what every rank spends on its own share (no collective in the timed part): the slowest and the mean over the ranks show how
-            # well the plan balances on real hardware, next to the end-to-end time above
-            share_stats = None
-            if world > 1:
-                t_sh = []
-                for _ in range(3):
-                    L.sonic_device_sync()
-                    t0 = time.perf_counter()
-                    sp.prove_share(ns_tr[max(1, W) + K - 1])
-                    t_sh.append(time.perf_counter() - t0)
-                mine_ms = 1e3 * min(t_sh)
-                t = torch.tensor([mine_ms], dtype=torch.float64, device=coll_dev)
-                tmax, tsum = t.clone(), t.clone()
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-                share_stats = {"slowest_share_ms": round(float(tmax.item()), 3), "mean_share_ms": round(float(tsum.item()) / world, 3)}
-            same_ns = None
-            if rank == 0 and world > 1:       # the same proof made by this GPU alone (untimed): the bytes must not depend on the sharing
-                alone = sonic_amd.Prover(srs_ns, circuit_ns, prepare=False)
-                alone.set_assignment(asg_ns)
-                same_ns = alone.prove_bytes(ns_tr[max(1, W) + K - 1]) == ns_proof
-                alone.close()
-            prove_strong = {"metric": "ONE prove() shared by all ranks", "n": ns_n, "Q": Q, "d": ns_d, "scaling": "strong", "n_gpus": world,
-                            "ms_per_proof": round(1e3 * dt_ns / K, 3), "value": round(K / dt_ns, 4), "unit": "proofs/s",
-                            "method": ("every rank builds the polynomials its pieces read and runs a contiguous, cost-balanced piece of the proof's 7+4Q MSMs "
-                                       "(cuts inside an MSM split its term range); one all-gather of %d-byte shares; sonic_proof_from_shares on every rank"
-                                       % L.sonic_proof_share_size(Q)) if world > 1 else "single rank: the plain sequential prove() (baseline of the curve)",
-                            "same_bytes_as_one_gpu_alone": same_ns, "proof_bytes": len(ns_proof), "srs_new_s": round(t_srs_ns, 2), "shares": share_stats}
-            if world == 1 and args.strong_emulate > 1:
-                E = args.strong_emulate
-                tr_e = ns_tr[max(1, W) + K - 1]
-                ms_e, shares_e = [], []
-                for r in range(E):
-                    sp.set_emulated_rank(r, E)
-                    sp.prove_share(tr_e)
-                    L.sonic_device_sync()
-                    t0 = time.perf_counter()
-                    for _ in range(3):
-                        sh_e = sp.prove_share(tr_e)
-                    ms_e.append(1e3 * (time.perf_counter() - t0) / 3)
-                    shares_e.append(sh_e)
-                t0 = time.perf_counter()
-                comb = sonic_amd.proof_from_shares(Q, shares_e, tr_e)
-                t_comb = 1e3 * (time.perf_counter() - t0)
-                prove_strong["emulated_shares"] = {"world": E, "ms_per_share": [round(v, 2) for v in ms_e], "slowest_ms": round(max(ms_e), 2),
-                                                   "combine_ms_host": round(t_comb, 3), "combined_equals_whole_proof": comb == ns_proof,
-                                                   "speedup_vs_one_gpu": round((1e3 * dt_ns / K) / (max(ms_e) + t_comb), 2),
-                                                   "note": "UNMEASURED ON MULTI-GPU HARDWARE: this one GPU ran every rank's share in turn; "
-                                                           "the all-gather of %d bytes per rank over xGMI is not included" % L.sonic_proof_share_size(Q)}
-            if rank == 0 and world == 1:
-                north_star = {"target": "prove() wall-clock at n=2^20 (d = 8n = 2^23; BASELINE states d=2^22, which Protocol.hs:54-55 rejects) on 1 MI355X, "
-                                        ">= 10x the CPU prove(), bit-exact", "n": ns_n, "d": ns_d, "Q": Q,
-                              "ms_per_proof": round(1e3 * dt_ns / K, 3), "how": f"{K} sequential prove() calls, each finished before the next begins"}
-                # the CPU port on this very proof takes ~55 s: not part of the default run (it would double it); the committed measurement
-                # of `bench.py --north-star-cpu` on a box of the same pool is quoted beside the live GPU time, marked as such
-                ref_ns, ref_src = load_profile_json("north_star.json")
-                if ref_ns and ref_ns.get("north_star", {}).get("cpu") and ref_ns["north_star"].get("n") == ns_n:
-                    c_ref = ref_ns["north_star"]["cpu"]
-                    north_star["cpu_from_profile"] = {"file": ref_src, "s_per_proof": c_ref["s_per_proof"], "cores": c_ref["cores"], "kind": c_ref["kind"],
-                                                      "same_bytes_as_gpu_proof_in_that_run": c_ref["same_bytes_as_gpu_proof"],
-                                                      "gpu_ms_in_that_run": ref_ns["north_star"]["ms_per_proof"],
-                                                      "ratio_vs_this_run": round(c_ref["s_per_proof"] / (dt_ns / K), 1),
-                                                      "note": "NOT timed in this run: `python bench.py --north-star-cpu` times it live"}
-                if args.north_star_cpu and not args.no_cpu:
+        prove_strong = run_leg("prove_strong", prove_strong_leg)
+        if "error" not in (prove_strong or {}) and rank == 0 and world == 1:
+            dt_ns, ns_n, ns_d = ns_state["dt_ns"], ns_state["ns_n"], ns_state["ns_d"]
+            north_star = {"target": "prove() wall-clock at n=2^20 (d = 8n = 2^23; BASELINE states d=2^22, which Protocol.hs:54-55 rejects) on 1 MI355X, "
+                                    ">= 10x the CPU prove(), bit-exact", "n": ns_n, "d": ns_d, "Q": Q,
+                          "ms_per_proof": round(1e3 * dt_ns / K, 3), "how": f"{K} sequential prove() calls, each finished before the next begins"}
+            if not args.no_north_star_cpu and not args.no_cpu:
+                # the CPU port on this very proof, timed live in this run (~55 s on the pool's 16 usable cores)
+                try:
                     from oracle import orc
                     cores_ns = effective_cores()
                     orc.set_mode(1, cores_ns)
+                    srs_ns, c_ns, ns_tr = ns_state["srs_ns"], ns_state["c_ns"], ns_state["ns_tr"]
                     o_ns = orc.SRS.from_points(ns_d, srs_ns.points(0, -ns_d, 2 * ns_d + 1), srs_ns.points(1, -ns_d, 2 * ns_d + 1))
                     t0 = time.perf_counter()
                     cp_ns = orc.prove(o_ns, ns_n, Q, c_ns["wL"], c_ns["wR"], c_ns["wO"], c_ns["cs"], c_ns["aL"], c_ns["aR"], c_ns["aO"], ns_tr[max(1, W) + K - 1], True)
                     cdt_ns = time.perf_counter() - t0
-                    north_star["cpu"] = {"kind": "port", "what": "oracle/sonic_oracle.c, the repo's plain-C port (Pippenger + NTT)", "cores": cores_ns, "n": ns_n,
-                                         "s_per_proof": round(cdt_ns, 2), "same_bytes_as_gpu_proof": cp_ns == ns_proof,
+                    north_star["cpu"] = {"kind": "port", "what": "oracle/sonic_oracle.c, the repo's plain-C port (Pippenger + NTT), timed live in this run", "cores": cores_ns, "n": ns_n,
+                                         "s_per_proof": round(cdt_ns, 2), "same_bytes_as_gpu_proof": cp_ns == ns_state["ns_proof"],
                                          "gpu_over_cpu": round(cdt_ns / (dt_ns / K), 1)}
                     del o_ns
-            sp.close()
-            if srs_ns is not srs:
-                del srs_ns
+                except Exception as e:      # noqa: BLE001
+                    leg_errors["north_star_cpu"] = repr(e)
+                    north_star["cpu"] = {"error": repr(e)}
+        if ns_state.get("sp") is not None:
+            ns_state["sp"].close()
+        ns_state.clear()
 
-        except Exception as e:      # noqa: BLE001
-            leg_errors["prove_strong"] = repr(e)
-            prove_strong = {"error": repr(e)}
-            north_star = None
+    # ---------------- rank 0 drives ALL GPUs from this one process through the C ABI (N > 1; the other ranks idle on the store) --------
+    in_process = None
+    if pg and world > 1 and do_prove and not args.prove_only and use_nccl:
+        store = dist.distributed_c10d._get_default_store()
+        barrier()
+        if rank == 0:
+            try:
+                in_process = in_process_legs(sonic_amd, L, _lib, x, alpha, list(range(world)), args.log2n, Q, K, max(1, W), args.strong_log2n, strong_n,
+                                             make_transcripts, rand_fr_array, big_circuit, srs0=srs)
+            except Exception as e:      # noqa: BLE001
+                leg_errors["in_process"] = repr(e)
+                in_process = {"error": repr(e)}
+            store.set("sonic_in_process_done", "1")
+        else:
+            store.wait(["sonic_in_process_done"])         # a host-side wait: no collective kernel spins on this rank's GPU meanwhile
+        barrier()
 
     if rank != 0:
         if pg:
             dist.destroy_process_group()
         return
 
-    if msm is not None:
+    if msm is not None and "error" not in msm:
         # roofline of the dominant kernel (k_bucket_accum of the N = 2^20 MSM): algorithmic bytes = 128 B per
         # scalar-mul (96 B affine point + 32 B scalar) x the terms one launch covers
         alg_bytes = 128.0 * msm_n
@@ -587,83 +828,28 @@ def main():
         else:
             int_roofline = {"note": "profiles/rNN_kernel_model.json missing (tools/kernel_model.py)", "additions_per_launch": n_adds, "kernel_adds_per_s": round(adds_per_s, 1)}
 
-    # whole prove(): SURVEY 8d's algorithmic bytes against the time of one streamed proof
+    # whole prove(): SURVEY 8d's algorithmic bytes against the time of one streamed proof; the scalar-mul rate from the terms the
+    # kernels actually ran (a prepared handle runs ~45n of the reference's 49n: the S_j come from the committed rows)
     roofline_prove = None
     if do_prove:
         lgM = (7 * n + 8).bit_length()
-        scalar_muls = 27 * n + 28 + 2 * Q + Q * (11 * n + Q)
+        scalar_muls = scalar_muls_reference(n, Q)
+        executed = scalar_muls_executed(n, Q, True)
         alg_p = 128.0 * scalar_muls + 288.0 * (1 << lgM)
         roofline_prove = {"bound": "hbm", "algorithmic_bytes_per_proof": alg_p, "scalar_muls_per_proof": scalar_muls, "ntt_size": 1 << lgM,
-                          "rule": "128 B x (27n + 28 + 2Q + Q(11n + Q)) + 288 M (SURVEY 8d)", "achieved": round(alg_p * proofs_per_s / world / 1e9, 2),
+                          "rule": "128 B x (27n + 28 + 2Q + Q(11n + Q)) + 288 M (SURVEY 8d: the reference's 49n terms at Q = 2)", "achieved": round(alg_p * proofs_per_s / world / 1e9, 2),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_p * proofs_per_s / world / 1e9 / HBM_PEAK_GBS, 5),
-                          "scalar_muls_per_s_inside_prove": round(scalar_muls * proofs_per_s, 1)}
+                          "scalar_muls_executed_per_proof": executed,
+                          "scalar_muls_executed_rule": "share_plan.hpp share_line: prepared handles commit S_j as an n-term + a Q-term MSM instead of 3n + 1 terms",
+                          "scalar_muls_per_s_inside_prove": round(executed * proofs_per_s, 1)}
 
     cpu_baseline = None
     if not args.no_cpu and do_prove:
-        from oracle import orc    # the CPU oracle is only ever the baseline leg here, never part of the GPU path
-        cores = effective_cores()
-        cr = np.random.default_rng(3)
-        orc.set_mode(1, cores)
-
-        def cpu_prove_time(lg, osrs_, cc, tr_):
-            m = 1 << lg
-            t0_ = time.perf_counter()
-            pb_ = orc.prove(osrs_, m, Q, cc["wL"], cc["wR"], cc["wO"], cc["cs"], cc["aL"], cc["aR"], cc["aO"], tr_, True)
-            return time.perf_counter() - t0_, pb_
-
-        # probe at n = 2^12 on an oracle-made SRS (cost is ~linear in n), then ONE proof at the largest n <= the bench's n that
-        # fits the budget -- on the bench's own SRS, circuit and transcript when that is the bench's n, so that the CPU proof
-        # can be compared with the GPU's byte for byte.  No extrapolation: what is printed was timed.
-        plg = min(12, args.log2n)
-        pcirc = big_circuit(1, 1 << plg, Q)
-        ptr = rand_fr_array(cr, 8 + 2 * Q)
-        ptr[:, 0] |= 1
-        psrs = orc.SRS(8 << plg, x, alpha, threads=cores)
-        probe, _ = cpu_prove_time(plg, psrs, pcirc, ptr)
-        cpu_lg = args.cpu_log2n if args.cpu_log2n > 0 else args.log2n
-        if args.cpu_log2n <= 0:
-            while cpu_lg > plg and probe * (1 << (cpu_lg - plg)) > args.cpu_budget_s:
-                cpu_lg -= 1
-        same = None
-        if cpu_lg == args.log2n:
-            # the SRS is set-up, not part of prove(): the oracle takes the GPU-made points (orc_srs_from_points) instead of
-            # spending minutes of fixed-base multiplications on the host
-            t0 = time.perf_counter()
-            osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1))
-            t_osrs = time.perf_counter() - t0
-            cdt, cproof = cpu_prove_time(cpu_lg, osrs, circ, transcripts[W + K - 1])
-            same = cproof == proof
-            srs_note = f"SRS points taken from the GPU-made SRS ({t_osrs:.1f}s copy, untimed)"
-        else:
-            cn_ = 1 << cpu_lg
-            t0 = time.perf_counter()
-            osrs = orc.SRS(8 * cn_, x, alpha, threads=cores)
-            t_osrs = time.perf_counter() - t0
-            ccirc = big_circuit(1, cn_, Q)
-            cdt, _ = cpu_prove_time(cpu_lg, osrs, ccirc, ptr)
-            srs_note = f"oracle-made SRS ({t_osrs:.1f}s, untimed)"
-        cmsm_n = min(msm_n, 2 * (8 << cpu_lg))
-        t0 = time.perf_counter()
-        orc.msm_srs(osrs, 0, -(8 << cpu_lg), sc[:cmsm_n], 1, cores)
-        cmsm_dt = time.perf_counter() - t0
-        # the reference-shaped cost ("cpu-literal"): per-term double-and-add fold for the MSMs
-        # (CommitmentScheme.hs:26-29) and the schoolbook product for tPoly, one thread as the reference never forks; small n only
-        orc.set_mode(0, 1)
-        lit_n = 256
-        lc = big_circuit(1, lit_n, Q)
-        lsrs = orc.SRS(8 * lit_n, x, alpha, threads=cores)
-        t0 = time.perf_counter()
-        orc.prove(lsrs, lit_n, Q, lc["wL"], lc["wR"], lc["wO"], lc["cs"], lc["aL"], lc["aR"], lc["aO"], ptr, False)
-        lit_dt = time.perf_counter() - t0
-        orc.set_mode(1, cores)
-        cpu_baseline = {"value": round(1.0 / cdt, 5), "unit": "proofs/s", "cores": cores, "kind": "port",
-                        "n": 1 << cpu_lg, "at_bench_size": cpu_lg == args.log2n, "s_per_proof": round(cdt, 2), "same_bytes_as_gpu_proof": same,
-                        "sample": f"oracle/sonic_oracle.c (Pippenger + NTT, {cores} threads = usable host cores of {os.cpu_count()} visible) ONE prove() at n=2^{cpu_lg}, Q={Q}, d=8n: "
-                                  f"{cdt:.2f}s; {srs_note}; sized by a {probe:.2f}s probe at n=2^{plg} against a {args.cpu_budget_s:.0f}s budget",
-                        "msm_scalar_muls_per_s": round(cmsm_n / cmsm_dt, 1), "msm_sample": f"ONE N={cmsm_n} Pippenger MSM, {cores} threads, {cmsm_dt:.2f}s",
-                        "literal": {"n": lit_n, "s_per_proof": round(lit_dt, 2), "cores": 1,
-                                    "note": "the oracle with the reference's algorithms (fold of per-term double-and-add, schoolbook tPoly): "
-                                            "cost grows like n^2 in tPoly and 380 group operations per term in the MSMs"}}
+        try:
+            cpu_baseline = cpu_baseline_leg(args, sonic_amd, srs, x, alpha, circ, transcripts, proof, sc, n, Q, d, msm_n, K, W, big_circuit, rand_fr_array)
+        except Exception as e:      # noqa: BLE001
+            leg_errors["cpu_baseline"] = repr(e)
+            cpu_baseline = {"error": repr(e)}
 
     line = {
         "metric": "prove() proofs/sec",
@@ -681,11 +867,12 @@ def main():
         "config": {"workload": f"prove(): rndCircuit n=2^{args.log2n}, Q={Q}, SRS d=2^{args.log2n + 3} (d=8n >= 7n, Protocol.hs:54); "
                                f"G1 MSM N=2^{args.msm_log2} per GPU; one G1 MSM N=2^{strong_n.bit_length() - 1} over all GPUs", "n": n, "Q": Q, "d": d,
                    "sharding": "proof-per-rank (value); MSM term-range-sharded (msm, weak); one MSM bucket-range-sharded (msm_strong, strong)",
-                   "streaming": "K proofs streamed by one host thread through 2 prover handles per GPU (submit / collect); "
-                                "the strictly sequential rate is in `sequential`",
+                   "streaming": "K proofs streamed by one host thread through 2 prover handles per GPU (submit / collect), circuit + assignment resident, constraint rows "
+                                "committed once per circuit (sonic_prover_prepare); `sequential`, `resident_unprepared` and `one_shot` are beside it",
                    "process_group": (f"{args.backend}, {world} rank(s)" if pg else "none (plain single-process run)")},
         "msm": msm,
         "msm_strong": msm_strong,
+        "msm_protocol_shaped": msm_protocol,
         "roofline": roofline,
         "int_roofline": int_roofline,
         "roofline_ntt": ntt,
@@ -695,11 +882,336 @@ def main():
         "north_star": north_star,
         "proof_bytes": len(proof),
         "sequential": sequential,
+        "resident_unprepared": resident_unprepared,
+        "one_shot": one_shot,
+        "batch_c_abi": batch_c_abi,
+        "sensitivities": sensitivities,
+        "in_process": in_process,
+        "status": "failed legs: " + ", ".join(sorted(leg_errors)) if leg_errors else "ok",
         "leg_errors": leg_errors or None,
     }
     print(json.dumps(line), flush=True)
     if pg:
         dist.destroy_process_group()
+    if leg_errors:
+        sys.exit(3)
+
+
+# ======================================================================================================================================
+def protocol_shaped_msm(sonic_amd, L, _lib, x, alpha, K, W):
+    """the stand-alone MSM again with the scalars the protocol really feeds it -- the quotient w = (t(X,y) - t(z,y)) / (X - z)
+    of W_t = openPoly(t(X,y), z) (Protocol.hs:81) at n = 2^17: 7n + 8 = 917 512 terms over the stated d = 2^20 SRS -- and with the
+    coefficients of s(X,y) (Signature.hs:42, unprepared S_j: 3n + 1 terms of which 2n are copies of two values and n are zero-free runs),
+    the shape that produces heavy buckets.  The polynomials are built on the host with python integers and the product's own NTT
+    (sonic_amd.workload.wt_quotient_scalars); nothing of the oracle is involved."""
+    from sonic_amd.workload import wt_quotient_scalars
+    lg = 17
+    n, d = 1 << lg, 8 << lg
+    t0 = time.time()
+    srs = sonic_amd.SRS.new(d, x, alpha)
+    wt, sy = wt_quotient_scalars(sonic_amd, 3000, n, 2)
+    t_setup = time.time() - t0
+    out = {"n": n, "d": d, "setup_s": round(t_setup, 2),
+           "what": "sonic_msm_g1_srs_dev over the plain basis from exponent -4n-8 (W_t's slice) / the alpha basis (S_j's slice), scalars resident in HBM, one MSM at a time"}
+    # W_t: plain basis, exponents [-4n-8, 3n-1] (CommitmentScheme.hs:45-47).  S_j = commitPoly(d, s(X,y_j)): alpha basis, shift d - max = 0,
+    # exponents [-n, 2n]; the coefficient at exponent 0 is zero and meets the omitted g^alpha (SRS.hs:38)
+    for name, scal, basis, e0 in (("W_t_quotient", wt, 0, -4 * n - 8), ("s_of_X_y_coefficients", sy, 1, -n)):
+        N = scal.shape[0]
+        dptr = C.c_void_p()
+        _lib.check(L.sonic_dev_alloc(32 * N, C.byref(dptr)))
+        _lib.check(L.sonic_dev_upload(dptr, scal.ctypes.data, 32 * N))
+        res = C.create_string_buffer(96)
+        for _ in range(W):
+            _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
+        L.sonic_device_sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
+        dt = time.perf_counter() - t0
+        uniq = int(np.unique(np.ascontiguousarray(scal).view(np.dtype((np.void, 32)))).shape[0])
+        zeros = int((~scal.any(axis=1)).sum())
+        # the same number of uniform scalars over the same slice, for comparison
+        uni = np.random.default_rng(9).integers(0, 256, size=(N, 32), dtype=np.uint8)
+        uni[:, 31] &= 0x3f
+        _lib.check(L.sonic_dev_upload(dptr, uni.ctypes.data, 32 * N))
+        for _ in range(W):
+            _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
+        L.sonic_device_sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
+        dtu = time.perf_counter() - t0
+        L.sonic_dev_free(dptr)
+        out[name] = {"N": N, "ms_per_msm": round(1e3 * dt / K, 3), "scalar_muls_per_s": round(N * K / dt, 1), "distinct_scalars": uniq, "zero_scalars": zeros,
+                     "uniform_scalars_same_slice_ms": round(1e3 * dtu / K, 3)}
+    srs.close()
+    return out
+
+
+def sensitivity_legs(sonic_amd, L, srs, x, alpha, n, Q, d, K, W, make_transcripts, big_circuit):
+    """prove() at the STATED d with n_eff = d/8 (configs[2] read the other way: n = 2^17, d = 2^20), Q in {1, 4} and seeds 1, 2 at
+    the headline size; each streamed over two prepared handles like `value`"""
+    def stream(srs_, n_, q_, seed):
+        c = big_circuit(seed, n_, q_)
+        circuit = sonic_amd.ArithCircuit(sonic_amd.GateWeights(c["wL"], c["wR"], c["wO"]), c["cs"])
+        pp = sonic_amd.ProverPipeline(srs_, circuit, depth=2)
+        pp.set_assignment(sonic_amd.Assignment(c["aL"], c["aR"], c["aO"]))
+        trs = make_transcripts(900 + seed, K + max(W, 2), q_)
+        pp.prove_all(trs[:max(W, 2)])
+        L.sonic_device_sync()
+        t0 = time.perf_counter()
+        pp.prove_all(trs[max(W, 2):])
+        L.sonic_device_sync()
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in range(K):
+            pp.provers[0].prove_bytes(trs[max(W, 2) + i])
+        dts = time.perf_counter() - t0
+        pp.close()
+        return {"n": n_, "Q": q_, "d": int(srs_.srsD), "seed": seed, "proofs_per_s": round(K / dt, 4), "ms_per_proof": round(1e3 * dt / K, 2),
+                "sequential_ms_per_proof": round(1e3 * dts / K, 2), "rows_with_ones": c["rows"]}
+    out = {}
+    n2, d2 = n // 2, d // 2
+    srs2 = sonic_amd.SRS.new(d2, x, alpha)
+    out["stated_d_reading"] = dict(stream(srs2, n2, Q, 1000), note=f"BASELINE configs[2] read as d = 2^{d2.bit_length() - 1} with n = d/8 (SURVEY 8d (ii))")
+    srs2.close()
+    out["Q1"] = stream(srs, n, 1, 1000)
+    out["Q4"] = stream(srs, n, 4, 1000)
+    out["seed1"] = stream(srs, n, Q, 1)
+    out["seed2"] = stream(srs, n, Q, 2)
+    return out
+
+
+def cpu_baseline_leg(args, sonic_amd, srs, x, alpha, circ, transcripts, proof, sc, n, Q, d, msm_n, K, W, big_circuit, rand_fr_array):
+    from oracle import orc    # the CPU oracle is only ever the baseline leg here, never part of the GPU path
+    cores = effective_cores()
+    cr = np.random.default_rng(3)
+    orc.set_mode(1, cores)
+
+    def cpu_prove_time(lg, osrs_, cc, tr_):
+        m = 1 << lg
+        t0_ = time.perf_counter()
+        pb_ = orc.prove(osrs_, m, Q, cc["wL"], cc["wR"], cc["wO"], cc["cs"], cc["aL"], cc["aR"], cc["aO"], tr_, True)
+        return time.perf_counter() - t0_, pb_
+
+    # probe at n = 2^12 on an oracle-made SRS (cost is ~linear in n), then ONE proof at the largest n <= the bench's n that
+    # fits the budget -- on the bench's own SRS, circuit and transcript when that is the bench's n, so that the CPU proof
+    # can be compared with the GPU's byte for byte.  No extrapolation: what is printed was timed.
+    plg = min(12, args.log2n)
+    pcirc = big_circuit(1, 1 << plg, Q)
+    ptr = rand_fr_array(cr, 8 + 2 * Q)
+    ptr[:, 0] |= 1
+    psrs = orc.SRS(8 << plg, x, alpha, threads=cores)
+    probe, _ = cpu_prove_time(plg, psrs, pcirc, ptr)
+    cpu_lg = args.cpu_log2n if args.cpu_log2n > 0 else args.log2n
+    if args.cpu_log2n <= 0:
+        while cpu_lg > plg and probe * (1 << (cpu_lg - plg)) > args.cpu_budget_s:
+            cpu_lg -= 1
+    same = None
+    if cpu_lg == args.log2n:
+        # the SRS is set-up, not part of prove(): the oracle takes the GPU-made points (orc_srs_from_points) instead of
+        # spending minutes of fixed-base multiplications on the host
+        t0 = time.perf_counter()
+        osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1))
+        t_osrs = time.perf_counter() - t0
+        cdt, cproof = cpu_prove_time(cpu_lg, osrs, circ, transcripts[W + K - 1])
+        same = cproof == proof
+        srs_note = f"SRS points taken from the GPU-made SRS ({t_osrs:.1f}s copy, untimed)"
+    else:
+        cn_ = 1 << cpu_lg
+        t0 = time.perf_counter()
+        osrs = orc.SRS(8 * cn_, x, alpha, threads=cores)
+        t_osrs = time.perf_counter() - t0
+        ccirc = big_circuit(1, cn_, Q)
+        cdt, _ = cpu_prove_time(cpu_lg, osrs, ccirc, ptr)
+        srs_note = f"oracle-made SRS ({t_osrs:.1f}s, untimed)"
+    cmsm_n = min(msm_n, 2 * (8 << cpu_lg))
+    t0 = time.perf_counter()
+    orc.msm_srs(osrs, 0, -(8 << cpu_lg), sc[:cmsm_n], 1, cores)
+    cmsm_dt = time.perf_counter() - t0
+    # the reference-shaped cost (BASELINE.md section 3, "cpu-literal"): per-term double-and-add fold for the MSMs
+    # (CommitmentScheme.hs:26-29) and the schoolbook product for tPoly, one thread as the reference never forks; small n only
+    orc.set_mode(0, 1)
+    lit_n = 256
+    lc = big_circuit(1, lit_n, Q)
+    lsrs = orc.SRS(8 * lit_n, x, alpha, threads=cores)
+    t0 = time.perf_counter()
+    orc.prove(lsrs, lit_n, Q, lc["wL"], lc["wR"], lc["wO"], lc["cs"], lc["aL"], lc["aR"], lc["aO"], ptr, False)
+    lit_dt = time.perf_counter() - t0
+    orc.set_mode(1, cores)
+    return {"value": round(1.0 / cdt, 5), "unit": "proofs/s", "cores": cores, "kind": "port",
+            "n": 1 << cpu_lg, "at_bench_size": cpu_lg == args.log2n, "s_per_proof": round(cdt, 2), "same_bytes_as_gpu_proof": same,
+            "sample": f"oracle/sonic_oracle.c (Pippenger + NTT, {cores} threads = usable host cores of {os.cpu_count()} visible) ONE prove() at n=2^{cpu_lg}, Q={Q}, d=8n: "
+                      f"{cdt:.2f}s; {srs_note}; sized by a {probe:.2f}s probe at n=2^{plg} against a {args.cpu_budget_s:.0f}s budget",
+            "msm_scalar_muls_per_s": round(cmsm_n / cmsm_dt, 1), "msm_sample": f"ONE N={cmsm_n} Pippenger MSM, {cores} threads, {cmsm_dt:.2f}s",
+            "literal": {"n": lit_n, "s_per_proof": round(lit_dt, 2), "cores": 1,
+                        "note": "the oracle with the reference's algorithms (fold of per-term double-and-add, schoolbook tPoly): "
+                                "cost grows like n^2 in tPoly and 380 group operations per term in the MSMs"}}
+
+
+def in_process_legs(sonic_amd, L, _lib, x, alpha, devices, log2n, Q, K, W, strong_log2n, strong_n, make_transcripts, rand_fr_array, big_circuit, srs0=None):
+    """ONE host process, every GPU in `devices`, nothing but the C ABI: replicas by SRS.new on each device (concurrently) or copied
+    device to device, then
+      proofs        sonic_prove_batch over two prepared handles per device (weak scaling: K proofs per device)
+      prove_strong  sonic_prove_shared: one n = 2^strong_log2n proof over one handle per device
+      msm_strong    sonic_msm_g1_srs_multi_dev by bucket range: one strong_n-term MSM, slices resident on the devices
+    Bytes are compared with one device alone."""
+    import threading
+    world = len(devices)
+    n, d = 1 << log2n, 8 << log2n
+    out = {"devices": devices, "what": "one host process drives every GPU through include/sonic_hip.h alone (no torch.distributed, no RCCL): one host thread per handle inside the library"}
+    t0 = time.time()
+    reps = [None] * world
+    errs = []
+
+    def mk(i):
+        try:
+            if i == 0 and srs0 is not None and srs0.device == devices[0]:
+                reps[i] = srs0
+            else:
+                reps[i] = sonic_amd.SRS.new(d, x, alpha, device=devices[i])
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=mk, args=(i,)) for i in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise RuntimeError("SRS.new on the devices failed: " + "; ".join(errs))
+    out["srs_new_s_all_devices_concurrently"] = round(time.time() - t0, 2)
+    # -- throughput: K proofs per device over 2 handles per device
+    c = big_circuit(1000, n, Q)
+    circuit = sonic_amd.ArithCircuit(sonic_amd.GateWeights(c["wL"], c["wR"], c["wO"]), c["cs"])
+    asg = sonic_amd.Assignment(c["aL"], c["aR"], c["aO"])
+    handles = []
+    for r in reps:
+        for _ in range(2):
+            h = sonic_amd.Prover(r, circuit, prepare=True)
+            h.set_assignment(asg)
+            handles.append(h)
+    # proof i runs on handle i % len(handles): interleave the devices so that consecutive proofs go to different GPUs
+    handles = handles[0::2] + handles[1::2]
+    trs = make_transcripts(77, (K + max(W, 2)) * world)
+    sonic_amd.prove_batch(handles, trs[:max(W, 2) * world])
+    t0 = time.perf_counter()
+    proofs = sonic_amd.prove_batch(handles, trs[max(W, 2) * world:])
+    dt = time.perf_counter() - t0
+    alone = handles[0].prove_bytes(trs[-1])
+    out["proofs"] = {"metric": "prove() proofs/sec", "value": round(K * world / dt, 4), "ms_per_proof_per_gpu": round(1e3 * dt / K, 2), "n": n, "Q": Q, "scaling": "weak",
+                     "proofs_timed": K * world, "handles": len(handles), "same_bytes_as_one_handle_alone": proofs[-1] == alone,
+                     "entry": "sonic_prove_batch"}
+    for h in handles:
+        h.close()
+    # -- one MSM of strong_n terms by bucket range
+    sc = rand_fr_array(np.random.default_rng(500), strong_n)
+    slices = []
+    for i, r in enumerate(reps):
+        lo, hi = strong_n * i // world, strong_n * (i + 1) // world
+        ptr = C.c_void_p()
+        _lib.check(L.sonic_dev_alloc_on(devices[i], 32 * max(1, hi - lo), C.byref(ptr)))
+        if hi > lo:
+            _lib.check(L.sonic_dev_upload(ptr, sc[lo:hi].ctypes.data, 32 * (hi - lo)))
+        slices.append((-d + lo, ptr, hi - lo))
+    res = {}
+    for mode, name in ((1, "bucket_ranges"), (0, "term_ranges")):
+        try:
+            for _ in range(W):
+                got = sonic_amd.msm_g1_srs_multi(reps, 0, -d, None, mode=mode, d_slices=slices)
+            t0 = time.perf_counter()
+            for _ in range(K):
+                got = sonic_amd.msm_g1_srs_multi(reps, 0, -d, None, mode=mode, d_slices=slices)
+            dtm = time.perf_counter() - t0
+            res[name] = {"ms_per_msm": round(1e3 * dtm / K, 3), "scalar_muls_per_s": round(strong_n * K / dtm, 1), "result": got.hex()[:16]}
+        except Exception as e:      # noqa: BLE001
+            res[name] = {"error": repr(e)}
+    one_ptr = C.c_void_p()
+    _lib.check(L.sonic_dev_alloc_on(devices[0], 32 * strong_n, C.byref(one_ptr)))
+    _lib.check(L.sonic_dev_upload(one_ptr, sc.ctypes.data, 32 * strong_n))
+    one = C.create_string_buffer(96)
+    for _ in range(W):
+        _lib.check(L.sonic_msm_g1_srs_dev(reps[0]._h, 0, -d, one_ptr, strong_n, one))
+    t0 = time.perf_counter()
+    for _ in range(K):
+        _lib.check(L.sonic_msm_g1_srs_dev(reps[0]._h, 0, -d, one_ptr, strong_n, one))
+    dt1 = time.perf_counter() - t0
+    L.sonic_dev_free(one_ptr)
+    for _, ptr, _ in slices:
+        L.sonic_dev_free(ptr)
+    for v in res.values():
+        if "result" in v:
+            v["same_result_as_one_gpu"] = v.pop("result") == one.raw.hex()[:16]
+            v["speedup_vs_one_gpu"] = round((1e3 * dt1 / K) / v["ms_per_msm"], 2)
+    out["msm_strong"] = dict(res, N_total=strong_n, one_gpu_ms_per_msm=round(1e3 * dt1 / K, 3), scaling="strong", entry="sonic_msm_g1_srs_multi_dev")
+    for i, r in enumerate(reps):
+        if r is not srs0:
+            r.close()
+    # -- one proof at the north-star size over one handle per device
+    if strong_log2n > 0:
+        ns_n, ns_d = 1 << strong_log2n, 8 << strong_log2n
+        reps2 = [None] * world
+
+        def mk2(i):
+            try:
+                reps2[i] = sonic_amd.SRS.new(ns_d, x, alpha, device=devices[i])
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=mk2, args=(i,)) for i in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise RuntimeError("SRS.new (north-star size) failed: " + "; ".join(errs))
+        c2 = big_circuit(2000, ns_n, Q)
+        circuit2 = sonic_amd.ArithCircuit(sonic_amd.GateWeights(c2["wL"], c2["wR"], c2["wO"]), c2["cs"])
+        asg2 = sonic_amd.Assignment(c2["aL"], c2["aR"], c2["aO"])
+        hs = []
+        for r in reps2:
+            h = sonic_amd.Prover(r, circuit2, prepare=True)
+            h.set_assignment(asg2)
+            hs.append(h)
+        tr2 = make_transcripts(4242, K + W)
+        for i in range(W):
+            sonic_amd.prove_shared(hs, tr2[i])
+        t0 = time.perf_counter()
+        for i in range(K):
+            shared = sonic_amd.prove_shared(hs, tr2[W + i])
+        dts = time.perf_counter() - t0
+        hs[0].set_share(0, 1)
+        hs[0].prove_bytes(tr2[W + K - 1])
+        t0 = time.perf_counter()
+        for i in range(K):
+            alone2 = hs[0].prove_bytes(tr2[W + i])
+        dta = time.perf_counter() - t0
+        out["prove_strong"] = {"n": ns_n, "d": ns_d, "Q": Q, "scaling": "strong", "ms_per_proof": round(1e3 * dts / K, 3), "one_gpu_ms_per_proof": round(1e3 * dta / K, 3),
+                               "speedup_vs_one_gpu": round(dta / dts, 2), "same_bytes_as_one_gpu_alone": shared == alone2, "entry": "sonic_prove_shared"}
+        for h in hs:
+            h.close()
+        for r in reps2:
+            r.close()
+    return out
+
+
+def in_process_line(args, sonic_amd, L, _lib, srs, x, alpha, circuit, asg, circ, transcripts, devices, n, Q, d, msm_n, strong_n, K, W, make_transcripts, rand_fr_array,
+                    big_circuit):
+    """`bench.py --gpus N --in-process`: the contract's line with every leg made by ONE process through the C ABI"""
+    errs = {}
+    try:
+        legs = in_process_legs(sonic_amd, L, _lib, x, alpha, devices, args.log2n, Q, K, max(1, W), args.strong_log2n, strong_n, make_transcripts, rand_fr_array, big_circuit, srs0=srs)
+    except Exception as e:      # noqa: BLE001
+        legs = {"error": repr(e)}
+        errs["in_process"] = repr(e)
+    pr = legs.get("proofs", {})
+    world = len(devices)
+    return {"metric": "prove() proofs/sec", "value": pr.get("value", 0.0), "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": pr.get("ms_per_proof_per_gpu"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (Fq 12x32, Fr 8x32 Montgomery)", "data": "synthetic",
+            "config": {"workload": f"prove(): rndCircuit n=2^{args.log2n}, Q={Q}, SRS d=2^{args.log2n + 3} (d=8n >= 7n, Protocol.hs:54); one G1 MSM N=2^{strong_n.bit_length() - 1} over all GPUs; "
+                                   f"one prove() n=2^{args.strong_log2n} over all GPUs", "n": n, "Q": Q, "d": d,
+                       "sharding": "proof-per-device (value: sonic_prove_batch); one MSM bucket-range-sharded (sonic_msm_g1_srs_multi_dev); one proof shared (sonic_prove_shared)",
+                       "process_group": f"none: ONE process, devices {devices}, host threads inside libsonic_hip.so"},
+            "in_process": legs, "status": "ok" if not errs else "failed legs: in_process", "leg_errors": errs or None}
 
 
 if __name__ == "__main__":

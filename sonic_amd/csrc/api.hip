@@ -97,6 +97,20 @@ DeviceScope::~DeviceScope() {
   t_ctx = prev_ctx_;
   if (prev_dev_ >= 0 && prev_dev_ != ctx_->dev) (void)hipSetDevice(prev_dev_);
 }
+const NttTables& device_ntt_tables(int log2n) {
+  DeviceCtx& c = current_ctx();
+  std::lock_guard<std::mutex> g(c.pool_mu);
+  NttTables*& t = c.prover_ntt[log2n];
+  if (!t) {
+    std::unique_ptr<NttTables> nt(new NttTables());
+    hipStream_t st = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    try { nt->ensure(st, log2n); HIP_OK(hipStreamSynchronize(st)); } catch (...) { (void)hipStreamDestroy(st); throw; }
+    (void)hipStreamDestroy(st);
+    t = nt.release();
+  }
+  return *t;
+}
 DeviceCtx& current_ctx() {
   if (!t_ctx) { set_error("internal: no device scope on this thread"); throw HipFail{SONIC_ERR_HIP}; }
   return *t_ctx;
@@ -383,7 +397,7 @@ int sonic_srs_from_points_on(int device, int64_t d, const uint8_t* basis0, const
 
 void sonic_srs_free(sonic_srs_t* srs) {
   if (!srs) return;
-  try { DeviceScope scope(srs->device); delete srs; } catch (const HipFail&) { delete srs; }
+  try { DeviceScope scope(srs->device); drop_one_shot_of(srs); delete srs; } catch (const HipFail&) { delete srs; }
 }
 int64_t sonic_srs_d(const sonic_srs_t* srs) { return srs ? srs->d : -1; }
 int sonic_srs_device(const sonic_srs_t* srs) { return srs ? srs->device : -1; }
@@ -608,6 +622,9 @@ struct sonic_msm_lane {
   int segment = 16;
   bool in_flight = false;
   bool own_stream = true;        // false: the lane runs on a stream the caller owns (sonic_msm_lane_new_on_stream)
+  // sonic_msm_g1_srs_multi keeps a pooled lane's exchange buffers across calls: this rank's scalar slice (host-scalar form), its full
+  // bucket set, the slices it pulled from its peers, its device-side result
+  DevBuf x_scalars, x_buckets, x_slices, x_part;
   std::mutex mu;
   ~sonic_msm_lane() {
     if (st) { (void)hipStreamSynchronize(st); if (own_stream) (void)hipStreamDestroy(st); }
@@ -720,20 +737,34 @@ int sonic_msm_collect(sonic_msm_lane_t* l, uint8_t* out_g1, uint8_t* out_partial
   API_END
 }
 
+// a lane of the current device's pool (made on first need; workspaces and buffers stay with it), handed back when the holder dies
+struct PooledLane {
+  DeviceCtx& ctx;
+  sonic_msm_lane_t* lane = nullptr;
+  explicit PooledLane(DeviceCtx& c) : ctx(c) {
+    {
+      std::lock_guard<std::mutex> g(ctx.pool_mu);
+      if (!ctx.lanes.empty()) { lane = static_cast<sonic_msm_lane_t*>(ctx.lanes.back()); ctx.lanes.pop_back(); }
+    }
+    if (!lane) {
+      int rc = sonic_msm_lane_new_on(ctx.dev, &lane);
+      if (rc) throw HipFail{rc};
+      lane->segment = 8;          // one MSM at a time: shortest chain
+    }
+  }
+  ~PooledLane() { if (lane) { std::lock_guard<std::mutex> g(ctx.pool_mu); ctx.lanes.push_back(lane); } }
+  PooledLane(const PooledLane&) = delete;
+  PooledLane& operator=(const PooledLane&) = delete;
+};
+
 // the blocking entry points run on one shared lane (pinned result slot, one host synchronisation per call)
 static int msm_srs_common(const sonic_srs_t* srs, int basis, int64_t e0, const void* d_scalars, const uint8_t* h_scalars,
                           int64_t n, uint8_t* out96, uint8_t* out192) {
   API_BEGIN_ON(srs_device(srs))
   if (!srs || n < 0 || (basis != 0 && basis != 1)) return SONIC_ERR_INVALID_ARG;
   // a lane per call from the device's pool (the blocking MSMs of different host threads run side by side)
-  DeviceCtx& ctx = current_ctx();
-  sonic_msm_lane_t* lane = nullptr;
-  {
-    std::lock_guard<std::mutex> g(ctx.pool_mu);
-    if (!ctx.lanes.empty()) { lane = static_cast<sonic_msm_lane_t*>(ctx.lanes.back()); ctx.lanes.pop_back(); }
-  }
-  if (!lane) { int rc = sonic_msm_lane_new_on(ctx.dev, &lane); if (rc) return rc; lane->segment = 8; }     // one MSM at a time: shortest chain
-  struct Back { sonic_msm_lane_t* l; DeviceCtx& c; ~Back() { std::lock_guard<std::mutex> g(c.pool_mu); c.lanes.push_back(l); } } back{lane, ctx};
+  PooledLane pooled(current_ctx());
+  sonic_msm_lane_t* lane = pooled.lane;
   DevBuf sc;
   const void* dsc = d_scalars;
   if (h_scalars && n > 0) {
@@ -869,47 +900,51 @@ static int msm_multi(const sonic_srs_t* const* srs, int world, int basis, const 
   HostBarrier bar(world);
   auto body = [&](int r) {
     int rc = SONIC_OK;
-    sonic_msm_lane_t* lane = nullptr;
-    void *dsc = nullptr, *buckets = nullptr, *slices = nullptr, *dpart = nullptr;
     const int dev = srs[r]->device;
     bool at_barrier_1 = false, at_barrier_2 = false;
     auto fail = [&](int code) { rc = code; char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)r] = b; };
-    do {
-      if ((rc = sonic_msm_lane_new_on(dev, &lane))) { fail(rc); break; }
-      const void* sc = d_scalars ? d_scalars[r] : nullptr;
-      if (!d_scalars && n[r] > 0) {
-        if ((rc = sonic_dev_alloc_on(dev, 32 * (size_t)n[r], &dsc)) || (rc = sonic_dev_upload(dsc, h_scalars[r], 32 * (size_t)n[r]))) { fail(rc); break; }
-        sc = dsc;
-      }
-      if (!exchange) {
-        uint8_t part[192];
-        if ((rc = sonic_msm_submit(lane, srs[r], basis, e0[r], sc, n[r])) || (rc = sonic_msm_collect(lane, nullptr, part))) { fail(rc); break; }
-        memcpy(&partial[(size_t)r], part, 192);
-        break;
-      }
-      const size_t cap = (size_t)world * (size_t)S;
-      if ((rc = sonic_dev_alloc_on(dev, cap * sizeof(G1XYZZ), &buckets)) || (rc = sonic_dev_alloc_on(dev, cap * sizeof(G1XYZZ), &slices)) ||
-          (rc = sonic_dev_alloc_on(dev, sizeof(MsmSlot), &dpart))) { fail(rc); break; }
-      if ((rc = sonic_msm_accumulate_dev(lane, srs[r], basis, e0[r], sc, n[r], buckets, (int64_t)cap)) || (rc = sonic_msm_lane_sync(lane))) { fail(rc); }
-      bucket_ptr[(size_t)r] = rc ? nullptr : buckets;
-      bar.wait(); at_barrier_1 = true;                           // every rank's buckets are complete (or it has failed)
-      bool all = true;
-      for (int q = 0; q < world; q++) all = all && bucket_ptr[(size_t)q] != nullptr;
-      if (all) {
-        try {
-          DeviceScope scope(dev);
-          for (int q = 0; q < world; q++)                        // slice r of rank q -> slot q of my [world][S] buffer
-            HIP_OK(hipMemcpyPeerAsync(static_cast<G1XYZZ*>(slices) + (size_t)q * S, dev, static_cast<const G1XYZZ*>(bucket_ptr[(size_t)q]) + (size_t)r * S,
-                                      srs[q]->device, (size_t)S * sizeof(G1XYZZ), lane->st));
-        } catch (const HipFail& f) { fail(f.code); }
-        if (!rc && ((rc = sonic_msm_reduce_slices_dev_v2(lane, srs[r], slices, world, S, (int64_t)r * S, dpart, sizeof(MsmSlot))) || (rc = sonic_msm_lane_sync(lane)) ||
-                    (rc = sonic_dev_download(&blobs[sizeof(MsmSlot) * (size_t)r], dpart, sizeof(MsmSlot))))) fail(rc);
-      } else if (!rc) { rc = SONIC_ERR_HIP; errs[(size_t)r] = "a peer rank failed before the bucket exchange"; }
-      bar.wait(); at_barrier_2 = true;                           // nobody frees its buckets while a peer still reads them
-    } while (false);
+    try {
+      DeviceScope scope(dev);
+      PooledLane pooled(current_ctx());          // the device's pooled lanes keep their workspaces and exchange buffers from call to call
+      sonic_msm_lane_t* lane = pooled.lane;
+      do {
+        const void* sc = d_scalars ? d_scalars[r] : nullptr;
+        if (!d_scalars && n[r] > 0) {
+          lane->x_scalars.ensure(32 * (size_t)n[r]);
+          HIP_OK(hipMemcpyAsync(lane->x_scalars.p, h_scalars[r], 32 * (size_t)n[r], hipMemcpyHostToDevice, lane->st));
+          sc = lane->x_scalars.p;
+        }
+        if (!exchange) {
+          uint8_t part[192];
+          if ((rc = sonic_msm_submit(lane, srs[r], basis, e0[r], sc, n[r])) || (rc = sonic_msm_collect(lane, nullptr, part))) { fail(rc); (void)hipStreamSynchronize(lane->st); break; }
+          memcpy(&partial[(size_t)r], part, 192);
+          break;
+        }
+        const size_t cap = (size_t)world * (size_t)S;
+        lane->x_buckets.ensure(cap * sizeof(G1XYZZ)); lane->x_slices.ensure(cap * sizeof(G1XYZZ)); lane->x_part.ensure(sizeof(MsmSlot));
+        if ((rc = sonic_msm_accumulate_dev(lane, srs[r], basis, e0[r], sc, n[r], lane->x_buckets.p, (int64_t)cap)) || (rc = sonic_msm_lane_sync(lane))) fail(rc);
+        if (rc) (void)hipStreamSynchronize(lane->st);
+        bucket_ptr[(size_t)r] = rc ? nullptr : lane->x_buckets.p;
+        bar.wait(); at_barrier_1 = true;                           // every rank's buckets are complete (or it has failed)
+        bool all = true;
+        for (int q = 0; q < world; q++) all = all && bucket_ptr[(size_t)q] != nullptr;
+        if (all) {
+          try {
+            for (int q = 0; q < world; q++)                        // slice r of rank q -> slot q of my [world][S] buffer
+              HIP_OK(hipMemcpyPeerAsync(lane->x_slices.as<G1XYZZ>() + (size_t)q * S, dev, static_cast<const G1XYZZ*>(bucket_ptr[(size_t)q]) + (size_t)r * S,
+                                        srs[q]->device, (size_t)S * sizeof(G1XYZZ), lane->st));
+          } catch (const HipFail& f) { fail(f.code); }
+          if (!rc && ((rc = sonic_msm_reduce_slices_dev_v2(lane, srs[r], lane->x_slices.p, world, S, (int64_t)r * S, lane->x_part.p, sizeof(MsmSlot))) ||
+                      (rc = sonic_msm_lane_sync(lane)))) fail(rc);
+          if (!rc) {
+            try { HIP_OK(hipMemcpy(&blobs[sizeof(MsmSlot) * (size_t)r], lane->x_part.p, sizeof(MsmSlot), hipMemcpyDeviceToHost)); } catch (const HipFail& f) { fail(f.code); }
+          }
+        } else if (!rc) { rc = -1; errs[(size_t)r] = "a peer rank failed before the bucket exchange"; }      // (secondary: the peer's own status is the call's)
+        (void)hipStreamSynchronize(lane->st);
+        bar.wait(); at_barrier_2 = true;                           // nobody re-uses its buckets while a peer still reads them
+      } while (false);
+    } catch (const HipFail& f) { fail(f.code); }
     if (exchange) { if (!at_barrier_1) bar.wait(); if (!at_barrier_2) bar.wait(); }
-    if (lane) sonic_msm_lane_free(lane);
-    for (void* pz : {dsc, buckets, slices, dpart}) if (pz) sonic_dev_free(pz);
     rcs[(size_t)r] = rc;
   };
   if (world == 1) body(0);
@@ -918,8 +953,12 @@ static int msm_multi(const sonic_srs_t* const* srs, int world, int basis, const 
     for (int r = 0; r < world; r++) th.emplace_back(body, r);
     for (auto& t : th) t.join();
   }
-  for (int r = 0; r < world; r++)
-    if (rcs[(size_t)r]) { set_error("sonic_msm_g1_srs_multi, rank %d (device %d): %s", r, srs[r]->device, errs[(size_t)r].c_str()); return rcs[(size_t)r]; }
+  for (int pass = 0; pass < 2; pass++)               // a rank's own failure first; "a peer failed" only if nothing else explains it
+    for (int r = 0; r < world; r++)
+      if (pass == 0 ? rcs[(size_t)r] > 0 : rcs[(size_t)r] != 0) {
+        set_error("sonic_msm_g1_srs_multi, rank %d (device %d): %s", r, srs[r]->device, errs[(size_t)r].c_str());
+        return rcs[(size_t)r] > 0 ? rcs[(size_t)r] : SONIC_ERR_HIP;
+      }
   if (exchange) return sonic_g1_sum_dev_partials(blobs.data(), world, out_g1);
   G1XYZZ acc = G1XYZZ::inf();
   for (int r = 0; r < world; r++) acc = g1_add(acc, partial[(size_t)r]);

@@ -27,7 +27,15 @@ struct DeviceCtx {
   NttTables* ntt = nullptr;              // sonic_ntt_fr / sonic_poly_mul_fr[_dev] (under call_mu)
   DevBuf mul_a, mul_b, mul_flags;        // scratch of sonic_poly_mul_fr_dev (under call_mu)
   int sort_staged = -1;                  // msm.hip: the LDS-staged sort passes got their dynamic-LDS attribute on this device (-1: not asked yet)
+  // twiddle tables of the prover handles, one set per transform size, shared by every handle on the device and never freed (64 + 64 MB
+  // at 2^21 points: two streaming handles used to hold one copy each) (under pool_mu)
+  std::map<int, NttTables*> prover_ntt;
+  // the prover shell the one-shot sonic_prove keeps for the next call with the same SRS and circuit shape (prove.hip)
+  std::mutex one_shot_mu;
+  void* one_shot = nullptr;
 };
+const NttTables& device_ntt_tables(int log2n);          // of the current device; built on first use (blocks until they are complete)
+void drop_one_shot_of(const sonic_srs* s);              // an SRS handle is going away: the cached one-shot shell over it goes first
 // dev < 0: the process's default device (sonic_init, else LOCAL_RANK % device count, else 0).  Throws HipFail{SONIC_ERR_NO_DEVICE}
 // without a GPU -- the library has no CPU fallback -- and HipFail{SONIC_ERR_INVALID_ARG} for an ordinal the node does not have.
 class DeviceScope {

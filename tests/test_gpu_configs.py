@@ -369,6 +369,26 @@ def test_bench_under_the_driver_launch_line_one_rank_rccl():
     assert ps["n"] == 1 << 13 and ps["n_gpus"] == 1 and ps["ms_per_proof"] > 0
     assert ps["emulated_shares"]["world"] == 8 and ps["emulated_shares"]["combined_equals_whole_proof"] is True
     assert j["north_star"]["n"] == 1 << 13 and j["north_star"]["ms_per_proof"] == ps["ms_per_proof"]
+    # round 5: the reference's own call shape and the unprepared stream beside the headline, the C entry point of the throughput mode,
+    # SURVEY 8d's second reading / sensitivities / protocol-shaped scalars, the executed-terms accounting, and a status the driver can read
+    assert j["status"] == "ok" and j["leg_errors"] is None
+    assert j["one_shot"]["same_bytes_as_streamed"] is True and j["one_shot"]["ms_per_proof"] > 0 and j["one_shot"]["first_call_ms"] > 0
+    assert j["resident_unprepared"]["same_bytes_as_prepared"] is True and j["batch_c_abi"]["same_bytes_as_streamed"] is True
+    n_, q_ = j["config"]["n"], j["config"]["Q"]
+    rp = j["roofline_prove"]
+    assert rp["scalar_muls_per_proof"] == 27 * n_ + 28 + 2 * q_ + q_ * (11 * n_ + q_) and rp["scalar_muls_executed_per_proof"] == 45 * n_ + 42
+    assert j["resident_unprepared"]["scalar_muls_executed_per_proof"] == 49 * n_ + 40
+    assert abs(rp["scalar_muls_per_s_inside_prove"] - rp["scalar_muls_executed_per_proof"] * j["value"]) / rp["scalar_muls_per_s_inside_prove"] < 1e-3
+    sv = j["sensitivities"]
+    assert sv["stated_d_reading"]["n"] == n_ // 2 and sv["stated_d_reading"]["d"] == 4 * n_ and sv["Q1"]["Q"] == 1 and sv["Q4"]["Q"] == 4
+    assert sv["seed1"]["seed"] == 1 and sv["seed2"]["seed"] == 2 and all(v["ms_per_proof"] > 0 for v in sv.values())
+    mp = j["msm_protocol_shaped"]
+    assert mp["W_t_quotient"]["N"] == 7 * mp["n"] + 8 and mp["s_of_X_y_coefficients"]["N"] == 3 * mp["n"] + 1
+    assert mp["s_of_X_y_coefficients"]["distinct_scalars"] <= mp["n"] + 3 and mp["W_t_quotient"]["distinct_scalars"] > 7 * mp["n"]
+    e = j["msm_strong"]["emulated_share"]
+    assert abs(e["ms_per_share"] - e["ms_per_share_kernels_only"] - e["exchange_model"]["ms"]) < 2e-3      # the modelled exchange is INSIDE the figure
+    assert e["speedup_vs_single"] <= e["speedup_without_the_exchange"]
+    assert ps["emulated_shares"]["allgather_model_ms"] > 0 and ps["emulated_shares"]["ranks_that_repeat_the_t_product"] >= 1
 
 
 _NTT_ALT = r"""

@@ -179,6 +179,33 @@ def test_bench_two_ranks_one_gpu():
     assert j["north_star"] is None
 
 
+def test_bench_starts_its_own_ranks_and_never_mislabels():
+    """`python bench.py --gpus N` WITHOUT a launcher: it starts the N ranks itself before touching the GPU and
+    relays rank 0's line (gloo here: two ranks on the one GPU); asked for more RCCL ranks than the node has GPUs it refuses with a
+    non-zero status instead of measuring one rank under the label N; the in-process form (one process, the C ABI, a device list)"""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    small = ["--steps", "2", "--warmup", "1", "--log2n", "10", "--msm-log2", "12", "--no-cpu", "--strong-log2n", "11", "--msm-strong-log2", "13", "--no-sensitivities"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + small, cwd=ROOT, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["process_group"].startswith("gloo, 2 rank") and j["status"] == "ok" and j["prove_strong"]["n_gpus"] == 2
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")] and "not measuring" in out.stderr
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--in-process", "--devices", "0,0,0"] + small, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    ip = j["in_process"]
+    assert j["n_gpus"] == 3 and j["value"] > 0 and j["status"] == "ok" and "ONE process" in j["config"]["process_group"]
+    assert ip["proofs"]["same_bytes_as_one_handle_alone"] is True and ip["prove_strong"]["same_bytes_as_one_gpu_alone"] is True
+    assert ip["msm_strong"]["bucket_ranges"]["same_result_as_one_gpu"] is True and ip["msm_strong"]["term_ranges"]["same_result_as_one_gpu"] is True
+
+
 @_reports
 def _worker_rccl(rank, world, port, q):
     """one rank per GPU over RCCL: the device-tensor collectives of ShardedMsm (all_gather_into_tensor, all_to_all_single ordered on

@@ -234,3 +234,45 @@ def test_ntt_full_size_closed_form(sonic, log2n):
         assert int.from_bytes(got[i].tobytes(), "little") == want, (log2n, i)
     _lib.check(_lib.lib().sonic_ntt_fr(got.ctypes.data, log2n, 1))
     assert np.array_equal(got, a)
+
+
+def test_product_at_the_transform_limit_2p28(sonic):
+    """the largest transform the butterfly routines address (2^28 points: the first stage's last twiddle sits at byte offset 2^32 - 32
+    of its table; ADVICE r04 -- round 4 stopped at 2^27): the product of two sparse polynomials of 2^27 coefficients each, operands
+    and result resident in HBM (sonic_poly_mul_fr_dev; 8 GB result, 16 GB of stage-major twiddles), has nine non-zero coefficients
+    at the sums of the operands' positions -- checked there and at sampled positions that must be zero (the `*` of
+    src/Sonic/Constraints.hs:61 at a size no CPU oracle reaches in a test)."""
+    import ctypes as C
+    from sonic_amd import _lib
+    L = _lib.lib()
+    na = nb = 1 << 27
+    pyr = random.Random(28)
+    ta = {0: pyr.randrange(1, R), pyr.randrange(1, na - 1): pyr.randrange(1, R), na - 1: R - 1}
+    tb = {0: R - 2, pyr.randrange(1, nb - 1): pyr.randrange(1, R), nb - 1: pyr.randrange(1, R)}
+    da, db, do = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for ptr, cnt in ((da, na), (db, nb), (do, na + nb - 1)):
+        _lib.check(L.sonic_dev_alloc(32 * cnt, C.byref(ptr)))
+    CH = 1 << 21                                         # 64-MB pieces of zeros; the few non-zero coefficients go on top
+    zeros = np.zeros((CH, 32), np.uint8)
+    for ptr, cnt, terms in ((da, na, ta), (db, nb, tb)):
+        for o in range(0, cnt, CH):
+            _lib.check(L.sonic_dev_upload(C.c_void_p(ptr.value + 32 * o), zeros.ctypes.data, 32 * min(CH, cnt - o)))
+        for k, c in terms.items():
+            _lib.check(L.sonic_dev_upload(C.c_void_p(ptr.value + 32 * k), c.to_bytes(32, "little"), 32))
+    _lib.check(L.sonic_poly_mul_fr_dev(da, na, db, nb, do))
+    want = {}
+    for i, ci in ta.items():
+        for j, cj in tb.items():
+            want[i + j] = (want.get(i + j, 0) + ci * cj) % R
+    one = C.create_string_buffer(32)
+
+    def at(k):
+        _lib.check(L.sonic_dev_download(one, C.c_void_p(do.value + 32 * k), 32))
+        return int.from_bytes(one.raw, "little")
+    for k, c in want.items():
+        assert at(k) == c, k
+    for k in [1, 2, 2047, 2048, na - 2, na, na + nb - 3] + [pyr.randrange(na + nb - 1) for _ in range(40)]:
+        if k not in want:
+            assert at(k) == 0, k
+    for ptr in (da, db, do):
+        L.sonic_dev_free(ptr)

@@ -400,11 +400,11 @@ def test_ntt_matches_oracle(sonic, orc, log2n):
 
 
 def test_ntt_size_limit(sonic):
-    """2^27 points is the largest transform (32-bit twiddle offsets inside the butterfly routines): beyond it the call is refused
-    before anything is read"""
+    """2^28 points is the largest transform (32-bit unsigned twiddle offsets inside the butterfly routines; tests/test_gpu_fullsize.py runs
+    one): beyond it the call is refused before anything is read"""
     from sonic_amd import _lib
     buf = np.zeros((4, 32), np.uint8)
-    for log2n in (28, 40, -1):
+    for log2n in (29, 40, -1):
         assert _lib.lib().sonic_ntt_fr(buf.ctypes.data, log2n, 0) == 7        # SONIC_ERR_INVALID_ARG
 
 
