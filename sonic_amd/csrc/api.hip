@@ -282,7 +282,6 @@ sonic_srs* srs_alloc(int64_t d) {
   // measured (prove at n = d/8): up to d = 2^20 the MSMs (0.4 d .. 0.9 d terms) run best with ~2^16 bucket walks
   // (c = 17: one to two waves per SIMD, short reduction); from d = 2^21 the two windows saved by c = 20 win.
   int c = lg >= 21 ? 20 : (lg > 17 ? 17 : lg);
-  if (const char* tc = getenv("SONIC_MSM_TABLE_C")) { int v = atoi(tc); if (v >= 9 && v <= 22) c = v; }   // tuning knob
   if (c < 9) c = 9;
   // W windows of even width (msm.hpp): the widest is ceil(255 / W) <= c
   int W = (255 + c - 1) / c;
@@ -616,10 +615,6 @@ struct sonic_msm_lane {
   MsmSlot* h_slot = nullptr;
   int* h_err = nullptr;
   int Wb = 0;
-  // buckets per running-sum segment (window-table plans): lanes exist to stream MSMs, where the reduction of one hides under
-  // the accumulation of another and the work-optimal end wins (measured at N = 2^20 over three lanes: K = 8 3.61, 16 3.31,
-  // 32 3.56, 64 4.03 ms per MSM); one MSM at a time wants the shortest chain (K = 8: 4.18, 16: 4.45, 32: 5.05 ms)
-  int segment = 16;
   bool in_flight = false;
   bool own_stream = true;        // false: the lane runs on a stream the caller owns (sonic_msm_lane_new_on_stream)
   // sonic_msm_g1_srs_multi keeps a pooled lane's exchange buffers across calls: this rank's scalar slice (host-scalar form), its full
@@ -660,7 +655,6 @@ int sonic_msm_lane_new_on_stream(void* hip_stream, sonic_msm_lane_t** out) {
   l->device = current_ctx().dev;
   l->st = static_cast<hipStream_t>(hip_stream);
   l->own_stream = false;
-  l->segment = 8;               // ordered on the caller's stream, such a lane runs one MSM at a time: shortest chain
   l->slot.alloc(sizeof(MsmSlot));
   l->err.alloc(4);
   HIP_OK(hipHostMalloc((void**)&l->h_slot, sizeof(MsmSlot), hipHostMallocDefault));
@@ -711,8 +705,6 @@ static int msm_submit_common(sonic_msm_lane_t* l, const sonic_srs_t* srs, int ba
   HIP_OK(hipMemsetAsync(l->err.p, 0, 4, st));
   fr_check_enqueue(st, dsc, n, l->err.as<int>());
   MsmPlan pl = srs_msm_plan(srs, n);
-    static const int seg_env = getenv("SONIC_MSM_SEGMENT") ? atoi(getenv("SONIC_MSM_SEGMENT")) : 0;      // tuning knob: buckets per running-sum segment
-  if (pl.Wb == 1 && pl.NB >= (1 << 16)) msm_plan_set_segment(pl, seg_env > 0 ? seg_env : l->segment);
   pl.accum_block = 64;           // a lane's MSM runs alone or beside other lanes' MSMs, not inside a proof (msm.hpp)
   msm_enqueue(st, l->ws, pl, srs->basis(basis) + (e0 + srs->d), dsc, n, false, l->slot.as<MsmSlot>());
   l->Wb = pl.Wb;
@@ -749,7 +741,6 @@ struct PooledLane {
     if (!lane) {
       int rc = sonic_msm_lane_new_on(ctx.dev, &lane);
       if (rc) throw HipFail{rc};
-      lane->segment = 8;          // one MSM at a time: shortest chain
     }
   }
   ~PooledLane() { if (lane) { std::lock_guard<std::mutex> g(ctx.pool_mu); ctx.lanes.push_back(lane); } }

@@ -854,16 +854,16 @@ __global__ __launch_bounds__(256, 2) void k_bucket_tree_levels(G1XYZZ* __restric
   }
 }
 
-static const bool g_use_tree = !(getenv("SONIC_MSM_TREE") && atoi(getenv("SONIC_MSM_TREE")) == 0);      // knob: 0 = the running-sum segments of rounds 1-3
-bool msm_tree_reduction() { return g_use_tree; }
 
 // reduces `sets` bucket sets of 2^L buckets each (consecutive in Z) into the jobs' slots
 static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint32_t tot_mul, const MsmBatchDev& batch) {
   const int LB = L < TREE_BLOCK_LOG ? L : TREE_BLOCK_LOG;
   // (a first launch with 8 buckets per thread -- 11 additions in registers, blocks of 2048, one wave per SIMD -- measured the same:
   // 0.51 + 2 x 0.09 ms against 0.52 + 2 x 0.10 ms at 2^19 buckets)
-  // knob: rounds of quads a level may take before whole additions per lane are preferred (0: never quads; >= 32: the leaf levels too)
-  static const int quads = getenv("SONIC_TREE_QUADS") ? atoi(getenv("SONIC_TREE_QUADS")) : 2;
+  // rounds of quads a level may take before whole additions per lane are preferred (measured in round 4, first launch at 2^19 buckets:
+  // 0 / 2 / 4 / 8 / 16 rounds 0.521 / 0.426 / 0.453 / 0.463 / 0.465 ms: the early levels are bound by issue, where a quad's 20 lane-products
+  // per addition lose to a lane's 14)
+  constexpr int quads = 2;
   LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB, quads);
   int done = LB;
   if (L > done) {
@@ -1040,8 +1040,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   }
   LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
          ws.order.as<uint32_t>());
-  static const int accum_env = [] { const char* e = getenv("SONIC_ACCUM_BLOCK"); const int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();   // tuning knob
-  const int accum_block = accum_env ? accum_env : ((pl.accum_block == 64 || pl.accum_block == 128) ? pl.accum_block : 256);
+  const int accum_block = (pl.accum_block == 64 || pl.accum_block == 128) ? pl.accum_block : 256;
   LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
          (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs,
          ws.heavy_items.as<HeavyItem>());
@@ -1051,7 +1050,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
   if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)
   const int sets = k * pl.Wb;
-  if ((g_use_tree && pl.tree && pl.Wb == 1 && pl.NB >= 4) || pl.endo) {
+  if ((pl.tree && pl.Wb == 1 && pl.NB >= 4) || pl.endo) {
     int L = 0;
     while ((1 << L) < pl.NB) L++;
     bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), sets, L, 1u, batch);
@@ -1084,56 +1083,26 @@ __global__ __launch_bounds__(256, 1) void k_sum_slices(const G1XYZZ* __restrict_
 }
 
 void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot) {
-  // buckets per running-sum segment of a slice: a rank's 1/world of the buckets leaves most of the chip idle, so the chain, not the
-  // work, is what counts -- shorter segments, more threads (tuning knob SONIC_SLICE_SEGMENT: 1, 2, 4 or 8)
-  static const int K_env = getenv("SONIC_SLICE_SEGMENT") ? atoi(getenv("SONIC_SLICE_SEGMENT")) : 0;
-  // default: 2 for the slices of 8 ranks (65536 buckets: the chip is nearly empty, the chain is what counts), growing with the slice so
-  // that there are never more than 65536 segments (one wave per SIMD), as for a whole bucket set
-  int K = MSM_SLICE_SEGMENT;
-  while (K < 8 && len / K > 65536) K *= 2;
-  if (K_env == 1 || K_env == 2 || K_env == 4 || K_env == 8) K = K_env;
-  if (k < 1 || len < K || len % MSM_SLICE_QUANTUM || base % MSM_SLICE_QUANTUM || base + len >= (1L << 31))
+  (void)c;
+  if (k < 1 || len < 4 || len % MSM_SLICE_QUANTUM || base % MSM_SLICE_QUANTUM || base + len >= (1L << 31))
     throw std::runtime_error("msm_reduce_slices_enqueue: slice length and base must be multiples of MSM_SLICE_QUANTUM");
-  const int nseg = (int)(len / K);
-  if (g_use_tree) {
-    // the butterfly wants a power of two: the sum of the slices goes into a zero-padded (= infinity) copy; bucket i weighs base + i + 1
-    int L = 2;
-    while (((long)1 << L) < len) L++;
-    const long P = (long)1 << L;
-    ws.buckets.ensure((size_t)P * sizeof(G1XYZZ));
-    if (P > len) HIP_OK(hipMemsetAsync(ws.buckets.as<G1XYZZ>() + len, 0, (size_t)(P - len) * sizeof(G1XYZZ), st));
-    // (a quad per bucket, and four lanes per bucket with an LDS tree, both measured slower at 65536 buckets x 8 slices -- 0.21 / 0.22 against
-    // 0.15 ms: the kernel reads 100 MB once and is bound by that, not by its chain of 7 additions)
-    LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
-    MsmBatchDev b1;
-    memset(&b1, 0, sizeof b1);
-    b1.k = 1;
-    b1.bits = 255;
-    b1.slot_form = 1;
-    b1.slot[0] = d_slot;
-    bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), 1, L, (uint32_t)(base + 1), b1);
-    return;
-  }
-  ws.buckets.ensure((size_t)len * sizeof(G1XYZZ));
-  ws.segres.ensure(((size_t)nseg + nseg / 256 + 2) * sizeof(G1XYZZ));
-  const G1XYZZ* B = d_slices;
-  if (k > 1) {
-    LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
-    B = ws.buckets.as<G1XYZZ>();
-  }
-  LAUNCH(k_bucket_segments, ceil_div((long)nseg, 256), 256, 0, st, B, 1, (int)len, K, nseg, (int)(base / K), ws.segres.as<G1XYZZ>());
-  MsmBatchDev batch;
-  memset(&batch, 0, sizeof batch);
-  batch.k = 1;
-  batch.slot[0] = d_slot;
-  if (nseg > 4096) {
-    const int group = 256, ngroups = nseg / group;
-    G1XYZZ* part = ws.segres.as<G1XYZZ>() + (size_t)nseg;
-    LAUNCH(k_group_sum, ngroups, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), (long)nseg, group, part);
-    LAUNCH(k_window_sum, 1, 256, 0, st, (const G1XYZZ*)part, 1, c, ngroups, batch);
-  } else {
-    LAUNCH(k_window_sum, 1, 256, 0, st, (const G1XYZZ*)ws.segres.as<G1XYZZ>(), 1, c, nseg, batch);
-  }
+  // the butterfly wants a power of two: the sum of the slices goes into a zero-padded (= infinity) copy; bucket i weighs base + i + 1
+  // (up to round 3 this was a running sum over 2-bucket segments: ~1.0 ms of dependent chain for a 1/8 slice, 0.29 ms as a tree)
+  int L = 2;
+  while (((long)1 << L) < len) L++;
+  const long P = (long)1 << L;
+  ws.buckets.ensure((size_t)P * sizeof(G1XYZZ));
+  if (P > len) HIP_OK(hipMemsetAsync(ws.buckets.as<G1XYZZ>() + len, 0, (size_t)(P - len) * sizeof(G1XYZZ), st));
+  // (a quad per bucket, and four lanes per bucket with an LDS tree, both measured slower at 65536 buckets x 8 slices -- 0.21 / 0.22 against
+  // 0.15 ms: the kernel reads 100 MB once and is bound by that, not by its chain of 7 additions)
+  LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+  MsmBatchDev b1;
+  memset(&b1, 0, sizeof b1);
+  b1.k = 1;
+  b1.bits = 255;
+  b1.slot_form = 1;
+  b1.slot[0] = d_slot;
+  bucket_tree_enqueue(st, ws.buckets.as<G1XYZZ>(), 1, L, (uint32_t)(base + 1), b1);
 }
 
 void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArray d_points, const Fr* d_scalars,

@@ -27,7 +27,7 @@ struct MsmPlan {
   // threads per workgroup of the bucket accumulation.  256 inside prove() (several chains run side by side; measured in round 3:
   // 34.7 ms per proof against 35.8-36.2 with 64 or 128); 64 for the stand-alone MSM lanes, where one-wave workgroups refill a freed
   // wave slot without waiting for three more (k_bucket_accum 2.31-2.40 against 2.42-2.45 ms, MSM 2^20 streamed 3.22-3.24 against
-  // 3.33-3.59 ms).  SONIC_ACCUM_BLOCK overrides both.
+  // 3.33-3.59 ms).
   int accum_block = 256;
   // reduce the shared bucket set by the bit-sum butterfly (log-depth, least work, ~4x the memory traffic) instead of running sums over
   // K-bucket segments (one pass over the buckets, a long dependent chain per segment).  The tree wins wherever the reduction is
@@ -66,7 +66,6 @@ struct MsmSlot {
   int W, c, pad0, pad1;
   G1XYZZ win[MSM_MAX_WINDOWS];
 };
-bool msm_tree_reduction();
 
 struct MsmWorkspace {
   DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, heavy_meta, heavy_items, heavy_partial, endo_scalars;
@@ -93,7 +92,6 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
                        G1XYZZ* ext_buckets = nullptr);
 // The second half on the rank that owns bucket range [base, base + len): adds the k slices it received element-wise and
 // reduces them with the range's weights into d_slot (one window sum).  len and base are multiples of MSM_SLICE_QUANTUM.
-constexpr int MSM_SLICE_SEGMENT = 2;          // buckets per running-sum segment of a slice: measured on one GPU doing 1/8 of an N = 2^22 MSM, K = 8 / 4 / 2 / 1: 2.62 / 2.54 / 2.46 / 2.47 ms per share
 constexpr long MSM_SLICE_QUANTUM = 16384;     // = 2048 segments: whole 256-segment groups and wave-uniform segment bits
 void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot);
 

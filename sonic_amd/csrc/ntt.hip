@@ -58,8 +58,8 @@ __device__ __forceinline__ long stage_off(int L, int s) { return (1L << L) - (1L
 static const int WIDE_GRID = getenv("SONIC_NTT_GRID") ? atoi(getenv("SONIC_NTT_GRID")) : 512;
 // workgroup caps of the two transform kernels (tools/ntt_time.py: one block or tile per workgroup up to these caps measures best alone
 // on the chip -- 0.444 against 0.465 ms for the LDS kernel at 1024 against 512 workgroups -- and the same inside prove)
-static const int WIDE_BLOCKS = getenv("SONIC_NTT_WIDE_BLOCKS") ? atoi(getenv("SONIC_NTT_WIDE_BLOCKS")) : 4 * WIDE_GRID;      // 2048-element blocks (twice as many of 1024)
-static const int LOCAL_BLOCKS = getenv("SONIC_NTT_LOCAL_BLOCKS") ? atoi(getenv("SONIC_NTT_LOCAL_BLOCKS")) : 2 * WIDE_GRID;    // 2048-element tiles
+static const int WIDE_BLOCKS = 4 * WIDE_GRID;      // 2048-element blocks (twice as many of 1024)
+static const int LOCAL_BLOCKS = 2 * WIDE_GRID;     // 2048-element tiles
 static inline int wide_grid(long items) { long g = (items + 255) / 256; return (int)(g < WIDE_GRID ? g : WIDE_GRID); }
 
 // Several consecutive WIDE stages in one pass through HBM (round 4; before: two per pass as radix-4 butterflies in registers, 6 passes

@@ -45,12 +45,9 @@ enum { PH_R = 1,      // R                                   (blinders)
 // window tables of the per-circuit commitments C_q (sonic_prover_prepare): 29 windows of 9 / 8 bits over 256 shared buckets
 constexpr int CQ_TAB_W = 29, CQ_TAB_C = 9;
 constexpr long CQ_TAB_MAX_Q = 1L << 16;
-static int PROVE_SEGMENT = getenv("SONIC_PROVE_SEGMENT") ? atoi(getenv("SONIC_PROVE_SEGMENT")) : 0;
-static int PROVE_SEGMENT_LAST = getenv("SONIC_PROVE_SEGMENT_LAST") ? atoi(getenv("SONIC_PROVE_SEGMENT_LAST")) : 0;
 static int prove_segment(const MsmPlan& pl, int k, bool last) {
   const bool big = pl.NB >= (1 << 18);
-  if (last) return PROVE_SEGMENT_LAST > 0 ? PROVE_SEGMENT_LAST : (big ? 16 : 4);
-  if (PROVE_SEGMENT > 0) return PROVE_SEGMENT;
+  if (last) return big ? 16 : 4;
   return k > 1 ? (big ? 64 : 16) : (big ? 8 : 4);
 }
 
@@ -84,10 +81,13 @@ static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, con
   long nmax = 0;
   for (int j = 0; j < k; j++) nmax = std::max(nmax, jobs[j].n);
   MsmPlan pl = srs_msm_plan(srs, nmax);
-  // SONIC_PROVE_TREE: which groups reduce their buckets by the bit-sum butterfly: 0 none, 1 the group that finishes last (default),
-  // 2 all.  `exposed`: the caller knows that little else runs beside this group (a rank's share of a proof split over many GPUs).
-  static const int tree_mode = getenv("SONIC_PROVE_TREE") ? atoi(getenv("SONIC_PROVE_TREE")) : 1;
-  const bool tree = tree_mode >= 2 || (tree_mode == 1 && (last || exposed));
+  // Which groups reduce their buckets by the bit-sum butterfly: the group that finishes last, and every group when the caller knows
+  // that little else runs beside it (`exposed`: a rank's share of a proof split over many GPUs); the others keep the running sums
+  // over K-bucket segments.  Both forms cost the same instructions per bucket set (1.8e8 wave-instructions at 2^19 buckets:
+  // profiles/r04_valu_budget.txt); the butterfly is one addition deep instead of ~2K + 30, the segments touch every bucket once.
+  // Butterfly in EVERY group, measured again in round 5 (same box, alternating, ms per proof): streamed 33.76 / 33.91 against
+  // 33.67 / 33.76, one at a time 34.75 / 34.98 against 34.21 / 34.50, n = 2^20 127.6 / 127.5 against 126.6 / 127.2 -- not adopted.
+  const bool tree = last || exposed;
   if (k > 1 && msm_can_batch(pl)) {
     // the group that finishes last reduces with nothing left to hide under: shortest chain instead of least work
     msm_plan_set_segment(pl, prove_segment(pl, k, last));
@@ -505,12 +505,8 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   for (long j = 0; j < Q; j++) if (need_j[(size_t)j]) last_j = j;
   const int last_group = need_T ? 3 : need_su ? 2 : need_j_any ? 1 : 0;
   Lane* cur = nullptr;
-  // SONIC_PROVE_PACK=1 packs consecutive groups into ONE batched chain as long as their MSMs fit MSM_MAX_JOBS (Q = 2: {R, W_a, W_b}
-  // with {S_1, W_1, W'_1}; {S_2, W_2, W'_2} with {C, Q_1, Q_2, Q_v}), the chain waiting for the later polynomial: fewer, wider
-  // chains.  Off by default -- measured in round 3 on one box, ms per proof streamed / one at a time, packed vs not:
-  // n = 2^14 5.59 / 6.40 vs 6.18 / 5.69, 2^16 12.19 / 13.08 vs 12.52 / 11.71, 2^18 35.9 / 38.9 vs 35.0 / 35.9, 2^20 127.5 / 129.5 vs
-  // 129.9 / 131.0: the chains of one proof overlap less, which costs the headline size more than the wider launches give.
-  static const bool pack = getenv("SONIC_PROVE_PACK") && atoi(getenv("SONIC_PROVE_PACK")) != 0;
+  // (packing consecutive groups into ONE batched chain -- fewer, wider chains -- was measured in round 3 and removed in round 5: n = 2^18
+  // 35.9 / 38.9 ms streamed / one at a time packed against 35.0 / 35.9: the chains of one proof overlap less)
   std::vector<std::function<void()>> after_flush;       // small MSMs that use the lane's workspace after the batch (stream order)
   auto flush_now = [&](bool last = false) {
     if (!cur) return;
@@ -519,12 +515,11 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     for (auto& f : after_flush) f();
     after_flush.clear();
   };
-  auto begin_group = [&](hipEvent_t e, int njobs_coming) {
-    if (pack && cur && cur->njobs > 0 && cur->njobs + njobs_coming <= MSM_MAX_JOBS) { HIP_OK(hipStreamWaitEvent(cur->st, e, 0)); return; }
+  auto begin_group = [&](hipEvent_t e) {
     flush_now();
     cur = &p->pick(e); cur->njobs = 0;
   };
-  auto flush_group = [&](bool last = false) { if (!pack || last) flush_now(last); };
+  auto flush_group = [&](bool last = false) { flush_now(last); };
   auto commit = [&](int ph, const Fr* poly, long lo, long len, long maxm, long slot) {
     if (!on(ph) || !own(slot)) return;
     if (cur->njobs == MSM_MAX_JOBS) flush_now();
@@ -596,7 +591,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     p->fr_valid[2] = 1;
   }
   if (need_g0) {
-    begin_group(p->ev_r1, 3);
+    begin_group(p->ev_r1);
     commit(PH_R, r1, r_lo, r_len, n, 0);                                               // R            :63
     open(PH_OPEN, r1, r_lo, r_len, pZ, 0, 2);                                          // (a, W_a)     :79
     open(PH_OPEN, r1, r_lo, r_len, pYZ, 1, 3);                                         // (b, W_b)     :80
@@ -605,7 +600,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   for (long j = 0; j < Q; j++) {
     if (!need_j[(size_t)j]) continue;
     Fr* syj = p->syj[j].as<Fr>();
-    begin_group(p->ev_syj[j], 3);
+    begin_group(p->ev_syj[j]);
     if (p->prepared) commit(PH_HSCS, p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);   // S_j (diagonal part)   Signature.hs:42
     else commit(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j                   :42
     open(PH_HSCS, syj, s_lo, s_len, pZj(j), 3 + j, 6 + 2 * j);                       // (s_j, W_j)    :43
@@ -622,7 +617,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     }
   }
   if (need_su) {
-    begin_group(p->ev_su, (int)std::min<long>(Q + 2, MSM_MAX_JOBS));
+    begin_group(p->ev_su);
     commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                  // C             :52
     for (long j = 0; j < Q; j++) open(PH_HSCW, su, u_lo, u_len, pYj(j), 3 + Q + j, 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
     open(PH_QV, su, u_lo, u_len, pV, -1, 5 + 4 * Q);                                 // Q_v           :63

@@ -276,3 +276,87 @@ def test_product_at_the_transform_limit_2p28(sonic):
             assert at(k) == 0, k
     for ptr in (da, db, do):
         L.sonic_dev_free(ptr)
+
+
+def _dense_circuit(seed, n, Q):
+    """dense random weights: every w_L/R/O[q][i] uniform in Fr (the reference's rndCircuit only ever has one all-ones row per matrix,
+    test/Test/Reference.hs:141-155), c_q = w_L a_L + w_R a_R + w_O a_O (:138), a_O = a_L * a_R"""
+    rng = np.random.default_rng(seed)
+    c = big_circuit(seed, n, Q)
+    la, lb, lo = c["ints"]
+    W = [rand_fr_array(rng, Q * n) for _ in range(3)]
+    cs = []
+    for q in range(Q):
+        acc = 0
+        for w, a in zip(W, (la, lb, lo)):
+            row = w[q * n:(q + 1) * n]
+            acc += sum(int.from_bytes(row[i].tobytes(), "little") * a[i] for i in range(n))
+        cs.append(acc % R)
+    return dict(c, wL=W[0], wR=W[1], wO=W[2], cs=fr_bytes(cs))
+
+
+@pytest.mark.parametrize("n", [3 * (1 << 13) + 5, (1 << 15) - 1])
+def test_prove_bytes_off_the_power_of_two_grid(sonic, orc, n):
+    """byte parity against the C oracle at sizes where the boundaries are crossed TOGETHER -- n = 3 * 2^13 + 5
+    (7n + 9 = 172 108: a product of 2^18 points for 66 % padding; MSM sizes that are no multiple of any tile) and n = 2^15 - 1
+    (7n + 9 = 229 378 just under 2^18) -- with Q = 4 DENSE random weights (every S_j MSM then has 3n distinct scalars, the prepared row
+    tables C_q are real 29-window tables over 4 committed rows) prepared and not, and once with the rndCircuit rows (n equal
+    coefficients in s(X,y): the heavy-bucket path) (src/Sonic/Protocol.hs:47-109, Signature.hs:38-72, Constraints.hs:34-68)."""
+    pyr = random.Random(n)
+    d = 7 * n + 3                                              # the smallest legal d is 7n (Protocol.hs:54); not a power of two either
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    srs = sonic.SRS.new(d, x, alpha)
+    osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1))
+    orc.set_mode(1, NCPU)
+    for kind, Q in (("dense", 4), ("rnd", 2)):
+        c = _dense_circuit(n, n, Q) if kind == "dense" else big_circuit(n + 1, n, Q)
+        circuit = sonic.ArithCircuit(sonic.GateWeights(c["wL"], c["wR"], c["wO"]), c["cs"])
+        asg = sonic.Assignment(c["aL"], c["aR"], c["aO"])
+        tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+        want = orc.prove(osrs, n, Q, c["wL"], c["wR"], c["wO"], c["cs"], c["aL"], c["aR"], c["aO"], tr, True)
+        for prepare in (False, True):
+            p = sonic.Prover(srs, circuit, prepare=prepare)
+            p.set_assignment(asg)
+            assert p.prove_bytes(tr) == want, (n, kind, prepare)
+            shares = []
+            for r in range(3):                                 # and as three ranks' shares (cuts fall inside MSMs of odd lengths)
+                p.set_share(r, 3)
+                shares.append(p.prove_share(tr))
+            assert sonic.proof_from_shares(Q, shares, tr) == want, (n, kind, prepare, "shares")
+            p.close()
+        proof, oracle_ = sonic.prove(srs, asg, circuit, transcript=[int.from_bytes(tr[i].tobytes(), "little") for i in range(8 + 2 * Q)])
+        assert proof.to_bytes() == want, (n, kind, "one-shot")
+    srs.close()
+
+
+def test_msm_protocol_shaped_scalars_2p20(sonic, orc):
+    """a stand-alone N = 2^20 MSM whose scalars look like the protocol's (src/Sonic/Constraints.hs:34-53 through
+    commitPoly, CommitmentScheme.hs:25-29): long runs of 0, of 1, of r - 1 (= -1: folded onto the negated point), of ONE repeated random
+    value (n equal coefficients: a heavy bucket in every window), small values, and uniform ones -- against the oracle's Pippenger."""
+    from sonic_amd.commitment import msm_g1_srs
+    N = 1 << 20
+    d = 1 << 20
+    pyr = random.Random(20)
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    srs = sonic.SRS.new(d, x, alpha)
+    osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1))
+    rng = np.random.default_rng(20)
+    sc = rand_fr_array(rng, N)
+    one = np.frombuffer((1).to_bytes(32, "little"), np.uint8)
+    minus1 = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
+    rep = np.frombuffer(pyr.randrange(1, R).to_bytes(32, "little"), np.uint8)
+    half = np.frombuffer(((R - 1) // 2).to_bytes(32, "little"), np.uint8)
+    sc[0:150000] = 0
+    sc[150000:300000] = one
+    sc[300000:450000] = minus1
+    sc[450000:700000] = rep                                     # 250 000 copies of one value: 13 heavy buckets
+    sc[700000:700100] = half                                    # the fold's boundary (r - 1)/2 and its neighbour
+    sc[700100:700200] = np.frombuffer(((R + 1) // 2).to_bytes(32, "little"), np.uint8)
+    small = rng.integers(0, 1 << 16, size=100000)
+    sc[700200:800200] = 0
+    sc[700200:800200, 0] = (small & 0xff).astype(np.uint8)
+    sc[700200:800200, 1] = (small >> 8).astype(np.uint8)
+    for basis, e0 in ((0, -d), (1, 1)):
+        got = msm_g1_srs(srs, basis, e0, sc)
+        assert got == orc.msm_srs(osrs, basis, e0, sc, 1, NCPU), (basis, e0)
+    srs.close()
