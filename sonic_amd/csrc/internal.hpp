@@ -27,6 +27,7 @@ struct DeviceCtx {
   NttTables* ntt = nullptr;              // sonic_ntt_fr / sonic_poly_mul_fr[_dev] (under call_mu)
   DevBuf mul_a, mul_b, mul_flags;        // scratch of sonic_poly_mul_fr_dev (under call_mu)
   int sort_staged = -1;                  // msm.hip: the LDS-staged sort passes got their dynamic-LDS attribute on this device (-1: not asked yet)
+  int ntt_big = -1;                      // ntt.hip: the same for the 128-KB block of k_ntt_wide_big
   // twiddle tables of the prover handles, one set per transform size, shared by every handle on the device and never freed (64 + 64 MB
   // at 2^21 points: two streaming handles used to hold one copy each) (under pool_mu)
   std::map<int, NttTables*> prover_ntt;

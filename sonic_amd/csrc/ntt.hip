@@ -102,7 +102,8 @@ __device__ __forceinline__ void ntt_bfly(int inverse, const uint32_t (&e0)[U], c
 template <int U, int ELOG>
 __device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
                                               const Fr* __restrict__ scale) {
-  static_assert((1 << ELOG) == 2 * U * 256, "U butterflies per thread of a 256-thread workgroup");
+  constexpr int THREADS = (1 << ELOG) / (2 * U);            // U butterflies per thread and stage
+  static_assert(THREADS == 256 || THREADS == 1024, "256 threads per block of 1024 / 2048 elements, 1024 for the 4096-element block");
   const uint32_t lds0 = lds_address(sh);
   const int lc = ELOG - ns;                                 // log2 C
   const int lstride = log2n - s0 - ns;                      // log2 of the row stride
@@ -111,7 +112,7 @@ __device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const 
   for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
     const long u = item >> (lstride - lc), cb = item & (col_blocks - 1);
     const long base = (u << (log2n - s0)) + (cb << lc);
-    for (int e = threadIdx.x; e < (1 << ELOG); e += 256) sh[e] = d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))];
+    for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) sh[e] = d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))];
     __syncthreads();
     for (int t = 0; t < ns; t++) {
       const int tt = inverse ? ns - 1 - t : t;               // forward (DIF): widest span first; inverse (DIT): the reverse
@@ -122,7 +123,7 @@ __device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const 
       uint32_t e0[U], tj[U];
 #pragma unroll
       for (int q = 0; q < U; q++) {
-        const int bt = threadIdx.x + q * 256;
+        const int bt = threadIdx.x + q * THREADS;
         const int c = bt & ((1 << lc) - 1), kp = bt >> lc;
         const int k = ((kp >> hb) << (hb + 1)) | (kp & ((1 << hb) - 1));         // row with bit hb clear
         const long j = (((long)(k & ((1 << hb) - 1)) << lstride) + (cb << lc) + c) & ((1L << lhalf) - 1);
@@ -135,9 +136,9 @@ __device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const 
     }
     if (scale) {
       const Fr sc = *scale;
-      for (int e = threadIdx.x; e < (1 << ELOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = fp_mul(sh[e], sc);
+      for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = fp_mul(sh[e], sc);
     } else {
-      for (int e = threadIdx.x; e < (1 << ELOG); e += 256) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = sh[e];
+      for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = sh[e];
     }
     __syncthreads();
   }
@@ -152,6 +153,19 @@ __global__ __launch_bounds__(256, 4) void k_ntt_wide(Fr* __restrict__ d, const F
                                                       const Fr* __restrict__ scale) {
   __shared__ __attribute__((aligned(16))) Fr sh[1 << (WIDE_ELEMS_LOG - 1)];
   ntt_wide_body<2, WIDE_ELEMS_LOG - 1>(sh, d, tw, log2n, s0, ns, tw_shift, inverse, scale);
+}
+
+// Nine or ten wide stages in ONE pass (round 5): 4096-element blocks -- 1024 rows x 4 columns at ten stages (128-B runs), 512 x 8 at nine --
+// in 128 KB of LDS, one 1024-thread workgroup per CU (16 waves: the same four per SIMD as k_ntt_wide), two butterflies per thread.  A
+// transform of 2^20 or 2^21 points then makes TWO passes over HBM instead of three.  Measured (tools/ntt_time.py, product alone on the
+// chip, same box, alternating): M = 2^21 0.891 / 0.895 -> 0.870 / 0.867 ms (wide part 0.466 -> 0.450), M = 2^20 0.474 -> 0.445 ms (wide
+// part 0.244 -> 0.212); at M = 2^19 the 128 blocks leave half of the CUs idle (0.277 -> 0.313 ms) and eleven stages would mean 64-B
+// runs, so the pass is used for nine and ten wide stages only.  The transforms stay bound by VALU issue (21 stages x 2^20 butterflies x
+// ~356 instructions: 0.66 ms of pure issue per product at M = 2^21); what the fused pass saves is one exposed load / store phase.
+__global__ __launch_bounds__(1024, 1) void k_ntt_wide_big(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
+                                                          const Fr* __restrict__ scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
+  ntt_wide_body<2, 12>(reinterpret_cast<Fr*>(smem_big), d, tw, log2n, s0, ns, tw_shift, inverse, scale);
 }
 
 // all stages with span <= tile, fused in LDS.  tile_log = min(log2n, TILE_LOG).  Full tiles (2048 elements: every transform the prover
@@ -274,11 +288,26 @@ static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool 
   const int nglobal = log2n - tile_log;
   const size_t lds = sizeof(Fr) << tile_log;
   // the wide stages in passes of at most WIDE_MAX_STAGES, as even as possible (10 -> 5 + 5, 12 -> 6 + 6, 13 -> 5 + 4 + 4)
-  constexpr int WIDE_MAX_STAGES = 6;
+  // nine or ten wide stages go in one pass through a 128-KB block (k_ntt_wide_big) where the device grants that much dynamic LDS
+  bool big = (nglobal == 9 || nglobal == 10) && NTT_WAVES == 4;
+  if (big) {
+    DeviceCtx& dctx = current_ctx();
+    if (dctx.ntt_big < 0) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_wide_big), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) (void)hipGetLastError();
+      dctx.ntt_big = e == hipSuccess ? 1 : 0;
+    }
+    big = dctx.ntt_big == 1;
+  }
+  const int WIDE_MAX_STAGES = big ? nglobal : 6;
   const int passes = (nglobal + WIDE_MAX_STAGES - 1) / WIDE_MAX_STAGES;
   int first[8], count[8];
   for (int p = 0, s = 0; p < passes; p++) { count[p] = nglobal / passes + (p < nglobal % passes ? 1 : 0); first[p] = s; s += count[p]; }
   auto wide = [&](int p, const Fr* scale) {
+    if (big) {
+      LAUNCH(k_ntt_wide_big, (int)std::min<long>(1L << (log2n - 12), 512), 1024, 128 * 1024, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);
+      return;
+    }
     const int elog = NTT_WAVES == 4 ? WIDE_ELEMS_LOG - 1 : WIDE_ELEMS_LOG;
     const long items = 1L << (log2n - elog);
     if (NTT_WAVES == 4) LAUNCH(k_ntt_wide, (int)std::min<long>(items, 2L * WIDE_BLOCKS), 256, 0, st, d, table, log2n, first[p], count[p], tw_shift, inverse ? 1 : 0, scale);

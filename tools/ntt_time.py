@@ -32,7 +32,7 @@ def main():
         _lib.check(L.sonic_poly_mul_fr_dev(da, na, db, nb, do))
     L.sonic_profile_enable(0)
     per = {}
-    for nm in ("k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4"):
+    for nm in ("k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4", "k_ntt_wide_big"):
         ms, cnt = C.c_double(), C.c_int64()
         L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
         per[nm] = round(ms.value / reps, 4)
