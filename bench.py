@@ -464,16 +464,16 @@ def main(argv=None):
             _lib.check(L.sonic_poly_mul_fr_dev(da, na, db, nb, do))
         L.sonic_profile_enable(0)
         per = {}
-        for nm in ("k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4", "k_fr_pointwise_mul"):       # (…4: the SONIC_NTT_WAVES=2 variants)
+        for nm in ("k_ntt_wide_big", "k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4", "k_fr_pointwise_mul"):       # (…4: the SONIC_NTT_WAVES=2 variants)
             ms, cnt = C.c_double(), C.c_int64()
             L.sonic_profile_get(nm.encode(), C.byref(ms), C.byref(cnt))
             per[nm] = {"ms_per_product": round(ms.value / reps, 4), "launches_per_product": cnt.value // reps}
         t_ms = sum(v["ms_per_product"] for v in per.values())
         pmc_ntt, pmc_ntt_src = load_profile_json("pmc_ntt.json")        # committed rocprofv3 --pmc passes of tools/ntt_time.py (per product, M = 2^21)
-        passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4")) // 3
-        per = {k: v for k, v in per.items() if v["launches_per_product"] or k in ("k_ntt_wide", "k_ntt_local")}
+        passes = sum(per[k]["launches_per_product"] for k in ("k_ntt_wide_big", "k_ntt_wide", "k_ntt_local", "k_ntt_wide4", "k_ntt_local4")) // 3
+        per = {k: v for k, v in per.items() if v["launches_per_product"] or k in ("k_ntt_wide_big", "k_ntt_local")}
         alg = 288.0 * M
-        ntt = {"bound": "hbm", "kernel": "three radix-2 transforms of size M, the pointwise product folded into the inverse transform's first load (k_ntt_wide / k_ntt_local)",
+        ntt = {"bound": "hbm", "kernel": "three radix-2 transforms of size M, the pointwise product folded into the inverse transform's first load (k_ntt_wide_big / k_ntt_wide / k_ntt_local)",
                "M": M, "achieved": round(alg / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_product": round(t_ms, 4),
                "algorithmic_bytes": alg, "algorithmic_bytes_rule": "288 M: each transform reads and writes M x 32 B once (3 x 64 M) + 96 M for the pointwise product (SURVEY 8d lower bound)",
@@ -481,8 +481,9 @@ def main(argv=None):
                "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
                "traffic": (pmc_ntt or {}).get("hbm_bytes_per_product") if M == (pmc_ntt or {}).get("M") else None, "traffic_source": pmc_ntt_src,
                "rocprof_ms_per_product": (pmc_ntt or {}).get("rocprof_ms_per_product"),
-               "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS the transforms "
-                       "are bound by VALU issue: ~356 instructions per butterfly in the generated assembly routines sonic_ntt_bfly2_fwd / _inv (DESIGN.md section 5)"}
+               "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused through LDS (nine or ten in ONE pass at M = 2^20 / 2^21: two HBM passes per "
+                       "transform; five or six per pass otherwise) the transforms are bound by VALU issue: ~356 instructions per butterfly in the generated assembly "
+                       "routines sonic_ntt_bfly2_fwd / _inv (DESIGN.md section 5)"}
         for ptr in (da, db, do):
             L.sonic_dev_free(ptr)
 

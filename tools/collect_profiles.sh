@@ -2,7 +2,7 @@
 # Collects the measurements DESIGN.md section 5 quotes, on one MI355X box:  bash tools/collect_profiles.sh r03
 # Writes gpurun_out/<tag>/...; tools/publish_profiles.sh <tag> copies the summaries into profiles/ afterwards.
 # PMC passes are separate runs with one counter group each and no tracing, as MI355X_MICROARCH.md's HBM section prescribes.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -43,25 +43,15 @@ python3 tools/valu_budget.py $(find $OUT/pmc_valu -name "*counter_collection.csv
 {
   echo "# python bench.py --msm-strong --emulate-world E --no-cpu --steps 10: one GPU doing ONE rank's share of an N = 2^22 MSM split over E ranks (UNMEASURED ON MULTI-GPU HARDWARE: device copy instead of the xGMI all-to-all)"
   for E in 2 4 8; do
-    python3 bench.py --msm-strong --emulate-world $E --no-cpu --steps 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['msm_strong']; e=d['emulated_share']; print('E=$E  whole MSM on one GPU %.3f ms   one share %.3f ms   ratio %.2f   + modelled xGMI exchange %.3f ms -> %.3f ms, ratio %.2f   kernels %s' % (d['ms_per_msm'], e['ms_per_share'], e['speedup_vs_single'], e['exchange_model']['ms'], e['ms_per_share_with_modelled_exchange'], e['speedup_with_modelled_exchange'], {k: v for k, v in e['kernel_ms'].items() if v >= 0.02}))"
+    python3 bench.py --msm-strong --emulate-world $E --no-cpu --steps 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['msm_strong']; e=d['emulated_share']; print('E=$E  whole MSM on one GPU %.3f ms   one share: kernels %.3f ms + MODELLED xGMI exchange %.3f ms = %.3f ms   speed-up %.2f (%.2f before the exchange is counted)   kernels %s' % (d['ms_per_msm'], e['ms_per_share_kernels_only'], e['exchange_model']['ms'], e['ms_per_share'], e['speedup_vs_single'], e['speedup_without_the_exchange'], {k: v for k, v in e['kernel_ms'].items() if v >= 0.02}))"
   done
 } > $OUT/msm_strong_emulated.txt
-# round 4: the bucket reduction (bit-sum butterfly vs running-sum segments; quads on / off), ONE proof over E emulated ranks, the north_star
-# size with the CPU port on the same proof, the MFMA-assisted product bound, the reference's criterion shape
-{
-  echo "# python bench.py --msm-only --no-cpu --steps 10 --warmup 2 --kernel-table: N = 2^20 MSM, ms streamed / one at a time and the reduction kernels"
-  for v in "SONIC_MSM_TREE=1 SONIC_TREE_QUADS=1" "SONIC_MSM_TREE=1 SONIC_TREE_QUADS=0" "SONIC_MSM_TREE=0"; do
-    env $v python3 bench.py --msm-only --no-cpu --steps 10 --warmup 2 --kernel-table 2> $OUT/tree.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['msm']; print('$v  streamed %.3f ms  one at a time %.3f ms' % (d['ms_per_msm'], d['sequential']['ms_per_msm']))"
-    grep -E "k_bucket_tree|k_bucket_segments|k_group_sum|k_window_sum" $OUT/tree.err
-  done
-  echo "# python bench.py --no-cpu --steps 20 --msm-lanes 0: prove() n = 2^18, which groups use the tree (SONIC_PROVE_TREE: 0 none, 1 the last group [default], 2 all): ms streamed / sequential; n = 2^20 sequential; slowest of 8 emulated shares"
-  for t in 0 1 2; do
-    SONIC_PROVE_TREE=$t python3 bench.py --no-cpu --steps 20 --warmup 2 --msm-lanes 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('SONIC_PROVE_TREE=$t  streamed %.2f  sequential %.2f  n=2^20 %.2f  slowest share %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof'], d['prove_strong']['ms_per_proof'], d['prove_strong']['emulated_shares']['slowest_ms']))"
-  done
-} > $OUT/bucket_tree.txt
+# (round 5: the knobs behind round 4's bucket_tree.txt are gone; the one A/B that was repeated -- the butterfly in every group of a proof --
+# is profiles/r05_prove_tree_ab.txt, measured at commit 6662339 where SONIC_PROVE_TREE still existed)
 python3 tools/prove_strong.py --log2n 20 --worlds 2,3,4,6,8 --steps 3 --fit > $OUT/prove_strong_emulated.txt 2>&1
 python3 tools/prove_strong.py --log2n 18 --worlds 2,4,8 --steps 3 >> $OUT/prove_strong_emulated.txt 2>&1
-python3 bench.py --north-star-cpu --steps 5 --warmup 1 --msm-lanes 0 > $OUT/north_star.json 2> $OUT/north_star.err
+# one process, the C ABI, a device list: two handles standing in for two GPUs on this one (overheads of the in-process form, not scaling)
+python3 bench.py --gpus 2 --in-process --devices 0,0 --no-cpu > $OUT/in_process_one_gpu.json 2> $OUT/in_process_one_gpu.err
 ./tools/mfma_bound > $OUT/mfma_bound.txt 2>&1
 python3 tools/criterion_shape.py > $OUT/criterion_shape.txt 2>&1
 python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1
