@@ -921,6 +921,10 @@ static int msm_multi(const sonic_srs_t* const* srs, int world, int basis, const 
         for (int q = 0; q < world; q++) all = all && bucket_ptr[(size_t)q] != nullptr;
         if (all) {
           try {
+            // direct reads over xGMI where the GPUs are linked: ask once per pair (a runtime that refuses, or has it on already, still
+            // copies -- staged -- so the answer is not an error here)
+            for (int q = 0; q < world; q++)
+              if (srs[q]->device != dev) { if (hipDeviceEnablePeerAccess(srs[q]->device, 0) != hipSuccess) (void)hipGetLastError(); }
             for (int q = 0; q < world; q++)                        // slice r of rank q -> slot q of my [world][S] buffer
               HIP_OK(hipMemcpyPeerAsync(lane->x_slices.as<G1XYZZ>() + (size_t)q * S, dev, static_cast<const G1XYZZ*>(bucket_ptr[(size_t)q]) + (size_t)r * S,
                                         srs[q]->device, (size_t)S * sizeof(G1XYZZ), lane->st));
