@@ -11,7 +11,7 @@ python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/microbench > $OUT/microbench.txt 2>&1
 ./tools/ba_bench > $OUT/ba_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm_only -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 5 --warmup 1 > $OUT/msm_only.json 2> $OUT/msm_only.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python3 bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python3 bench.py --no-cpu --no-sensitivities > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
 # the NTT product alone (roofline_ntt's kernels): per-kernel durations as the profiler sees them, and their HBM traffic
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt_only -o t -- python3 tools/ntt_time.py > $OUT/ntt_only.txt 2> $OUT/ntt_only.err
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -27,17 +27,17 @@ python3 tools/valu_budget.py $(find $OUT/pmc_valu -name "*counter_collection.csv
 {
   echo "# python bench.py --no-cpu --log2n <k> (10 streamed proofs after 2 warm-up, Q = 2, d = 8n): ms per proof streamed / strictly sequential"
   for lg in 10 13 14 16 17 18 19 20; do
-    python3 bench.py --no-cpu --log2n $lg --msm-log2 12 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=2^$lg  d=2^$((lg+3))  streamed %.2f  sequential %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof']))"
+    python3 bench.py --no-cpu --no-sensitivities --strong-log2n 0 --log2n $lg --msm-log2 12 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=2^$lg  d=2^$((lg+3))  streamed %.2f  sequential %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof']))"
   done
   echo "# sensitivity to Q at n = 2^18 (7 + 4Q MSMs per proof)"
   for q in 1 2 4 8; do
-    python3 bench.py --no-cpu --Q $q --msm-log2 12 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('Q=$q  streamed %.2f  sequential %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof']))"
+    python3 bench.py --no-cpu --no-sensitivities --strong-log2n 0 --Q $q --msm-log2 12 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('Q=$q  streamed %.2f  sequential %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof']))"
   done
 } > $OUT/prove_sizes.txt
 {
   echo "# python bench.py --no-cpu --msm-only --msm-log2 <k> (SRS d = 2^21: window tables c = 20, 13 windows, 2^19 shared buckets): ms per MSM and scalar-muls/s, streamed over three lanes / one at a time"
   for lg in 16 18 20 22; do
-    python3 bench.py --no-cpu --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  streamed %.2f ms  %.3g /s   one at a time %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value'], d['msm']['sequential']['ms_per_msm'], d['msm']['sequential']['scalar_muls_per_s']))"
+    python3 bench.py --no-cpu --no-sensitivities --msm-only --msm-log2 $lg 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2^$lg  streamed %.2f ms  %.3g /s   one at a time %.2f ms  %.3g /s' % (d['msm']['ms_per_msm'], d['msm']['value'], d['msm']['sequential']['ms_per_msm'], d['msm']['sequential']['scalar_muls_per_s']))"
   done
 } > $OUT/msm_sizes.txt
 {
