@@ -481,9 +481,10 @@ def main(argv=None):
                "kernels": per, "measured": "HIP events around every launch of sonic_poly_mul_fr_dev, alone on the chip, 5 products",
                "traffic": (pmc_ntt or {}).get("hbm_bytes_per_product") if M == (pmc_ntt or {}).get("M") else None, "traffic_source": pmc_ntt_src,
                "rocprof_ms_per_product": (pmc_ntt or {}).get("rocprof_ms_per_product"),
-               "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused through LDS (nine or ten in ONE pass at M = 2^20 / 2^21: two HBM passes per "
-                       "transform; five or six per pass otherwise) the transforms are bound by VALU issue: ~356 instructions per butterfly in the generated assembly "
-                       "routines sonic_ntt_bfly2_fwd / _inv (DESIGN.md section 5)"}
+               "note": "the HBM roof is SURVEY 8d's framing; with the wide stages fused five or six per pass through LDS the transforms are bound by VALU issue: "
+                       "~356 instructions per butterfly in the generated assembly routines sonic_ntt_bfly2_fwd / _inv (DESIGN.md section 5).  These are the kernels "
+                       "prove() runs; the single-pass form of the wide stages (SONIC_NTT_BIG=1: two HBM passes per transform, 0.87 ms alone on the chip) makes "
+                       "streamed proofs slower and is not the default (profiles/r05_ntt_wide_big.txt)"}
         for ptr in (da, db, do):
             L.sonic_dev_free(ptr)
 
@@ -782,7 +783,8 @@ def main(argv=None):
                 in_process = {"error": repr(e)}
             store.set("sonic_in_process_done", "1")
         else:
-            store.wait(["sonic_in_process_done"])         # a host-side wait: no collective kernel spins on this rank's GPU meanwhile
+            import datetime
+            store.wait(["sonic_in_process_done"], datetime.timedelta(seconds=1800))      # a host-side wait: no collective kernel spins on this rank's GPU meanwhile
         barrier()
 
     if rank != 0:

@@ -155,13 +155,14 @@ __global__ __launch_bounds__(256, 4) void k_ntt_wide(Fr* __restrict__ d, const F
   ntt_wide_body<2, WIDE_ELEMS_LOG - 1>(sh, d, tw, log2n, s0, ns, tw_shift, inverse, scale);
 }
 
-// Nine or ten wide stages in ONE pass (round 5): 4096-element blocks -- 1024 rows x 4 columns at ten stages (128-B runs), 512 x 8 at nine --
+// Nine or ten wide stages in ONE pass (round 5; behind SONIC_NTT_BIG=1, see ntt_run): 4096-element blocks -- 1024 rows x 4 columns at ten stages (128-B runs), 512 x 8 at nine --
 // in 128 KB of LDS, one 1024-thread workgroup per CU (16 waves: the same four per SIMD as k_ntt_wide), two butterflies per thread.  A
 // transform of 2^20 or 2^21 points then makes TWO passes over HBM instead of three.  Measured (tools/ntt_time.py, product alone on the
 // chip, same box, alternating): M = 2^21 0.891 / 0.895 -> 0.870 / 0.867 ms (wide part 0.466 -> 0.450), M = 2^20 0.474 -> 0.445 ms (wide
 // part 0.244 -> 0.212); at M = 2^19 the 128 blocks leave half of the CUs idle (0.277 -> 0.313 ms) and eleven stages would mean 64-B
 // runs, so the pass is used for nine and ten wide stages only.  The transforms stay bound by VALU issue (21 stages x 2^20 butterflies x
 // ~356 instructions: 0.66 ms of pure issue per product at M = 2^21); what the fused pass saves is one exposed load / store phase.
+// NOT the default: a workgroup that needs a whole CU (16 waves, 128 KB) starts late beside the bucket accumulation of another proof.
 __global__ __launch_bounds__(1024, 1) void k_ntt_wide_big(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
                                                           const Fr* __restrict__ scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
@@ -289,7 +290,12 @@ static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool 
   const size_t lds = sizeof(Fr) << tile_log;
   // the wide stages in passes of at most WIDE_MAX_STAGES, as even as possible (10 -> 5 + 5, 12 -> 6 + 6, 13 -> 5 + 4 + 4)
   // nine or ten wide stages go in one pass through a 128-KB block (k_ntt_wide_big) where the device grants that much dynamic LDS
-  bool big = (nglobal == 9 || nglobal == 10) && NTT_WAVES == 4;
+  // OFF by default: alone on the chip it is the faster kernel, inside streamed proofs its 1024-thread workgroup has to wait for a CU with no
+  // accumulation wave left on it and the proofs get slower (same box, alternating, 20 streamed proofs at n = 2^18: 32.21 / 32.34 / 31.51 ms
+  // per proof with it against 31.44 / 31.35 / 31.47 without; sonic_prove_batch over two handles 34.1-34.6 against 32.3-33.4).
+  // SONIC_NTT_BIG=1 selects it (tests/test_gpu_configs.py holds it against the default kernels).
+  static const bool big_on = getenv("SONIC_NTT_BIG") && atoi(getenv("SONIC_NTT_BIG")) == 1;
+  bool big = big_on && (nglobal == 9 || nglobal == 10) && NTT_WAVES == 4;
   if (big) {
     DeviceCtx& dctx = current_ctx();
     if (dctx.ntt_big < 0) {

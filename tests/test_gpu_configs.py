@@ -407,16 +407,25 @@ g = np.random.default_rng(9)
 pa, pb = rand_fr_array(g, 5000), rand_fr_array(g, 7000)
 out = np.zeros((11999, 32), np.uint8)
 _lib.check(L.sonic_poly_mul_fr(pa.ctypes.data, 5000, pb.ctypes.data, 7000, out.ctypes.data)); h.update(out.tobytes())
+for na, nb in ((400000, 600000), (900000, 1100000)):       # products of 2^20 and 2^21 points: nine and ten wide stages
+    pa, pb = rand_fr_array(g, na), rand_fr_array(g, nb)
+    out = np.zeros((na + nb - 1, 32), np.uint8)
+    _lib.check(L.sonic_poly_mul_fr(pa.ctypes.data, na, pb.ctypes.data, nb, out.ctypes.data)); h.update(out.tobytes())
+a = rand_fr_array(np.random.default_rng(20), 1 << 20)
+for inverse in (0, 1):
+    got = a.copy(); _lib.check(L.sonic_ntt_fr(got.ctypes.data, 20, inverse)); h.update(got.tobytes())
 print("NTT_DIGEST", h.hexdigest())
 """
 
 
 def test_ntt_kernel_variants_agree():
     """the transform kernels exist in two builds of the same generated butterflies -- two per thread and four waves per SIMD (the
-    default), four per thread and two waves (SONIC_NTT_WAVES=2) -- and in any workgroup cap (SONIC_NTT_GRID): same bytes from all of
-    them (the default build is the one tests/test_gpu_parity.py holds against the oracle)"""
+    default), four per thread and two waves (SONIC_NTT_WAVES=2) -- in any workgroup cap (SONIC_NTT_GRID), and with nine or ten wide stages
+    in ONE pass through a 128-KB block (SONIC_NTT_BIG=1, round 5: faster alone on the chip, slower inside streamed proofs, so not the
+    default): same bytes from all of them, up to transforms of 2^21 points (the default build is the one tests/test_gpu_parity.py and
+    tests/test_gpu_fullsize.py hold against the oracle and the closed form)"""
     digests = []
-    for extra in ({}, {"SONIC_NTT_WAVES": "2"}, {"SONIC_NTT_GRID": "3"}, {"SONIC_NTT_WAVES": "2", "SONIC_NTT_GRID": "5"}):
+    for extra in ({}, {"SONIC_NTT_WAVES": "2"}, {"SONIC_NTT_GRID": "3"}, {"SONIC_NTT_WAVES": "2", "SONIC_NTT_GRID": "5"}, {"SONIC_NTT_BIG": "1"}):
         out = subprocess.run([sys.executable, "-c", _NTT_ALT], cwd=ROOT, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "NTT_DIGEST" in out.stdout, out.stderr[-3000:]
         digests.append(out.stdout.split("NTT_DIGEST")[1].split()[0])

@@ -214,8 +214,8 @@ def test_msm_full_size_properties(sonic, orc):
 
 @pytest.mark.parametrize("log2n", [20, 21, 24])
 def test_ntt_full_size_closed_form(sonic, log2n):
-    """the transforms at the bench size (2^21: ten wide stages -- two passes of five up to round 4, ONE pass through a 128-KB block since
-    round 5; 2^20: nine stages in one pass) and with three wide passes (2^24: 5 + 4 + 4 stages),
+    """the transforms at the bench size (2^21: ten wide stages in two passes of five), at 2^20 (nine: 5 + 4) and with three wide passes
+    (2^24: 5 + 4 + 4 stages),
     beyond what the CPU oracle transforms in seconds: the transform of an input with three non-zero coefficients has the closed
     form out[i] = sum_k c_k w^(k i), w = 7^((r-1)/2^log2n) (include/sonic_hip.h); sampled positions against python integers, and
     the inverse transform of the result must be the input again.  (The product of src/Sonic/Constraints.hs:61 runs on these

@@ -17,6 +17,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt_only -o t -- py
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/ntt_pmc_$C -o t -- python3 tools/ntt_time.py > /dev/null 2> $OUT/ntt_pmc_$C.err
 done
+# the opt-in single-pass form of the wide stages (SONIC_NTT_BIG=1; set in this shell's environment, not behind `--`): its traffic and durations
+export SONIC_NTT_BIG=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt_only_big -o t -- python3 tools/ntt_time.py > $OUT/ntt_only_big.txt 2> $OUT/ntt_only_big.err
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/ntt_big_pmc_$C -o t -- python3 tools/ntt_time.py > /dev/null 2> $OUT/ntt_big_pmc_$C.err
+done
+unset SONIC_NTT_BIG
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done

@@ -13,6 +13,11 @@ cp $(find $IN/bench_prof -name "*kernel_stats.csv" | head -1) $P/${TAG}_bench_ke
 for C in FETCH_SIZE WRITE_SIZE; do
   [ -d $IN/ntt_pmc_$C ] && cp $(find $IN/ntt_pmc_$C -name "*counter_collection.csv" | head -1) $P/${TAG}_ntt_pmc_${C}_counter_collection.csv
 done
+if [ -d $IN/ntt_only_big ]; then
+  cp $(find $IN/ntt_only_big -name "*kernel_stats.csv" | head -1) $P/${TAG}_ntt_only_big_kernel_stats.csv && cp $IN/ntt_only_big.txt $P/${TAG}_ntt_only_big.txt
+  for C in FETCH_SIZE WRITE_SIZE; do cp $(find $IN/ntt_big_pmc_$C -name "*counter_collection.csv" | head -1) $P/${TAG}_ntt_big_pmc_${C}_counter_collection.csv; done
+  python3 tools/pmc_ntt_summary.py $P/${TAG}_ntt_big_pmc_FETCH_SIZE_counter_collection.csv $P/${TAG}_ntt_big_pmc_WRITE_SIZE_counter_collection.csv $P/${TAG}_ntt_only_big_kernel_stats.csv > $P/${TAG}_pmc_ntt_big.json
+fi
 [ -d $IN/ntt_pmc_WRITE_SIZE ] && python3 tools/pmc_ntt_summary.py $P/${TAG}_ntt_pmc_FETCH_SIZE_counter_collection.csv $P/${TAG}_ntt_pmc_WRITE_SIZE_counter_collection.csv $P/${TAG}_ntt_only_kernel_stats.csv > $P/${TAG}_pmc_ntt.json
 for C in FETCH_SIZE WRITE_SIZE SQ; do
   cp $(find $IN/pmc_$C -name "*counter_collection.csv" | head -1) $P/${TAG}_pmc_${C}_counter_collection.csv
