@@ -847,7 +847,7 @@ def main(argv=None):
                           "scalar_muls_per_s_inside_prove": round(executed * proofs_per_s, 1)}
 
     cpu_baseline = None
-    if not args.no_cpu and do_prove:
+    if not args.no_cpu and do_prove and world == 1:        # (the CPU legs run at N = 1 only: they time host cores, not GPUs)
         try:
             cpu_baseline = cpu_baseline_leg(args, sonic_amd, srs, x, alpha, circ, transcripts, proof, sc, n, Q, d, msm_n, K, W, big_circuit, rand_fr_array)
         except Exception as e:      # noqa: BLE001
