@@ -163,3 +163,75 @@ def test_srs_pairing_record_field(sonic):
     with pytest.raises(_lib.SonicError) as e:
         g1only.srsPairing
     assert e.value.code == 7
+
+
+def test_concurrent_multi_device_calls_from_several_host_threads(sonic):
+    """the in-process entry points are re-entrant: two host threads run sonic_prove_shared over their own pairs of handles while a third
+    runs one MSM over two replicas by bucket range and a fourth streams a batch -- all on the device list [0, 0] (or real ordinals) --
+    and every result equals the single-handle one (per-device contexts, pooled lanes and leased streams instead of process-wide state)"""
+    import threading
+    nd = sonic.device_count()
+    devs = [0, 0] if nd < 2 else [0, 1]
+    n, Q = 900, 2
+    d = 8 * n
+    pyr = random.Random(4)
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    enc = big_circuit(11, n, Q)
+    circuit = sonic.ArithCircuit(sonic.GateWeights(enc["wL"], enc["wR"], enc["wO"]), enc["cs"])
+    asg = sonic.Assignment(enc["aL"], enc["aR"], enc["aO"])
+    reps = [sonic.SRS.new(d, x, alpha, device=devs[0])]
+    reps.append(reps[0].replicate(devs[1]))
+
+    def handles():
+        hs = [sonic.Prover(r, circuit, prepare=True) for r in reps]
+        for h in hs:
+            h.set_assignment(asg)
+        return hs
+    groups = [handles() for _ in range(3)]
+    trs = [rand_fr_array(np.random.default_rng(70 + i), 8 + 2 * Q) for i in range(8)]
+    for t in trs:
+        t[:, 0] |= 1
+    alone = sonic.Prover(reps[0], circuit, prepare=False)
+    alone.set_assignment(asg)
+    want = [alone.prove_bytes(t) for t in trs]
+    sc = rand_fr_array(np.random.default_rng(5), 6000)
+    from sonic_amd.commitment import msm_g1_srs
+    want_msm = msm_g1_srs(reps[0], 1, -3000, sc[:2999])
+    errors, results = [], {}
+
+    def shared(g, which):
+        try:
+            for rnd in range(4):
+                for i in which:
+                    assert sonic.prove_shared(groups[g], trs[i]) == want[i], (g, i)
+            results[("shared", g)] = True
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def msm():
+        try:
+            for rnd in range(6):
+                assert sonic.msm_g1_srs_multi(reps, 1, -3000, sc[:2999], mode=rnd & 1) == want_msm
+            results["msm"] = True
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def batch():
+        try:
+            for rnd in range(3):
+                assert sonic.prove_batch(groups[2], trs) == want
+            results["batch"] = True
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=shared, args=(0, [0, 1, 2, 3])), threading.Thread(target=shared, args=(1, [4, 5, 6, 7])),
+          threading.Thread(target=msm), threading.Thread(target=batch)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 4
+    for g in groups:
+        for h in g:
+            h.close()
+    alone.close()
