@@ -939,6 +939,8 @@ static int msm_multi(const sonic_srs_t* const* srs, int world, int basis, const 
         bar.wait(); at_barrier_2 = true;                           // nobody re-uses its buckets while a peer still reads them
       } while (false);
     } catch (const HipFail& f) { fail(f.code); }
+    catch (const std::exception& e) { rc = SONIC_ERR_HIP; errs[(size_t)r] = e.what(); }       // (nothing may leave a thread's body: std::terminate)
+    catch (...) { rc = SONIC_ERR_HIP; errs[(size_t)r] = "unknown exception"; }
     if (exchange) { if (!at_barrier_1) bar.wait(); if (!at_barrier_2) bar.wait(); }
     rcs[(size_t)r] = rc;
   };

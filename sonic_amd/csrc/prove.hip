@@ -377,7 +377,12 @@ int sonic_prover_set_assignment(sonic_prover_t* p, const uint8_t* aL, const uint
   upload_fr_mont(st, p->aR, aR, p->n, p->flags.as<int>());
   upload_fr_mont(st, p->aO, aO, p->n, p->flags.as<int>());
   int f = read_flags(st, p->flags);
-  if (f) return flags_to_status(f, "sonic_prover_set_assignment");
+  if (f) {
+    // the handle's buffers now hold a partly converted assignment: it must not be proven with (a caller that ignores the status and
+    // calls prove gets "no assignment set", not a proof of garbage)
+    p->have_assignment = false;
+    return flags_to_status(f, "sonic_prover_set_assignment");
+  }
   p->have_assignment = true;
   p->have_witness_digest = false;
   API_END
@@ -1392,11 +1397,13 @@ int sonic_prove_shared(sonic_prover_t* const* provers, int world, const uint8_t*
   auto body = [&](int r) {
     sonic_prover_t* p = provers[r];
     int rc = SONIC_OK;
-    bool placed;
-    { std::lock_guard<std::mutex> g(p->mu); placed = p->share_world == world && p->share_rank == r; }
-    if (!placed) rc = sonic_prover_set_share(p, r, world);          // (clears the slots of pieces the handle no longer runs; once per change)
-    if (!rc) rc = sonic_prover_prove_share(p, transcript, &shares[ssz * (size_t)r]);
-    if (rc) { char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)r] = b; }
+    try {
+      bool placed;
+      { std::lock_guard<std::mutex> g(p->mu); placed = p->share_world == world && p->share_rank == r; }
+      if (!placed) rc = sonic_prover_set_share(p, r, world);          // (clears the slots of pieces the handle no longer runs; once per change)
+      if (!rc) rc = sonic_prover_prove_share(p, transcript, &shares[ssz * (size_t)r]);
+      if (rc) { char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)r] = b; }
+    } catch (...) { rc = SONIC_ERR_HIP; }                            // (nothing may leave a thread's body: std::terminate)
     rcs[(size_t)r] = rc;
   };
   {
@@ -1429,10 +1436,12 @@ int sonic_prove_batch(sonic_prover_t* const* provers, int n_provers, int64_t K, 
   auto body = [&](int h) {
     for (int64_t i = h; i < K; i += n_provers) {
       int rc = SONIC_OK;
-      if (per_proof) rc = sonic_prover_set_assignment(provers[h], aL + asz * (size_t)i, aR + asz * (size_t)i, aO + asz * (size_t)i);
-      if (!rc) rc = sonic_prover_prove(provers[h], transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
+      try {
+        if (per_proof) rc = sonic_prover_set_assignment(provers[h], aL + asz * (size_t)i, aR + asz * (size_t)i, aO + asz * (size_t)i);
+        if (!rc) rc = sonic_prover_prove(provers[h], transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
+        if (rc && first_bad[(size_t)h] < 0) { first_bad[(size_t)h] = i; char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)h] = b; }
+      } catch (...) { rc = SONIC_ERR_HIP; }                          // (nothing may leave a thread's body: std::terminate)
       status[(size_t)i] = rc;
-      if (rc && first_bad[(size_t)h] < 0) { first_bad[(size_t)h] = i; char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)h] = b; }
     }
   };
   {
