@@ -771,12 +771,13 @@ def main(argv=None):
 
     # ---------------- rank 0 drives ALL GPUs from this one process through the C ABI (N > 1; the other ranks idle on the store) --------
     in_process = None
-    if pg and world > 1 and do_prove and not args.prove_only and use_nccl:
+    if pg and world > 1 and do_prove and not args.prove_only:
         store = dist.distributed_c10d._get_default_store()
         barrier()
         if rank == 0:
             try:
-                in_process = in_process_legs(sonic_amd, L, _lib, x, alpha, list(range(world)), args.log2n, Q, K, max(1, W), args.strong_log2n, strong_n,
+                # rank i's GPU (over RCCL every rank has its own; gloo ranks may share one: the device list then repeats an ordinal)
+                in_process = in_process_legs(sonic_amd, L, _lib, x, alpha, [i % ndev for i in range(world)], args.log2n, Q, K, max(1, W), args.strong_log2n, strong_n,
                                              make_transcripts, rand_fr_array, big_circuit, srs0=srs)
             except Exception as e:      # noqa: BLE001
                 leg_errors["in_process"] = repr(e)

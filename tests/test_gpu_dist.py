@@ -177,6 +177,10 @@ def test_bench_two_ranks_one_gpu():
     ps = j["prove_strong"]
     assert ps["scaling"] == "strong" and ps["n_gpus"] == 2 and ps["n"] == 1 << 12 and ps["same_bytes_as_one_gpu_alone"] is True and ps["ms_per_proof"] > 0
     assert j["north_star"] is None
+    # rank 0 also drove "both GPUs" (here: the one GPU twice) from its one process through the C ABI while rank 1 waited on the store
+    ip = j["in_process"]
+    assert ip["devices"] == [0, 0] and ip["proofs"]["same_bytes_as_one_handle_alone"] is True and ip["prove_strong"]["same_bytes_as_one_gpu_alone"] is True
+    assert ip["msm_strong"]["bucket_ranges"]["same_result_as_one_gpu"] is True and j["status"] == "ok"
 
 
 def test_bench_starts_its_own_ranks_and_never_mislabels():
