@@ -271,8 +271,8 @@ int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int ra
  *   sonic_prove_shared    ONE proof over `world` prover handles of the same circuit and assignment: handle r runs rank r's share
  *                         (sonic_prover_set_share is applied by the call), the 3.3-KB shares are combined on the host
  *                         (sonic_proof_from_shares).  Same bytes as sonic_prover_prove on one GPU.
- *   sonic_prove_batch     K independent proofs over n_provers handles (the reference's `mapM prove`; BASELINE "batch of 64 independent
- *                         proofs streamed over 8 GPUs"): proof i goes to handle i % n_provers, each handle proves its share of the
+ *   sonic_prove_batch     K proofs of ONE circuit over n_provers handles (`mapM (prove srs asg_i circuit)`; for K statements with their own
+ *                         circuits see sonic_prove_many): proof i goes to handle i % n_provers, each handle proves its share of the
  *                         list in order on a thread of its own; no collective.  Two handles per GPU stream that GPU's proofs (one
  *                         proof's host tail under the next proof's kernels).  aL, aR, aO: K x n x 32 bytes each, or all NULL to keep
  *                         every handle's resident assignment; transcripts: K x (8 + 2Q) x 32; out_proofs: K x sonic_proof_size(Q);
@@ -284,7 +284,18 @@ int sonic_prove_share_plan(int64_t n, int64_t Q, int prepared, int world, int ra
  *                         (CommitmentScheme.hs:25-29 is a fold over independent terms); mode 1 = by bucket range (strong scaling):
  *                         every GPU accumulates its slice into a full bucket set, the GPUs pull their bucket range from each other
  *                         (hipMemcpyPeerAsync: the all-to-all of sonic_msm_exchange_layout), each reduces 1/world of the buckets;
- *                         needs the full window tables on every replica. */
+ *                         needs the full window tables on every replica.
+ *   sonic_prove_many      K INDEPENDENT statements of one shape (n, Q) -- every proof its own circuit, assignment and transcript, as host
+ *                         buffers: `mapM (uncurry (prove srs))` -- spread over the SRS replicas with two host threads per replica, each
+ *                         making one-shot sonic_prove calls (the device parks the handles' shells between calls).  out_proofs: K x
+ *                         sonic_proof_size(Q); out_status (may be NULL): K statuses; returns the first non-zero one in list order. */
+typedef struct sonic_statement {
+  const uint8_t *wL, *wR, *wO, *cs;      /* ArithCircuit: Q x n weights each, Q constants */
+  const uint8_t *aL, *aR, *aO;           /* Assignment: n each */
+  const uint8_t* transcript;             /* 8 + 2Q draws */
+} sonic_statement_t;
+int sonic_prove_many(const sonic_srs_t* const* srs, int n_srs, int64_t n, int64_t Q, const sonic_statement_t* statements, int64_t K,
+                     uint8_t* out_proofs, int* out_status);
 int sonic_prove_shared(sonic_prover_t* const* provers, int world, const uint8_t* transcript, uint8_t* out_proof);
 int sonic_prove_batch(sonic_prover_t* const* provers, int n_provers, int64_t K, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO,
                       const uint8_t* transcripts, uint8_t* out_proofs, int* out_status);

@@ -25,7 +25,7 @@ from .commitment import commit_poly, open_poly, pc_v, msm_g1, MsmLane  # noqa: F
 from .protocol import hsc_prove_poly, hsc_verify_poly  # noqa: F401,E402
 from .protocol import prove_fs, verify_fs, fs_challenges, fs_circuit_digest, fs_srs_id  # noqa: F401,E402
 from .protocol import proof_from_shares, share_plan, from_x, from_y, biv_add  # noqa: F401,E402
-from .protocol import prove_shared, prove_batch, device_count  # noqa: F401,E402
+from .protocol import prove_shared, prove_batch, prove_many, device_count  # noqa: F401,E402
 from .commitment import msm_g1_srs_multi  # noqa: F401,E402
 from .protocol import prove, verify, hsc_prove, hsc_verify, Proof, HscProof, RndOracle, Prover, ProverPipeline, ArithCircuit, Assignment, GateWeights  # noqa: F401,E402
 

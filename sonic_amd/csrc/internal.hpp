@@ -31,12 +31,13 @@ struct DeviceCtx {
   // twiddle tables of the prover handles, one set per transform size, shared by every handle on the device and never freed (64 + 64 MB
   // at 2^21 points: two streaming handles used to hold one copy each) (under pool_mu)
   std::map<int, NttTables*> prover_ntt;
-  // the prover shell the one-shot sonic_prove keeps for the next call with the same SRS and circuit shape (prove.hip)
+  // the idle prover shells the one-shot sonic_prove keeps for later calls with the same SRS and circuit shape (prove.hip): at most
+  // ONE_SHOT_SHELLS, the oldest goes when another is parked
   std::mutex one_shot_mu;
-  void* one_shot = nullptr;
+  std::vector<void*> one_shot;
 };
 const NttTables& device_ntt_tables(int log2n);          // of the current device; built on first use (blocks until they are complete)
-void drop_one_shot_of(const sonic_srs* s);              // an SRS handle is going away: the cached one-shot shell over it goes first
+void drop_one_shot_of(const sonic_srs* s);              // an SRS handle is going away: the parked one-shot shells over it go first
 // dev < 0: the process's default device (sonic_init, else LOCAL_RANK % device count, else 0).  Throws HipFail{SONIC_ERR_NO_DEVICE}
 // without a GPU -- the library has no CPU fallback -- and HipFail{SONIC_ERR_INVALID_ARG} for an ordinal the node does not have.
 class DeviceScope {

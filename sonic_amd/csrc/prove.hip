@@ -1326,19 +1326,26 @@ int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t*
 
 // prove :: SRS -> Assignment Fr -> ArithCircuit Fr -> m (Proof, RndOracle) with the reference's own shape: everything handed over per
 // call (Protocol.hs:47-52).  A handle costs streams, events, ~20 workspace allocations that grow on the first proof and the twiddle
-// tables -- tens of milliseconds against a 32-ms proof -- so the device keeps the shell of the last one-shot call and the next call
-// with the same SRS handle and (n, Q) only uploads its circuit and assignment into it (round 5; bench.py `one_shot`).  Calls that
-// arrive while the shell is busy (another host thread inside sonic_prove on this GPU) make a handle of their own, as before.
+// tables -- tens of milliseconds against a 32-ms proof -- so the device parks the shell of a finished one-shot call and the next call
+// with the same SRS handle and (n, Q) only uploads its circuit and assignment into it (round 5; bench.py `one_shot`).  Several host
+// threads inside sonic_prove on one GPU each take a parked shell or make one; at most ONE_SHOT_SHELLS stay parked per device.
 }  // extern "C"
 namespace {
 struct OneShotShell { const sonic_srs* srs; sonic_prover* p; };
+constexpr size_t ONE_SHOT_SHELLS = 4;
 }
 namespace sonic {
 void drop_one_shot_of(const sonic_srs* s) {
   DeviceCtx& c = current_ctx();
-  std::lock_guard<std::mutex> g(c.one_shot_mu);
-  OneShotShell* sh = static_cast<OneShotShell*>(c.one_shot);
-  if (sh && sh->srs == s) { delete sh->p; delete sh; c.one_shot = nullptr; }
+  std::vector<OneShotShell*> gone;
+  {
+    std::lock_guard<std::mutex> g(c.one_shot_mu);
+    for (size_t i = 0; i < c.one_shot.size();) {
+      OneShotShell* sh = static_cast<OneShotShell*>(c.one_shot[i]);
+      if (sh->srs == s) { gone.push_back(sh); c.one_shot.erase(c.one_shot.begin() + (long)i); } else i++;
+    }
+  }
+  for (OneShotShell* sh : gone) { delete sh->p; delete sh; }
 }
 }
 extern "C" {
@@ -1348,29 +1355,74 @@ int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL,
   API_BEGIN_ON(srs_device(srs))
   if (!srs || n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !aL || !aR || !aO || !transcript || !out_proof) { set_error("sonic_prove: bad argument (need n >= 1, Q >= 1)"); return SONIC_ERR_INVALID_ARG; }
   DeviceCtx& ctx = current_ctx();
-  std::unique_lock<std::mutex> shell_lock(ctx.one_shot_mu, std::try_to_lock);
-  sonic_prover_t* p = nullptr;
-  bool cached = false;
-  int rc = SONIC_OK;
-  if (shell_lock.owns_lock()) {
-    OneShotShell* sh = static_cast<OneShotShell*>(ctx.one_shot);
-    if (sh && sh->srs == srs && sh->p->n == n && sh->p->Q == Q && !sh->p->prepared && sh->p->share_world <= 1) {
-      p = sh->p; cached = true;
-      rc = prover_load_circuit(p, wL, wR, wO, cs);
-    } else {
-      if (sh) { delete sh->p; delete sh; ctx.one_shot = nullptr; }
-      rc = sonic_prover_new(srs, n, Q, wL, wR, wO, cs, &p);
-      if (!rc) { ctx.one_shot = new OneShotShell{srs, p}; cached = true; }
+  OneShotShell* sh = nullptr;
+  {
+    std::lock_guard<std::mutex> g(ctx.one_shot_mu);
+    for (size_t i = ctx.one_shot.size(); i-- > 0;) {                 // newest first
+      OneShotShell* c = static_cast<OneShotShell*>(ctx.one_shot[i]);
+      if (c->srs == srs && c->p->n == n && c->p->Q == Q) { sh = c; ctx.one_shot.erase(ctx.one_shot.begin() + (long)i); break; }
     }
-  } else {
-    rc = sonic_prover_new(srs, n, Q, wL, wR, wO, cs, &p);
   }
-  if (rc) return rc;
-  rc = sonic_prover_set_assignment(p, aL, aR, aO);
-  if (!rc) rc = sonic_prover_prove(p, transcript, out_proof);
-  if (!cached) sonic_prover_free(p);
+  int rc = SONIC_OK;
+  if (sh) rc = prover_load_circuit(sh->p, wL, wR, wO, cs);
+  else {
+    sonic_prover_t* p = nullptr;
+    rc = sonic_prover_new(srs, n, Q, wL, wR, wO, cs, &p);
+    if (rc) return rc;
+    sh = new OneShotShell{srs, p};
+  }
+  if (!rc) rc = sonic_prover_set_assignment(sh->p, aL, aR, aO);
+  if (!rc) rc = sonic_prover_prove(sh->p, transcript, out_proof);
+  // park the shell (also after a failed call: the next one loads its own circuit and assignment); the oldest parked shell makes room
+  OneShotShell* evict = nullptr;
+  {
+    std::lock_guard<std::mutex> g(ctx.one_shot_mu);
+    if (ctx.one_shot.size() >= ONE_SHOT_SHELLS) { evict = static_cast<OneShotShell*>(ctx.one_shot.front()); ctx.one_shot.erase(ctx.one_shot.begin()); }
+    ctx.one_shot.push_back(sh);
+  }
+  if (evict) { delete evict->p; delete evict; }
   return rc;
   API_END
+}
+
+// mapM (\(assignment, circuit) -> prove srs assignment circuit) over K INDEPENDENT statements of one shape (n, Q), spread over the SRS
+// replicas -- one per GPU -- with two host threads per replica (statement i on thread i mod 2 n_srs; two one-shot calls in flight per
+// GPU stream it: one call's upload and host tail under the other's kernels).  BASELINE's "batch of 64 independent proofs streamed over 8
+// GPUs" with every proof its own circuit and witness; no collective.  Returns the first non-zero status in list order; all are attempted.
+int sonic_prove_many(const sonic_srs_t* const* srs, int n_srs, int64_t n, int64_t Q, const sonic_statement_t* statements, int64_t K,
+                     uint8_t* out_proofs, int* out_status) {
+  if (!srs || n_srs < 1 || n_srs > 512 || n < 1 || Q < 1 || K < 0 || (K > 0 && (!statements || !out_proofs))) return SONIC_ERR_INVALID_ARG;
+  for (int i = 0; i < n_srs; i++) if (!srs[i]) return SONIC_ERR_INVALID_ARG;
+  const size_t psz = sonic_proof_size(Q);
+  const int T = 2 * n_srs;
+  std::vector<int> status((size_t)K, SONIC_OK);
+  std::vector<std::string> errs((size_t)T);
+  auto body = [&](int t) {
+    const sonic_srs_t* s = srs[t % n_srs];
+    for (int64_t i = t; i < K; i += T) {
+      int rc = SONIC_ERR_HIP;
+      try {
+        const sonic_statement_t& st = statements[i];
+        rc = sonic_prove(s, n, Q, st.wL, st.wR, st.wO, st.cs, st.aL, st.aR, st.aO, st.transcript, out_proofs + psz * (size_t)i);
+        if (rc && errs[(size_t)t].empty()) { char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)t] = b; }
+      } catch (...) { rc = SONIC_ERR_HIP; }                            // (nothing may leave a thread's body: std::terminate)
+      status[(size_t)i] = rc;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T && t < K; t++) th.emplace_back(body, t);
+    body(0);
+    for (auto& x : th) x.join();
+  }
+  if (out_status) for (int64_t i = 0; i < K; i++) out_status[i] = status[(size_t)i];
+  for (int64_t i = 0; i < K; i++)
+    if (status[(size_t)i]) {
+      const int t = (int)(i % T);
+      set_error("sonic_prove_many, statement %ld (device %d): %s", (long)i, srs_device(srs[t % n_srs]), errs[(size_t)t].c_str());
+      return status[(size_t)i];
+    }
+  return SONIC_OK;
 }
 
 // ---- N GPUs from ONE host process: one proof shared by several handles, a batch of proofs over several handles ------------------

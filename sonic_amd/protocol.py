@@ -301,6 +301,40 @@ def prove_batch(provers, transcripts, assignments=None) -> List[bytes]:
     return [out[i].tobytes() for i in range(K)]
 
 
+class _Statement(C.Structure):          # sonic_statement_t
+    _fields_ = [(k, C.c_void_p) for k in ("wL", "wR", "wO", "cs", "aL", "aR", "aO", "transcript")]
+
+
+def prove_many(replicas, statements) -> List[bytes]:
+    """`mapM (\\(asg, circ, tr) -> prove srs asg circ)` over K INDEPENDENT statements of one shape (n, Q) -- every proof its own circuit,
+    assignment and transcript -- spread over the SRS replicas, one per GPU (sonic_prove_many: two host threads per replica making
+    one-shot calls; no collective).  statements: (Assignment, ArithCircuit, transcript) triples.  BASELINE's "batch of 64 independent
+    proofs streamed over 8 GPUs"."""
+    replicas, statements = list(replicas), list(statements)
+    K = len(statements)
+    if K == 0:
+        return []
+    keep, arr = [], (_Statement * K)()
+    n = Q = None
+    for i, (asg, circ, tr) in enumerate(statements):
+        wL, wR, wO, cs, n_i, Q_i = _circuit_arrays(circ)
+        aL, aR, aO, t = fr_array(asg.aL), fr_array(asg.aR), fr_array(asg.aO), fr_array(tr)
+        if n is None:
+            n, Q = n_i, Q_i
+        if (n_i, Q_i) != (n, Q) or aL.shape[0] != n or aR.shape[0] != n or aO.shape[0] != n or t.shape[0] != transcript_len(Q):
+            raise ValueError(f"prove_many: statement {i} has another shape than statement 0 (n = {n}, Q = {Q})")
+        bufs = (wL, wR, wO, cs, aL, aR, aO, t)
+        keep.append(bufs)
+        for name, b in zip(("wL", "wR", "wO", "cs", "aL", "aR", "aO", "transcript"), bufs):
+            setattr(arr[i], name, b.ctypes.data)
+    psz = _lib.lib().sonic_proof_size(Q)
+    out = np.zeros((K, psz), np.uint8)
+    status = (C.c_int * K)()
+    srs_arr = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+    _lib.check(_lib.lib().sonic_prove_many(srs_arr, len(replicas), n, Q, arr, K, out.ctypes.data, status))
+    return [out[i].tobytes() for i in range(K)]
+
+
 class ProverPipeline:
     """`mapM prove` over a stream of statements of one circuit, from one host thread: `depth` prover handles used in turn, so that
     while proof i is being waited for and finished, proof i + 1 is already running (its polynomial building and sorts fill the

@@ -15,7 +15,8 @@
  *   1. sonic_prove on device[0] alone                                        == the oracle's proof
  *   2. sonic_prove_shared over all devices (replicas made by sonic_srs_new_on and by sonic_srs_replicate), unprepared and prepared,
  *      then over the first two handles only (the plan changes), then over one                == the oracle's proof
- *   3. sonic_prove_batch: K proofs over all handles, resident assignment and per-proof assignments == sonic_prover_prove one by one
+ *   3. sonic_prove_batch: K proofs over all handles, resident assignment and per-proof assignments == sonic_prover_prove one by one;
+ *      sonic_prove_many: K whole statements (circuit + assignment + transcript each) over all replicas    == the same proofs
  *   4. sonic_msm_g1_srs_multi by term range and by bucket range (host scalars), sonic_msm_g1_srs_multi_dev (resident slices)
  *                                                                                             == sonic_msm_g1_srs on device[0]
  *   5. the error contract: unknown ordinal, handles of different circuits, a handle named twice, a lane and an SRS on different GPUs
@@ -141,6 +142,23 @@ int main(int argc, char** argv) {
       if ((rc = sonic_prover_set_assignment(prv[1 % world], aL, aR, aO))) return fail("sonic_prover_set_assignment(restore)", rc);
     }
     free(st);
+  }
+
+  /* 3b. K statements handed over whole -- circuit, assignment, transcript per proof, as the reference's prove takes them -- spread over the
+   * replicas by sonic_prove_many (here the K statements share their circuit and differ in their transcripts) */
+  {
+    sonic_statement_t* sts = malloc(sizeof(sonic_statement_t) * (size_t)K);
+    int* st = malloc(sizeof(int) * (size_t)K);
+    if (!sts || !st) return 2;
+    for (i = 0; i < (int)K; i++) {
+      sts[i].wL = wL; sts[i].wR = wR; sts[i].wO = wO; sts[i].cs = cs; sts[i].aL = aL; sts[i].aR = aR; sts[i].aO = aO;
+      sts[i].transcript = trs + tsz * (size_t)i;
+    }
+    memset(batch, 0, psz * (size_t)K);
+    if ((rc = sonic_prove_many((const sonic_srs_t* const*)srs, world, n, Q, sts, K, batch, st))) return fail("sonic_prove_many", rc);
+    for (i = 0; i < (int)K; i++) if (st[i]) { fprintf(stderr, "multi_harness: sonic_prove_many status[%d] = %d\n", i, st[i]); return 1; }
+    if (memcmp(batch, batch2, psz * (size_t)K)) { fprintf(stderr, "multi_harness: sonic_prove_many over %d replicas differs from the proofs made one by one\n", world); return 1; }
+    free(sts); free(st);
   }
 
   /* 4. ONE MSM over all replicas */

@@ -147,6 +147,71 @@ def test_python_mirror_of_the_multi_device_entry_points(sonic, orc):
         p.close()
 
 
+def test_prove_many_independent_statements(sonic, orc, ref):
+    """BASELINE configs[4] read literally -- a batch of INDEPENDENT proofs: every statement its own circuit (dense weights, the rndCircuit
+    rows, and one with an all-zero constraint row), assignment and transcript, handed over as host buffers (`mapM (uncurry (prove srs))`,
+    src/Sonic/Protocol.hs:47-52) -- through sonic_prove_many over the replica list [0, 0] (real ordinals where the box has them): bytes
+    against the C oracle for every statement; a non-canonical assignment in one statement is that statement's status and the others are
+    still proven; the one-shot shells parked on the device are re-used across calls and shapes"""
+    from sonic_amd import _lib
+    nd = sonic.device_count()
+    devs = [0, 0] if nd < 2 else [0, 1]
+    n, Q = 700, 3
+    d = 7 * n + 11
+    pyr = random.Random(77)
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    reps = [sonic.SRS.new(d, x, alpha, device=devs[0])]
+    reps.append(reps[0].replicate(devs[1]))
+    osrs = orc.SRS.from_points(d, reps[0].points(0, -d, 2 * d + 1), reps[0].points(1, -d, 2 * d + 1))
+    orc.set_mode(1, os.cpu_count() or 1)
+    statements, want = [], []
+    for i in range(11):
+        c = big_circuit(300 + i, n, Q)
+        if i % 3 == 1:                       # dense random weights
+            la, lb, lo = c["ints"]
+            rng = np.random.default_rng(i)
+            W = [rand_fr_array(rng, Q * n) for _ in range(3)]
+            if i == 4:
+                for w in W:
+                    w[n:2 * n] = 0           # an all-zero constraint row
+            cs = []
+            for q in range(Q):
+                acc = 0
+                for w, a in zip(W, (la, lb, lo)):
+                    acc += sum(int.from_bytes(w[q * n + k].tobytes(), "little") * a[k] for k in range(n))
+                cs.append(acc % R)
+            c = dict(c, wL=W[0], wR=W[1], wO=W[2], cs=fr_bytes(cs))
+        tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+        statements.append((sonic.Assignment(c["aL"], c["aR"], c["aO"]), sonic.ArithCircuit(sonic.GateWeights(c["wL"], c["wR"], c["wO"]), c["cs"]), tr))
+        want.append(orc.prove(osrs, n, Q, c["wL"], c["wR"], c["wO"], c["cs"], c["aL"], c["aR"], c["aO"], tr, True))
+    assert sonic.prove_many(reps, statements) == want
+    assert sonic.prove_many(reps[:1], statements[:3]) == want[:3]            # one replica: two threads on it
+    assert sonic.prove_many(reps, []) == []
+    # a bad statement in the middle: its status is the call's, the proofs around it are made
+    bad = list(statements)
+    a5 = bad[5][0]
+    broken = np.array(a5.aR, copy=True)
+    broken[3, :] = 0xFF
+    bad[5] = (sonic.Assignment(a5.aL, broken, a5.aO), bad[5][1], bad[5][2])
+    with pytest.raises(_lib.SonicError) as e:
+        sonic.prove_many(reps, bad)
+    assert e.value.code == 3 and "statement 5" in e.value.message
+    # another shape afterwards (the parked shells of the first shape make room), then the first shape again
+    n2 = 90
+    c2 = big_circuit(9, n2, 1)
+    st2 = (sonic.Assignment(c2["aL"], c2["aR"], c2["aO"]), sonic.ArithCircuit(sonic.GateWeights(c2["wL"], c2["wR"], c2["wO"]), c2["cs"]),
+           fr_bytes([pyr.randrange(1, R) for _ in range(10)]))
+    got2 = sonic.prove_many(reps, [st2] * 5)
+    assert len(set(got2)) == 1 and got2[0] == orc.prove(osrs, n2, 1, c2["wL"], c2["wR"], c2["wO"], c2["cs"], c2["aL"], c2["aR"], c2["aO"], st2[2], True)
+    assert sonic.prove_many(reps, statements[:4]) == want[:4]
+    # a shape the SRS is too small for (Protocol.hs:54-55) is reported per statement
+    big = big_circuit(1, d // 7 + 1, 1)
+    with pytest.raises(_lib.SonicError) as e:
+        sonic.prove_many(reps, [(sonic.Assignment(big["aL"], big["aR"], big["aO"]), sonic.ArithCircuit(sonic.GateWeights(big["wL"], big["wR"], big["wO"]), big["cs"]),
+                                 fr_bytes([pyr.randrange(1, R) for _ in range(10)]))])
+    assert e.value.code == 1
+
+
 def test_srs_pairing_record_field(sonic):
     """srsPairing = e(g, h^alpha) (src/Sonic/SRS.hs:21,42) from the GPU-made G2 half through the host pairing, against the python
     oracle's pairing of the same two points (tests/test_sanitizers.py pins the same entry point GPU-free)"""
