@@ -79,7 +79,31 @@ __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_
 __device__ __forceinline__ Fr fr_canonical(const Fr& a) { return fp_add(a, Fr::zero()); }              // [0, 2r) -> [0, r)
 // U butterflies of a thread in one stage (unit: the stage with a span of one element -- every twiddle is w^0 = 1, the butterfly is a
 // sum and a difference).  U = 4: 176 VGPRs inside the routine, two waves per SIMD; U = 2: 106, four waves per SIMD.
-template <int U>
+// LDS layout of a block of E elements (round 5).  As 32-byte records (HI = 16: the upper four limbs right behind the lower four) every
+// ds_read_b128 / ds_write_b128 of a wave touches every OTHER 16-byte slot -- a two-way bank conflict on all LDS traffic of the transform
+// (rocprofv3 --pmc: SQ_LDS_BANK_CONFLICT = 63-68 % of SQ_LDS_IDX_ACTIVE, profiles/r05_lds_before.txt).  SPLIT: the lower halves of the
+// block's elements form one plane (element i at byte 16 i), the upper halves a second one HI = 16 E bytes further; consecutive lanes then
+// read consecutive slots.  HI is an immediate of the generated routines (sonic_ntt_bfly2s14_* for 1024-element blocks, ..s15_* for
+// 2048-element tiles); a 4096-element block (HI = 65536 does not fit the 16-bit offset field) and the four-butterfly routines keep records.
+template <int U, int ELOG> struct LdsLayout {
+  static constexpr bool SPLIT = U == 2 && ELOG <= 11;
+  static constexpr uint32_t STRIDE = SPLIT ? 16 : 32;
+  static constexpr uint32_t HI = SPLIT ? (16u << ELOG) : 16u;
+};
+__device__ __forceinline__ void lds_put(unsigned char* sh, uint32_t stride, uint32_t hi, int i, const Fr& v) {
+  const uint4* w = reinterpret_cast<const uint4*>(&v);
+  *reinterpret_cast<uint4*>(sh + stride * (uint32_t)i) = w[0];
+  *reinterpret_cast<uint4*>(sh + stride * (uint32_t)i + hi) = w[1];
+}
+__device__ __forceinline__ Fr lds_get(const unsigned char* sh, uint32_t stride, uint32_t hi, int i) {
+  Fr v;
+  uint4* w = reinterpret_cast<uint4*>(&v);
+  w[0] = *reinterpret_cast<const uint4*>(sh + stride * (uint32_t)i);
+  w[1] = *reinterpret_cast<const uint4*>(sh + stride * (uint32_t)i + hi);
+  return v;
+}
+
+template <int U, uint32_t HI = 16>
 __device__ __forceinline__ void ntt_bfly(int inverse, const uint32_t (&e0)[U], const uint32_t (&tj)[U], uint32_t span, const Fr* stw, bool unit = false) {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the generated routines exist in the device pass only)
 #if defined(SONIC_NTT_PROBE)              // timing probes (tools only; results are wrong): 1 = no butterflies at all, 2 = every stage as the unit stage
@@ -90,7 +114,16 @@ __device__ __forceinline__ void ntt_bfly(int inverse, const uint32_t (&e0)[U], c
     if (unit) sonic_ntt_bfly4_unit(e0[0], e0[1], e0[2], e0[3], span);
     else if (!inverse) sonic_ntt_bfly4_fwd(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
     else sonic_ntt_bfly4_inv(e0[0], e0[1], e0[2], e0[3], tj[0], tj[1], tj[2], tj[3], span, stw);
+  } else if constexpr (HI == 16384) {
+    if (unit) sonic_ntt_bfly2s14_unit(e0[0], e0[1], span);
+    else if (!inverse) sonic_ntt_bfly2s14_fwd(e0[0], e0[1], tj[0], tj[1], span, stw);
+    else sonic_ntt_bfly2s14_inv(e0[0], e0[1], tj[0], tj[1], span, stw);
+  } else if constexpr (HI == 32768) {
+    if (unit) sonic_ntt_bfly2s15_unit(e0[0], e0[1], span);
+    else if (!inverse) sonic_ntt_bfly2s15_fwd(e0[0], e0[1], tj[0], tj[1], span, stw);
+    else sonic_ntt_bfly2s15_inv(e0[0], e0[1], tj[0], tj[1], span, stw);
   } else {
+    static_assert(HI == 16, "a split layout needs its own generated routines (tools/gen_mont_asm.py)");
     if (unit) sonic_ntt_bfly2_unit(e0[0], e0[1], span);
     else if (!inverse) sonic_ntt_bfly2_fwd(e0[0], e0[1], tj[0], tj[1], span, stw);
     else sonic_ntt_bfly2_inv(e0[0], e0[1], tj[0], tj[1], span, stw);
@@ -100,10 +133,12 @@ __device__ __forceinline__ void ntt_bfly(int inverse, const uint32_t (&e0)[U], c
 
 // ELOG: log2 of the block's elements = 2 U x 256 threads
 template <int U, int ELOG>
-__device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
+__device__ __forceinline__ void ntt_wide_body(Fr* sh_fr, Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int s0, int ns, int tw_shift, int inverse,
                                               const Fr* __restrict__ scale) {
   constexpr int THREADS = (1 << ELOG) / (2 * U);            // U butterflies per thread and stage
   static_assert(THREADS == 256 || THREADS == 1024, "256 threads per block of 1024 / 2048 elements, 1024 for the 4096-element block");
+  using LY = LdsLayout<U, ELOG>;
+  unsigned char* sh = reinterpret_cast<unsigned char*>(sh_fr);
   const uint32_t lds0 = lds_address(sh);
   const int lc = ELOG - ns;                                 // log2 C
   const int lstride = log2n - s0 - ns;                      // log2 of the row stride
@@ -112,7 +147,7 @@ __device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const 
   for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
     const long u = item >> (lstride - lc), cb = item & (col_blocks - 1);
     const long base = (u << (log2n - s0)) + (cb << lc);
-    for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) sh[e] = d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))];
+    for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) lds_put(sh, LY::STRIDE, LY::HI, e, d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))]);
     __syncthreads();
     for (int t = 0; t < ns; t++) {
       const int tt = inverse ? ns - 1 - t : t;               // forward (DIF): widest span first; inverse (DIT): the reverse
@@ -127,18 +162,18 @@ __device__ __forceinline__ void ntt_wide_body(Fr* sh, Fr* __restrict__ d, const 
         const int c = bt & ((1 << lc) - 1), kp = bt >> lc;
         const int k = ((kp >> hb) << (hb + 1)) | (kp & ((1 << hb) - 1));         // row with bit hb clear
         const long j = (((long)(k & ((1 << hb) - 1)) << lstride) + (cb << lc) + c) & ((1L << lhalf) - 1);
-        e0[q] = lds0 + (uint32_t)(((k << lc) | c) * (int)sizeof(Fr));
+        e0[q] = lds0 + (uint32_t)((k << lc) | c) * LY::STRIDE;
         tj[q] = (uint32_t)j * (uint32_t)sizeof(Fr);
       }
-      const uint32_t span = (uint32_t)sizeof(Fr) << (hb + lc);
-      ntt_bfly<U>(inverse, e0, tj, span, stw);
+      const uint32_t span = LY::STRIDE << (hb + lc);
+      ntt_bfly<U, LY::HI>(inverse, e0, tj, span, stw);
       __syncthreads();
     }
     if (scale) {
       const Fr sc = *scale;
-      for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = fp_mul(sh[e], sc);
+      for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = fp_mul(lds_get(sh, LY::STRIDE, LY::HI, e), sc);
     } else {
-      for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = sh[e];
+      for (int e = threadIdx.x; e < (1 << ELOG); e += THREADS) d[base + ((long)(e >> lc) << lstride) + (e & ((1 << lc) - 1))] = lds_get(sh, LY::STRIDE, LY::HI, e);
     }
     __syncthreads();
   }
@@ -179,16 +214,17 @@ __device__ __forceinline__ void ntt_local_body(Fr* __restrict__ d, const Fr* __r
   const uint32_t lds0 = lds_address(sh);
   const int tile = 1 << tile_log;
   constexpr int THREADS = 1024 / U;
+  using LY = LdsLayout<U, TILE_LOG>;       // full tiles (the generated butterflies); the small transforms of the C++ branch keep 32-byte records
   const long ntiles = 1L << (log2n - tile_log);
   for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {       // grid-stride over the tiles (see WIDE_GRID)
   const long base = tl << tile_log;
-  // (mul: the pointwise product of two transforms folded into the inverse transform's first load)
-  if (mul) { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = fp_mul(d[base + i], mul[base + i]); }
-  else { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = d[base + i]; }
-  __syncthreads();
   // forward: stages s = log2n - tile_log .. log2n - 1 (half = tile/2 .. 1)
   // inverse: the same stages in reverse order (half = 1 .. tile/2)
+  // (mul: the pointwise product of two transforms folded into the inverse transform's first load)
   if (tile_log == TILE_LOG) {
+    if (mul) { for (int i = threadIdx.x; i < (1 << TILE_LOG); i += THREADS) lds_put(smem, LY::STRIDE, LY::HI, i, fp_mul(d[base + i], mul[base + i])); }
+    else { for (int i = threadIdx.x; i < (1 << TILE_LOG); i += THREADS) lds_put(smem, LY::STRIDE, LY::HI, i, d[base + i]); }
+    __syncthreads();
     for (int k = 0; k < TILE_LOG; k++) {
       const int hl = inverse ? k : TILE_LOG - 1 - k;       // log2(half)
       const int s = log2n - 1 - hl;
@@ -198,18 +234,21 @@ __device__ __forceinline__ void ntt_local_body(Fr* __restrict__ d, const Fr* __r
       for (int q = 0; q < U; q++) {
         const int bt = threadIdx.x + q * THREADS;
         const int j = bt & ((1 << hl) - 1);
-        e0[q] = lds0 + (uint32_t)((((bt >> hl) << (hl + 1)) + j) * (int)sizeof(Fr));
+        e0[q] = lds0 + (uint32_t)(((bt >> hl) << (hl + 1)) + j) * LY::STRIDE;
         tj[q] = (uint32_t)(j * (int)sizeof(Fr));
       }
-      const uint32_t span = (uint32_t)sizeof(Fr) << hl;
-      ntt_bfly<U>(inverse, e0, tj, span, stw, hl == 0);
+      const uint32_t span = LY::STRIDE << hl;
+      ntt_bfly<U, LY::HI>(inverse, e0, tj, span, stw, hl == 0);
       __syncthreads();
     }
     // the lazy range ends here: canonical out of the forward transform (and out of an inverse one that is scaled here)
-    if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(sh[i], sc); }
-    else if (!inverse) { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fr_canonical(sh[i]); }
-    else { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = sh[i]; }
+    if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(lds_get(smem, LY::STRIDE, LY::HI, i), sc); }
+    else if (!inverse) { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fr_canonical(lds_get(smem, LY::STRIDE, LY::HI, i)); }
+    else { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = lds_get(smem, LY::STRIDE, LY::HI, i); }
   } else {
+    if (mul) { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = fp_mul(d[base + i], mul[base + i]); }
+    else { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = d[base + i]; }
+    __syncthreads();
     for (int k = 0; k < tile_log; k++) {
       const int hl = inverse ? k : tile_log - 1 - k;
       const int s = log2n - 1 - hl;
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_local4(Fr* __restrict__ d, const
                                                       int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
   ntt_local_body<4>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
 }
-__global__ __launch_bounds__(512, 2) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
+__global__ __launch_bounds__(512, 4) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
                                                        int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
   ntt_local_body<2>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
 }

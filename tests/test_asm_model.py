@@ -423,35 +423,39 @@ def test_committed_header_is_generated():
 
 
 # ---- the NTT butterflies ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("U", [4, 2])
+@pytest.mark.parametrize("U,hi", [(4, 16), (2, 16), (2, 16384), (2, 32768)])
 @pytest.mark.parametrize("inverse,unit", [(False, False), (True, False), (False, True)])
-def test_ntt_butterfly_model(inverse, unit, U):
+def test_ntt_butterfly_model(inverse, unit, U, hi):
     """four butterflies of one stage out of LDS: operands anywhere in the lazy range [0, 2r) (edge values included), twiddles
     canonical; results congruent to the radix-2 butterfly, again below 2r, written where the operands came from; no operand is
-    read before the wait that covers its load, no carry inside the hazard window, no store's data rewritten under it"""
+    read before the wait that covers its load, no carry inside the hazard window, no store's data rewritten under it.
+    hi = 16: elements as 32-byte records; hi = 16384 / 32768 (round 5): the split layout -- lower halves at a 16-byte stride, upper
+    halves one plane further -- that removes the two-way bank conflict of the records"""
     N, p = 8, G.R
     Rm = 1 << 256
     Ri = pow(Rm, -1, p)
     rng = random.Random(77 + inverse)
     rg = G.ntt_regs(U)
-    body = G.ntt_bfly_text(inverse, unit, U)[:-1]             # without the return (unit: the stage whose twiddles are all 1)
+    body = G.ntt_bfly_text(inverse, unit, U, hi)[:-1]         # without the return (unit: the stage whose twiddles are all 1)
+    es = 32 if hi == 16 else 16                                # bytes between consecutive elements
+    addr = lambda e, k: e + 4 * k if k < 4 else e + hi + 4 * (k - 4)     # noqa: E731  (limb k of the element at e)
     assert sum(1 for l in body if l.startswith("s_nop")) <= 8
     edge = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p - 2, (1 << 255), (1 << 255) - 1]
     for it in range(12):
         lane = Lane()
-        span, twbase = 32 * rng.choice([1, 2, 64, 1024]), 0x7F0012340000
+        span, twbase = es * rng.choice([1, 2, 64, 1024 if hi == 16 else 256]), 0x7F0012340000
         lane.s[G.NTT_SPAN] = span
         lane.s64[G.NTT_TWB] = twbase
         e0s, tws = [], []
         vals = []
         for u in range(U):
-            e0 = 1024 * it + (32 * u if span >= 32 * U else 2 * span * u)        # the butterflies of a stage never share an element
+            e0 = (1024 if hi == 16 else 256) * it + (es * u if span >= es * U else 2 * span * u)        # the butterflies of a stage never share an element
             a = edge[(it + u) % len(edge)] if it < 6 else rng.randrange(2 * p)
             b = edge[(it * 3 + u + 1) % len(edge)] if it < 9 else rng.randrange(2 * p)
             w = Rm % p if unit else [0, 1, p - 1, Rm % p][(u + 2 * (U == 2)) % 4] if it == 0 else rng.randrange(p)
             t = 32 * rng.randrange(1 << 20)
             for k in range(N):
-                lane.lds[e0 + 4 * k], lane.lds[e0 + span + 4 * k], lane.glob[twbase + t + 4 * k] = limbs(a, N)[k], limbs(b, N)[k], limbs(w, N)[k]
+                lane.lds[addr(e0, k)], lane.lds[addr(e0 + span, k)], lane.glob[twbase + t + 4 * k] = limbs(a, N)[k], limbs(b, N)[k], limbs(w, N)[k]
             lane.v[f"v{rg['E0'] + u}"], lane.v[f"v{rg['TW'] + u}"] = e0, t
             e0s.append(e0); tws.append(t); vals.append((a, b, w))
         lane.run(body)
@@ -459,8 +463,8 @@ def test_ntt_butterfly_model(inverse, unit, U):
         lane.check_store_hold()
         assert not lane.loads_in_flight
         for u, (a, b, w) in enumerate(vals):
-            x = unlimbs([lane.lds[e0s[u] + 4 * k] for k in range(N)])
-            y = unlimbs([lane.lds[e0s[u] + span + 4 * k] for k in range(N)])
+            x = unlimbs([lane.lds[addr(e0s[u], k)] for k in range(N)])
+            y = unlimbs([lane.lds[addr(e0s[u] + span, k)] for k in range(N)])
             assert x < 2 * p and y < 2 * p, (it, u)
             if not inverse:
                 assert x % p == (a + b) % p and y % p == (a - b) * w * Ri % p, (it, u, hex(a), hex(b), hex(w))

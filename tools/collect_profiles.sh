@@ -17,6 +17,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt_only -o t -- py
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/ntt_pmc_$C -o t -- python3 tools/ntt_time.py > /dev/null 2> $OUT/ntt_pmc_$C.err
 done
+# LDS activity and bank conflicts (SURVEY 8d's counter list): the transforms and the sort passes
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --output-format csv -d $OUT/lds_ntt -o t -- python3 tools/ntt_time.py > /dev/null 2> $OUT/lds_ntt.err
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --output-format csv -d $OUT/lds_msm -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1 > /dev/null 2> $OUT/lds_msm.err
+{
+  echo "# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS -- python3 tools/ntt_time.py   (per launch, summed over the chip)"
+  python3 tools/pmc_lds_summary.py $(find $OUT/lds_ntt -name "*counter_collection.csv" | head -1) k_ntt_wide k_ntt_local
+  echo "# ... -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 3 --warmup 1"
+  python3 tools/pmc_lds_summary.py $(find $OUT/lds_msm -name "*counter_collection.csv" | head -1) k_part_scatter_staged k_part_sort k_part_hist k_border_place
+} > $OUT/lds_counters.txt
 # the opt-in single-pass form of the wide stages (SONIC_NTT_BIG=1; set in this shell's environment, not behind `--`): its traffic and durations
 export SONIC_NTT_BIG=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt_only_big -o t -- python3 tools/ntt_time.py > $OUT/ntt_only_big.txt 2> $OUT/ntt_only_big.err

@@ -581,8 +581,15 @@ NTT_NV = ntt_regs()["NV"]            # VGPRs v0 .. v175
 NTT_E0, NTT_TW, NTT_E1 = ntt_regs()["E0"], ntt_regs()["TW"], ntt_regs()["E1"]
 
 
-def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
-    """One stage's butterflies of a thread, values in the lazy range [0, 2r) (2r < 2^256), twiddles canonical:
+def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False, hi: int = 16):
+    """hi: byte offset of an element's upper four limbs from its lower four in LDS.  16 = the element as one 32-byte record.  With 32-byte
+    records a ds_read_b128 of a wave touches every OTHER 16-byte slot -- banks 0-3, 8-11, ... -- a two-way bank conflict on every LDS access
+    of the transform (rocprofv3: SQ_LDS_BANK_CONFLICT = 63-68 % of SQ_LDS_IDX_ACTIVE in k_ntt_wide / k_ntt_local, profiles/r05_lds_*).  The
+    split layout (round 5) keeps the lower halves of a block's elements in one plane (element i at byte 16 i) and the upper halves in a
+    second plane `hi` bytes further: consecutive lanes then read consecutive 16-byte slots.  `hi` is an immediate of the ds instructions
+    (<= 65535), so every plane distance has its own routines: 16384 for 1024-element blocks, 32768 for 2048-element tiles.
+
+    One stage's butterflies of a thread, values in the lazy range [0, 2r) (2r < 2^256), twiddles canonical:
         forward (DIF):  x = a + b,      y = (a - b) w        inverse (DIT):  t = b w,  x = a + t,  y = a - t
     a = LDS[e0], b = LDS[e0 + span], w = table[tw]; x and y go back where a and b came from.  A product of a value below 2r with a
     canonical twiddle is below r (2r / 2^256 + 1) < 1.91 r without any final subtraction, sums and differences are brought back
@@ -621,9 +628,9 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
     for u in range(U):
         pre.append(f"v_add_u32_e32 {v(NTT_E1 + u)}, {NTT_SPAN}, {v(NTT_E0 + u)}")
         pre.append(f"ds_read_b128 {v4(Ar(u, 0))}, {v(NTT_E0 + u)}")
-        pre.append(f"ds_read_b128 {v4(Ar(u, 4))}, {v(NTT_E0 + u)} offset:16")
+        pre.append(f"ds_read_b128 {v4(Ar(u, 4))}, {v(NTT_E0 + u)} offset:{hi}")
         pre.append(f"ds_read_b128 {v4(Br(u, 0))}, {v(NTT_E1 + u)}")
-        pre.append(f"ds_read_b128 {v4(Br(u, 4))}, {v(NTT_E1 + u)} offset:16")
+        pre.append(f"ds_read_b128 {v4(Br(u, 4))}, {v(NTT_E1 + u)} offset:{hi}")
         if not unit:
             pre.append(f"global_load_dwordx4 {v4(Wr(u, 0))}, {v(NTT_TW + u)}, {NTT_TWB}")
             pre.append(f"global_load_dwordx4 {v4(Wr(u, 4))}, {v(NTT_TW + u)}, {NTT_TWB} offset:16")
@@ -705,7 +712,7 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
 
     def store(addr, src):
         for h in (0, 4):
-            ins = emit(f"ds_write_b128 {v(addr)}, {v4(src(h))}" + (" offset:16" if h else ""), [v(addr)] + [v(src(h + k)) for k in range(4)], [])
+            ins = emit(f"ds_write_b128 {v(addr)}, {v4(src(h))}" + (f" offset:{hi}" if h else ""), [v(addr)] + [v(src(h + k)) for k in range(4)], [])
             ins.hold = 2          # its data registers must not be rewritten in the next two slots
 
     # Waits: the LDS reads all at once (a partial lgkmcnt would have to trust that nothing else is in flight on that counter), the
@@ -748,20 +755,22 @@ def ntt_bfly_program(inverse: bool, U: int = NTT_U, unit: bool = False):
     return pre, prog, post
 
 
-def ntt_bfly_text(inverse: bool, unit: bool = False, U: int = NTT_U):
-    pre, prog, post = ntt_bfly_program(inverse, U, unit=unit)
+def ntt_bfly_text(inverse: bool, unit: bool = False, U: int = NTT_U, hi: int = 16):
+    pre, prog, post = ntt_bfly_program(inverse, U, unit=unit, hi=hi)
     return pre + schedule(prog) + post + ["s_setpc_b64 s[30:31]"]
 
 
-def ntt_bfly_cxx(inverse: bool, unit: bool = False, U: int = NTT_U) -> str:
-    name = f"sonic_ntt_bfly{U}_" + ("unit" if unit else "inv" if inverse else "fwd")
-    body = ntt_bfly_text(inverse, unit, U)
+def ntt_bfly_cxx(inverse: bool, unit: bool = False, U: int = NTT_U, hi: int = 16) -> str:
+    assert hi == 16 or (hi & (hi - 1)) == 0 and 16 < hi <= 32768
+    name = f"sonic_ntt_bfly{U}" + ("" if hi == 16 else f"s{hi.bit_length() - 1}") + "_" + ("unit" if unit else "inv" if inverse else "fwd")
+    body = ntt_bfly_text(inverse, unit, U, hi)
     rg = ntt_regs(U)
     NTT_E0, NTT_TW, NTT_NV = rg["E0"], rg["TW"], rg["NV"]
     mads = sum(1 for l in body if l.startswith("v_mad_u64"))
     nops = sum(1 for l in body if l.startswith("s_nop"))
     what = "x = a + b, y = a - b: the stage whose twiddles are all 1" if unit else "t = b w, x = a + t, y = a - t" if inverse else "x = a + b, y = (a - b) w"
-    lines = routine_section(name, body, f"// {name}: {U} radix-2 butterflies ({what}) on Fr values in LDS, lazy range [0, 2r): {len(body)} instructions "
+    layout = "32-byte records" if hi == 16 else f"split layout: lower halves at 16-byte stride, upper halves {hi} bytes further"
+    lines = routine_section(name, body, f"// {name}: {U} radix-2 butterflies ({what}) on Fr values in LDS ({layout}), lazy range [0, 2r): {len(body)} instructions "
                                         f"({mads} v_mad_u64_u32, {nops} s_nop), VGPRs v0..v{NTT_NV - 1}")
     args = ", ".join([f"uint32_t e{u}" for u in range(U)] + ([] if unit else [f"uint32_t t{u}" for u in range(U)]) + ["uint32_t span"] + ([] if unit else ["const void* twiddles"]))
     lines.append("// e_u: LDS byte address of butterfly u's first element (the second one is `span` bytes further)" + ("" if unit else ", t_u: byte offset of its twiddle from `twiddles`"))
@@ -831,6 +840,19 @@ def render() -> str:
            ntt_bfly_cxx(True, U=2),
            "",
            ntt_bfly_cxx(False, unit=True, U=2),
+           "",
+           "// the same two-butterfly routines over the split LDS layout (no two-way bank conflict): 1024-element blocks / 2048-element tiles",
+           ntt_bfly_cxx(False, U=2, hi=16384),
+           "",
+           ntt_bfly_cxx(True, U=2, hi=16384),
+           "",
+           ntt_bfly_cxx(False, unit=True, U=2, hi=16384),
+           "",
+           ntt_bfly_cxx(False, U=2, hi=32768),
+           "",
+           ntt_bfly_cxx(True, U=2, hi=32768),
+           "",
+           ntt_bfly_cxx(False, unit=True, U=2, hi=32768),
            "}  // namespace sonic",
            "#endif", ""]
     return "\n".join(out)
