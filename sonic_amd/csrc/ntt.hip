@@ -206,7 +206,11 @@ __global__ __launch_bounds__(1024, 1) void k_ntt_wide_big(Fr* __restrict__ d, co
 
 // all stages with span <= tile, fused in LDS.  tile_log = min(log2n, TILE_LOG).  Full tiles (2048 elements: every transform the prover
 // runs) go through the generated butterflies, U per thread and stage (1024 / U threads); smaller transforms through the plain C++ ones.
-template <int U>
+// FULL: only full tiles (the generated butterflies); !FULL: only the small transforms (plain C++ butterflies over 32-byte records) -- two
+// kernels, so that the hot one does not carry the other's code and registers (with both in one kernel and the stage loop unrolled the split
+// layout pushed k_ntt_local past 128 VGPRs: three waves per SIMD and 14 % slower, or ten spilled registers and 5 % more HBM traffic under a
+// four-wave bound; now 127 VGPRs and no scratch)
+template <int U, bool FULL>
 __device__ __forceinline__ void ntt_local_body(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
                                                int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -221,10 +225,16 @@ __device__ __forceinline__ void ntt_local_body(Fr* __restrict__ d, const Fr* __r
   // forward: stages s = log2n - tile_log .. log2n - 1 (half = tile/2 .. 1)
   // inverse: the same stages in reverse order (half = 1 .. tile/2)
   // (mul: the pointwise product of two transforms folded into the inverse transform's first load)
-  if (tile_log == TILE_LOG) {
-    if (mul) { for (int i = threadIdx.x; i < (1 << TILE_LOG); i += THREADS) lds_put(smem, LY::STRIDE, LY::HI, i, fp_mul(d[base + i], mul[base + i])); }
-    else { for (int i = threadIdx.x; i < (1 << TILE_LOG); i += THREADS) lds_put(smem, LY::STRIDE, LY::HI, i, d[base + i]); }
+  if constexpr (FULL) {
+    if (mul) {
+      _Pragma("unroll 1")
+      for (int i = threadIdx.x; i < (1 << TILE_LOG); i += THREADS) lds_put(smem, LY::STRIDE, LY::HI, i, fp_mul(d[base + i], mul[base + i])); }
+    else {
+      _Pragma("unroll 1")
+      for (int i = threadIdx.x; i < (1 << TILE_LOG); i += THREADS) lds_put(smem, LY::STRIDE, LY::HI, i, d[base + i]); }
     __syncthreads();
+    // (not unrolled: the compiler otherwise computes the eleven stages' addresses up front and keeps -- or spills -- them across the routine calls)
+#pragma unroll 1
     for (int k = 0; k < TILE_LOG; k++) {
       const int hl = inverse ? k : TILE_LOG - 1 - k;       // log2(half)
       const int s = log2n - 1 - hl;
@@ -242,9 +252,9 @@ __device__ __forceinline__ void ntt_local_body(Fr* __restrict__ d, const Fr* __r
       __syncthreads();
     }
     // the lazy range ends here: canonical out of the forward transform (and out of an inverse one that is scaled here)
-    if (scale) { Fr sc = *scale; for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(lds_get(smem, LY::STRIDE, LY::HI, i), sc); }
-    else if (!inverse) { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fr_canonical(lds_get(smem, LY::STRIDE, LY::HI, i)); }
-    else { for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = lds_get(smem, LY::STRIDE, LY::HI, i); }
+    if (scale) { Fr sc = *scale; _Pragma("unroll 1") for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fp_mul(lds_get(smem, LY::STRIDE, LY::HI, i), sc); }
+    else if (!inverse) { _Pragma("unroll 1") for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = fr_canonical(lds_get(smem, LY::STRIDE, LY::HI, i)); }
+    else { _Pragma("unroll 1") for (int i = threadIdx.x; i < tile; i += THREADS) d[base + i] = lds_get(smem, LY::STRIDE, LY::HI, i); }
   } else {
     if (mul) { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = fp_mul(d[base + i], mul[base + i]); }
     else { for (int i = threadIdx.x; i < tile; i += THREADS) sh[i] = d[base + i]; }
@@ -270,11 +280,16 @@ __device__ __forceinline__ void ntt_local_body(Fr* __restrict__ d, const Fr* __r
 }
 __global__ __launch_bounds__(256, 2) void k_ntt_local4(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
                                                       int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
-  ntt_local_body<4>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
+  ntt_local_body<4, true>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
 }
 __global__ __launch_bounds__(512, 4) void k_ntt_local(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
                                                        int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
-  ntt_local_body<2>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
+  ntt_local_body<2, true>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
+}
+// transforms below 2^11 points (one tile of 2^tile_log elements per workgroup, plain C++ butterflies)
+__global__ __launch_bounds__(512) void k_ntt_small(Fr* __restrict__ d, const Fr* __restrict__ tw, int log2n, int tile_log, int tw_shift,
+                                                   int inverse, const Fr* __restrict__ scale, const Fr* __restrict__ mul) {
+  ntt_local_body<2, false>(d, tw, log2n, tile_log, tw_shift, inverse, scale, mul);
 }
 
 __global__ __launch_bounds__(256) void k_fr_scale(Fr* __restrict__ a, long n, const Fr* __restrict__ s) {
@@ -316,7 +331,8 @@ void NttTables::ensure(hipStream_t st, int need) {
 // at M = 2^21, 3.20 against 3.48 at 2^23) or 2 (four butterflies per thread: k_ntt_wide4 / k_ntt_local4)
 static const int NTT_WAVES = getenv("SONIC_NTT_WAVES") ? atoi(getenv("SONIC_NTT_WAVES")) : 4;
 static void local_launch(hipStream_t st, int grid, size_t lds, Fr* d, const Fr* table, int log2n, int tile_log, int tw_shift, int inverse, const Fr* scale, const Fr* mul) {
-  if (NTT_WAVES == 4) LAUNCH(k_ntt_local, grid, 512, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
+  if (tile_log < TILE_LOG) LAUNCH(k_ntt_small, grid, 512, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
+  else if (NTT_WAVES == 4) LAUNCH(k_ntt_local, grid, 512, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
   else LAUNCH(k_ntt_local4, grid, 256, lds, st, d, table, log2n, tile_log, tw_shift, inverse, scale, mul);
 }
 static void ntt_run(hipStream_t st, const NttTables& tw, Fr* d, int log2n, bool inverse, const Fr* mul = nullptr) {
