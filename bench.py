@@ -902,7 +902,7 @@ def main(argv=None):
 
 
 # ======================================================================================================================================
-def protocol_shaped_msm(sonic_amd, L, _lib, x, alpha, K, W):
+def protocol_shaped_msm(sonic_amd, L, _lib, x, alpha, K, W, which=("W_t_quotient", "s_of_X_y_coefficients"), uniform=True):
     """the stand-alone MSM again with the scalars the protocol really feeds it -- the quotient w = (t(X,y) - t(z,y)) / (X - z)
     of W_t = openPoly(t(X,y), z) (Protocol.hs:81) at n = 2^17: 7n + 8 = 917 512 terms over the stated d = 2^20 SRS -- and with the
     coefficients of s(X,y) (Signature.hs:42, unprepared S_j: 3n + 1 terms of which 2n are copies of two values and n are zero-free runs),
@@ -920,6 +920,8 @@ def protocol_shaped_msm(sonic_amd, L, _lib, x, alpha, K, W):
     # W_t: plain basis, exponents [-4n-8, 3n-1] (CommitmentScheme.hs:45-47).  S_j = commitPoly(d, s(X,y_j)): alpha basis, shift d - max = 0,
     # exponents [-n, 2n]; the coefficient at exponent 0 is zero and meets the omitted g^alpha (SRS.hs:38)
     for name, scal, basis, e0 in (("W_t_quotient", wt, 0, -4 * n - 8), ("s_of_X_y_coefficients", sy, 1, -n)):
+        if name not in which:
+            continue
         N = scal.shape[0]
         dptr = C.c_void_p()
         _lib.check(L.sonic_dev_alloc(32 * N, C.byref(dptr)))
@@ -935,19 +937,21 @@ def protocol_shaped_msm(sonic_amd, L, _lib, x, alpha, K, W):
         uniq = int(np.unique(np.ascontiguousarray(scal).view(np.dtype((np.void, 32)))).shape[0])
         zeros = int((~scal.any(axis=1)).sum())
         # the same number of uniform scalars over the same slice, for comparison
-        uni = np.random.default_rng(9).integers(0, 256, size=(N, 32), dtype=np.uint8)
-        uni[:, 31] &= 0x3f
-        _lib.check(L.sonic_dev_upload(dptr, uni.ctypes.data, 32 * N))
-        for _ in range(W):
-            _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
-        L.sonic_device_sync()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
-        dtu = time.perf_counter() - t0
+        dtu = None
+        if uniform:
+            uni = np.random.default_rng(9).integers(0, 256, size=(N, 32), dtype=np.uint8)
+            uni[:, 31] &= 0x3f
+            _lib.check(L.sonic_dev_upload(dptr, uni.ctypes.data, 32 * N))
+            for _ in range(W):
+                _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
+            L.sonic_device_sync()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                _lib.check(L.sonic_msm_g1_srs_dev(srs._h, basis, e0, dptr, N, res))
+            dtu = time.perf_counter() - t0
         L.sonic_dev_free(dptr)
         out[name] = {"N": N, "ms_per_msm": round(1e3 * dt / K, 3), "scalar_muls_per_s": round(N * K / dt, 1), "distinct_scalars": uniq, "zero_scalars": zeros,
-                     "uniform_scalars_same_slice_ms": round(1e3 * dtu / K, 3)}
+                     "uniform_scalars_same_slice_ms": round(1e3 * dtu / K, 3) if dtu is not None else None}
     srs.close()
     return out
 

@@ -279,10 +279,12 @@ sonic_srs* srs_alloc(int64_t d) {
   const size_t n = (size_t)(2 * d + 1);
   int lg = 0;
   while ((2L << lg) <= d) lg++;                 // floor(log2 d)
-  // measured (prove at n = d/8): up to d = 2^20 the MSMs (0.4 d .. 0.9 d terms) run best with ~2^16 bucket walks
-  // (c = 17: one to two waves per SIMD, short reduction); from d = 2^21 the two windows saved by c = 20 win.
-  int c = lg >= 21 ? 20 : (lg > 17 ? 17 : lg);
+  // measured (prove at n = d/8, profiles/r05_table_c_ab.txt): up to d = 2^19 the MSMs (0.4 d .. 0.9 d terms) run best with ~2^16
+  // bucket walks (c = 17: one to two waves per SIMD, short reduction); from d = 2^20 the two windows saved by c = 20 win (prove at
+  // n = 2^17 20.2 -> 19.2 ms; a stand-alone MSM of 0.9 d terms 5.7 -> 2.9 ms: 2^16 walks of 210 entries are one wave per SIMD).
+  int c = lg >= 20 ? 20 : (lg > 17 ? 17 : lg);
   if (c < 9) c = 9;
+  if (const char* tc = getenv("SONIC_MSM_TABLE_C")) { const int v = atoi(tc); if (v >= 9 && v <= 22) c = v; }
   // W windows of even width (msm.hpp): the widest is ceil(255 / W) <= c
   int W = (255 + c - 1) / c;
   const int c_full = (255 + W - 1) / W;

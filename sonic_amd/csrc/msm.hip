@@ -13,8 +13,8 @@
 //   4. k_bucket_accum  one thread per bucket walks its entries: affine point gathered from HBM
 //                      (96 B contiguous), XYZZ mixed addition.  Buckets far above the mean (the
 //                      protocol produces them: s(X,y) has n equal coefficients when a weight row
-//                      is all ones, test/Test/Reference.hs:143-145) are split into 16384-entry
-//                      items, each reduced by a whole workgroup through LDS (k_heavy_accum)
+//                      is all ones, test/Test/Reference.hs:143-145) are only recorded here; their entries,
+//                      end to end, are cut into equal stretches, one per workgroup (k_heavy_accum, k_heavy_finish)
 //   5. k_bucket_segments / k_group_sum / k_window_sum   sum_b b*B_b per bucket set by running sums over K-bucket
 //                      segments, then LDS trees
 //   6. host tail       Horner over the W window sums + normalisation to the canonical affine
@@ -45,22 +45,33 @@ constexpr uint32_t PASS1_GRID = 1024;      // workgroups of pass 1 (grid-stride 
 // workgroup each; a batched group of three or four would otherwise queue 6144-8192 short workgroups behind the wave slots that other
 // groups' accumulations hold
 constexpr uint32_t PART_SORT_GRID = 2048;
+#ifndef SONIC_PART_SORT_THREADS
+#define SONIC_PART_SORT_THREADS 1024
+#endif
+constexpr int PART_SORT_THREADS = SONIC_PART_SORT_THREADS;   // lanes of a pass-2 workgroup (its LDS stage allows one workgroup per CU)
 static_assert(PART_LOW_BITS >= 8 && PART_LOW_BITS <= 10, "k_part_sort scans 256 x {1, 2, 4} counters");
 
 static int g_window_override = 0;
 int msm_window_override() { return g_window_override; }
 void msm_set_window_override(int c) { g_window_override = c; }
 
-static constexpr uint32_t HEAVY_SEG = 16384;  // entries per heavy work item (256 threads x 64)
+// Heavy buckets (the unprepared S_j of a circuit whose constraint rows repeat a value: 2n of its 3n + 1 scalars are two values, so two
+// buckets per window hold n entries each -- two thirds of the MSM's additions).  k_bucket_accum only records them (HeavyRec); their
+// entries, laid end to end, are then cut into HEAVY_GRID equal stretches, one per workgroup of HEAVY_THREADS lanes (k_heavy_accum: one
+// workgroup per CU, two waves per SIMD -- the occupancy the registers allow anyway), so that every lane of the chip chains the same
+// number of additions whatever the buckets' sizes are; a stretch that crosses a bucket border yields one partial sum per bucket, and
+// k_heavy_finish adds a bucket's partials.  One addition on a wave takes 10-20 us: the trees at the end of a stretch run on quads
+// (g1_quad.hpp), four lanes per addition.
 // Usually there is nothing heavy and the launch only has to notice that; on a chip full of other MSMs' accumulation every
 // workgroup still waits for a free slot (1024 idle workgroups delayed the chain behind them by 1.4-3.4 ms in prove()).
-static constexpr int HEAVY_GRID = 128;
+static constexpr int HEAVY_THREADS = 512;
+static constexpr int HEAVY_GRID = 256;
+static constexpr uint32_t HEAVY_MIN_STRETCH = 4 * HEAVY_THREADS;
 
-// header of a chain, cleared by one memset at its start: the heavy-bucket counters and the size-class histogram / cursors of the
+// header of a chain, cleared by one memset at its start: the heavy-bucket counter and the size-class histogram / cursors of the
 // bucket ordering (k_part_sort, k_border_place)
-struct HeavyMeta { uint32_t n_items, n_heavy; uint32_t class_hist[256]; uint32_t class_cursor[256]; };
-struct HeavyRec { uint32_t bucket, base, nseg; };
-struct HeavyItem { uint32_t bucket, seg; };
+struct HeavyMeta { uint32_t pad, n_heavy; uint32_t class_hist[256]; uint32_t class_cursor[256]; };
+struct HeavyRec { uint32_t bucket, cnt, base, npart; };     // bucket, cnt: k_bucket_accum; first partial and their number: k_heavy_accum
 
 static void plan_finish(MsmPlan& p, long n) {
   p.NB = 1 << (p.c - 1);
@@ -129,10 +140,8 @@ void MsmWorkspace::reserve(long n, const MsmPlan& pl, int k) {
   scan_tmp.ensure((part_hn / 2048 + 4) * 4);
   order.ensure((M + 1) * 4);
   size_t max_heavy = NW / pl.heavy_threshold + 1;
-  size_t max_items = NW / HEAVY_SEG + max_heavy + 1;
   heavy_meta.ensure(sizeof(HeavyMeta) + max_heavy * sizeof(HeavyRec));
-  heavy_items.ensure(max_items * sizeof(HeavyItem));
-  heavy_partial.ensure(max_items * sizeof(G1XYZZ));
+  heavy_partial.ensure((max_heavy + HEAVY_GRID + 1) * sizeof(G1XYZZ));      // a stretch border inside a bucket adds one partial
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(256) void k_part_scatter_staged(const MsmBatchDev b
 // stage_cap > 0 (round 4): a partition of at most stage_cap entries is placed in LDS first and copied out in order -- whole lines
 // instead of one 4-byte store per entry into a 26-KB window (323 MB written for 54 MB of entries before); larger partitions (the
 // protocol's heavy buckets, or MSMs much larger than the plan was sized for) take the direct path
-__global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, const uint2* __restrict__ part,
+__global__ __launch_bounds__(PART_SORT_THREADS) void k_part_sort(const MsmBatchDev batch, const uint2* __restrict__ part,
                                                    const uint32_t* __restrict__ base, const uint32_t* __restrict__ total, size_t hn, int P,
                                                    uint32_t jobstride, uint32_t* __restrict__ off, uint32_t* __restrict__ entries, uint32_t* __restrict__ class_hist,
                                                    uint32_t stage_cap) {
@@ -378,7 +387,8 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
   __shared__ uint32_t chist[256];
   const uint32_t M = (uint32_t)batch.k * jobstride;
   const uint32_t nparts = (uint32_t)batch.k * (uint32_t)P;
-  chist[threadIdx.x] = 0;
+  constexpr uint32_t T = PART_SORT_THREADS;
+  if (threadIdx.x < 256) chist[threadIdx.x] = 0;
   for (uint32_t pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
   const int job = pi / P, t = pi % P;
   const uint32_t nblk = batch.tile0[job + 1] - batch.tile0[job];
@@ -386,25 +396,26 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
   const uint32_t beg = idx < hn ? base[idx] : *total;
   const uint32_t end = idx_next < hn ? base[idx_next] : *total;
   const bool last_block = pi == nparts - 1;
-  for (int t = threadIdx.x; t < (1 << PART_LOW_BITS); t += 256) cnt[t] = 0;
+  for (int t = threadIdx.x; t < (1 << PART_LOW_BITS); t += T) cnt[t] = 0;
   __syncthreads();
   // every lane of a wave must reach lds_take: round the trip count up to the wave
-  const uint32_t span = end - beg, trips = (span + 255) / 256;
+  const uint32_t span = end - beg, trips = (span + T - 1) / T;
   constexpr int B = 8;                       // loads in flight per lane (the walk is latency-bound otherwise)
   for (uint32_t k0 = 0; k0 < trips; k0 += B) {
     uint32_t lo[B];
 #pragma unroll
-    for (int j = 0; j < B; j++) { const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x; lo[j] = e < end ? part[e].x : 0xffffffffu; }
+    for (int j = 0; j < B; j++) { const uint32_t e = beg + (k0 + j) * T + threadIdx.x; lo[j] = e < end ? part[e].x : 0xffffffffu; }
 #pragma unroll
     for (int j = 0; j < B; j++) if (k0 + j < trips) lds_take(cnt, lo[j] != 0xffffffffu, lo[j] & ((1u << PART_LOW_BITS) - 1));
   }
   __syncthreads();
   // exclusive scan of the counters: CPT per thread + a 256-wide scan
   constexpr int CPT = (1 << PART_LOW_BITS) / 256;
+  const bool scans = threadIdx.x < 256;        // the first 256 threads scan; the others only meet them at the barriers
   uint32_t v[CPT], ssum = 0;
-  for (int k = 0; k < CPT; k++) { v[k] = cnt[threadIdx.x * CPT + k]; ssum += v[k]; }
+  for (int k = 0; k < CPT; k++) { v[k] = scans ? cnt[threadIdx.x * CPT + k] : 0u; ssum += v[k]; }
   uint32_t ex = block_exclusive_scan_256(ssum, sc4, nullptr);
-  for (int k = 0; k < CPT; k++) {
+  for (int k = 0; scans && k < CPT; k++) {
     const uint32_t local = (uint32_t)t * (1u << PART_LOW_BITS) + threadIdx.x * CPT + k;
     cnt[threadIdx.x * CPT + k] = ex;               // becomes the running cursor
     if (local < jobstride) { off[(uint32_t)job * jobstride + local] = beg + ex; atomicAdd(&chist[size_class(v[k])], 1u); }
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
     uint32_t lo[B], pay[B];
 #pragma unroll
     for (int j = 0; j < B; j++) {
-      const uint32_t e = beg + (k0 + j) * 256 + threadIdx.x;
+      const uint32_t e = beg + (k0 + j) * T + threadIdx.x;
       const bool live = e < end;
       const uint2 rec = live ? part[e] : make_uint2(0xffffffffu, 0u);
       lo[j] = rec.x;
@@ -432,26 +443,28 @@ __global__ __launch_bounds__(256) void k_part_sort(const MsmBatchDev batch, cons
   }
   __syncthreads();
   if (span <= stage_cap) {
-    for (uint32_t i = threadIdx.x; i < span; i += 256) entries[beg + i] = stage[i];
+    for (uint32_t i = threadIdx.x; i < span; i += T) entries[beg + i] = stage[i];
     __syncthreads();
   }
   }
-  const uint32_t c = chist[threadIdx.x];
+  const uint32_t c = threadIdx.x < 256 ? chist[threadIdx.x] : 0u;
   if (c) atomicAdd(&class_hist[threadIdx.x], c);
 }
 
 // ---- exclusive scan of u32 (three small kernels; tile = 2048) -------------------------------
+// (threads 256 and up of a wider workgroup take part in the barriers only)
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sh, uint32_t* total) {
   const int t = threadIdx.x;
-  sh[t] = v;
+  const bool in = t < 256;
+  if (in) sh[t] = v;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
-    uint32_t x = t >= o ? sh[t - o] : 0;
+    uint32_t x = in && t >= o ? sh[t - o] : 0;
     __syncthreads();
-    sh[t] += x;
+    if (in) sh[t] += x;
     __syncthreads();
   }
-  uint32_t incl = sh[t];
+  uint32_t incl = in ? sh[t] : 0u;
   if (total) *total = sh[255];
   __syncthreads();
   return incl - v;
@@ -533,8 +546,7 @@ __device__ __forceinline__ size_t entry_point(uint32_t e, long stride) {
 __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
                                                       const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
                                                       long stride, uint32_t nbuckets, uint32_t heavy_t,
-                                                      G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs,
-                                                      HeavyItem* items) {
+                                                      G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nbuckets) return;
   const uint32_t b = order[t];
@@ -542,11 +554,9 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
   const uint32_t cnt = end - beg;
   const PointArray pts{batch.points[b / jobstride], batch.pt_stride};
   if (cnt > heavy_t) {
-    uint32_t ns = (cnt + HEAVY_SEG - 1) / HEAVY_SEG;
-    uint32_t base = atomicAdd(&hm->n_items, ns);
-    uint32_t h = atomicAdd(&hm->n_heavy, 1u);
-    hrecs[h] = HeavyRec{b, base, ns};
-    for (uint32_t k = 0; k < ns; k++) items[base + k] = HeavyItem{b, k};
+    const uint32_t h = atomicAdd(&hm->n_heavy, 1u);
+    hrecs[h].bucket = b;
+    hrecs[h].cnt = cnt;
     return;
   }
   // Two-deep software pipeline: the index of entry e+2 and the point of entry e+1 are in flight while
@@ -579,64 +589,130 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
   buckets[b] = acc;
 }
 
-__global__ __launch_bounds__(256, 2) void k_heavy_accum(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
+// exclusive scan over the HEAVY_THREADS lanes of a workgroup (wave shuffles + one word per wave in LDS); *total = the sum
+__device__ __forceinline__ uint32_t heavy_scan(uint32_t v, uint32_t* wsum, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t before = 0, tot = 0;
+  for (int i = 0; i < HEAVY_THREADS / 64; i++) { const uint32_t w = wsum[i]; if (i < wv) before += w; tot += w; }
+  __syncthreads();
+  *total = tot;
+  return before + incl - v;
+}
+
+struct HeavyWork { uint32_t bucket, skip, len, slot; };     // entries [off[bucket] + skip, + len) -> partial[slot]
+
+__global__ __launch_bounds__(HEAVY_THREADS, 1) void k_heavy_accum(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
                                                      const uint32_t* __restrict__ off, long stride, const HeavyMeta* hm,
-                                                     const HeavyItem* items, G1XYZZ* __restrict__ partial) {
-  __shared__ G1XYZZ sh[256];
-  const uint32_t n_items = hm->n_items;
-  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const HeavyItem item = items[it];
-    const PointArray pts{batch.points[item.bucket / jobstride], batch.pt_stride};
-    const uint32_t beg = off[item.bucket] + item.seg * HEAVY_SEG;
-    uint32_t end = beg + HEAVY_SEG;
-    const uint32_t bend = off[item.bucket + 1];
-    if (end > bend) end = bend;
-    G1XYZZ acc = G1XYZZ::inf();
-    if (beg + threadIdx.x < end) {
-      const uint32_t last = beg + threadIdx.x + ((end - 1 - beg - threadIdx.x) / 256) * 256;   // this lane's last entry
-      uint32_t e = beg + threadIdx.x;
-      const uint32_t e_first = entries[e];
-      G1Affine p_first = pts[entry_point(e_first, stride)];
-      if (e_first >> 31) p_first.y = fp_neg(p_first.y);
-      acc = G1XYZZ::from_affine(p_first);                       // as in k_bucket_accum: the first entry is a copy, not an addition
-      e += 256;
-      uint32_t e_cur = entries[e <= last ? e : last];
-      uint32_t e_nxt = entries[e + 256 <= last ? e + 256 : last];
-      G1Affine p_cur = pts[entry_point(e_cur, stride)];
-      for (; e < end; e += 256) {
-        const uint32_t e_nn = entries[e + 512 <= last ? e + 512 : last];
-        const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
-        acc = g1_add_mixed_walk(acc, p_cur, e_cur >> 31);
-        p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
-      }
-    }
-    sh[threadIdx.x] = acc;
+                                                     HeavyRec* hrecs, G1XYZZ* __restrict__ partial) {
+  constexpr int HALF = HEAVY_THREADS / 2;
+  __shared__ G1XYZZ sh[HALF];                // 48 KB: the upper half of the workgroup hands its sums to the lower half first
+  __shared__ HeavyWork work[HEAVY_THREADS];
+  __shared__ uint32_t wsum[HEAVY_THREADS / 64];
+  __shared__ uint32_t n_work;
+  const uint32_t nh = hm->n_heavy;
+  if (nh == 0) return;
+  // how many entries there are, hence how long a stretch is
+  uint32_t mine = 0, total;
+  for (uint32_t r = threadIdx.x; r < nh; r += HEAVY_THREADS) mine += hrecs[r].cnt;
+  heavy_scan(mine, wsum, &total);
+  uint32_t stretch = (total + gridDim.x - 1) / gridDim.x;
+  if (stretch < HEAVY_MIN_STRETCH) stretch = HEAVY_MIN_STRETCH;
+  const uint64_t lo = (uint64_t)blockIdx.x * stretch, hi = lo + stretch;     // this workgroup's stretch of the concatenated entries
+  if (lo >= total) return;
+  if (threadIdx.x == 0) n_work = 0;
+  uint32_t carry_cnt = 0, carry_np = 0;
+  for (uint32_t r0 = 0; r0 < nh && carry_cnt < hi; r0 += HEAVY_THREADS) {
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-      if ((int)threadIdx.x < s) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    const uint32_t r = r0 + threadIdx.x;
+    const HeavyRec rec = r < nh ? hrecs[r] : HeavyRec{0u, 0u, 0u, 0u};
+    uint32_t batch_cnt, batch_np;
+    const uint64_t start = (uint64_t)carry_cnt + heavy_scan(rec.cnt, wsum, &batch_cnt), end = start + rec.cnt;
+    const uint32_t first_g = (uint32_t)(start / stretch), last_g = rec.cnt ? (uint32_t)((end - 1) / stretch) : first_g;
+    const uint32_t np = rec.cnt ? last_g - first_g + 1 : 0u;
+    const uint32_t base = carry_np + heavy_scan(np, wsum, &batch_np);
+    if (rec.cnt && blockIdx.x >= first_g && blockIdx.x <= last_g) {
+      const uint64_t a = start > lo ? start : lo, b = end < hi ? end : hi;
+      work[atomicAdd(&n_work, 1u)] = HeavyWork{rec.bucket, (uint32_t)(a - start), (uint32_t)(b - a), base + (blockIdx.x - first_g)};
+      if (blockIdx.x == first_g) { hrecs[r].base = base; hrecs[r].npart = np; }
+    }
+    carry_cnt += batch_cnt;
+    carry_np += batch_np;
+    __syncthreads();
+    const uint32_t nw = n_work;
+    for (uint32_t wi = 0; wi < nw; wi++) {
+      const HeavyWork wk = work[wi];
+      const PointArray pts{batch.points[wk.bucket / jobstride], batch.pt_stride};
+      const uint32_t beg = off[wk.bucket] + wk.skip, end_e = beg + wk.len;
+      G1XYZZ acc = G1XYZZ::inf();
+      if (beg + threadIdx.x < end_e) {
+        const uint32_t last = beg + threadIdx.x + ((end_e - 1 - beg - threadIdx.x) / HEAVY_THREADS) * HEAVY_THREADS;   // this lane's last entry
+        uint32_t e = beg + threadIdx.x;
+        const uint32_t e_first = entries[e];
+        G1Affine p_first = pts[entry_point(e_first, stride)];
+        if (e_first >> 31) p_first.y = fp_neg(p_first.y);
+        acc = G1XYZZ::from_affine(p_first);                       // as in k_bucket_accum: the first entry is a copy, not an addition
+        e += HEAVY_THREADS;
+        uint32_t e_cur = entries[e <= last ? e : last];
+        uint32_t e_nxt = entries[e + HEAVY_THREADS <= last ? e + HEAVY_THREADS : last];
+        G1Affine p_cur = pts[entry_point(e_cur, stride)];
+        for (; e < end_e; e += HEAVY_THREADS) {
+          const uint32_t e_nn = entries[e + 2 * HEAVY_THREADS <= last ? e + 2 * HEAVY_THREADS : last];
+          const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
+          acc = g1_add_mixed_walk(acc, p_cur, e_cur >> 31);
+          p_cur = p_nxt; e_cur = e_nxt; e_nxt = e_nn;
+        }
+      }
+      // 512 sums -> 1: one whole addition per lane of the lower half, then quads
+      if ((int)threadIdx.x >= HALF) sh[threadIdx.x - HALF] = acc;
+      __syncthreads();
+      if ((int)threadIdx.x < HALF) acc = g1_add(acc, sh[threadIdx.x]);
+      __syncthreads();
+      if ((int)threadIdx.x < HALF) sh[threadIdx.x] = acc;
+      __syncthreads();
+      const int cr = threadIdx.x & 3, q = threadIdx.x >> 2;
+      for (int sp = HALF / 2; sp >= 1; sp >>= 1) {
+        if (q < sp) {
+          Fq* pa = reinterpret_cast<Fq*>(&sh[q]) + cr;
+          const Fq* pb = reinterpret_cast<const Fq*>(&sh[q + sp]) + cr;
+          *pa = g1q_add(*pa, *pb, cr);
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x < 4) reinterpret_cast<Fq*>(&partial[wk.slot])[threadIdx.x] = reinterpret_cast<const Fq*>(&sh[0])[threadIdx.x];
       __syncthreads();
     }
-    if (threadIdx.x == 0) partial[it] = sh[0];
-    __syncthreads();
+    if (threadIdx.x == 0) n_work = 0;
   }
 }
 
-// one 64-lane workgroup per heavy bucket: lanes stride over the bucket's partials, LDS tree
+// one 64-lane workgroup per heavy bucket: its 16 quads stride over the bucket's partials, then a tree of quads through LDS
 __global__ __launch_bounds__(64, 2) void k_heavy_finish(const HeavyMeta* hm, const HeavyRec* hrecs, const G1XYZZ* __restrict__ partial,
                                                      G1XYZZ* __restrict__ buckets) {
-  __shared__ G1XYZZ sh[64];
+  __shared__ G1XYZZ sh[16];
   const uint32_t n_heavy = hm->n_heavy;
+  const int cr = threadIdx.x & 3, q = threadIdx.x >> 2;
   for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
     const HeavyRec r = hrecs[h];
-    G1XYZZ acc = G1XYZZ::inf();
-    for (uint32_t k = threadIdx.x; k < r.nseg; k += 64) acc = g1_add(acc, partial[r.base + k]);
-    sh[threadIdx.x] = acc;
+    Fq acc = Fq::zero();                                       // coordinate cr of the point at infinity
+    for (uint32_t k = q; k < r.npart; k += 16) {
+      const Fq c = reinterpret_cast<const Fq*>(&partial[r.base + k])[cr];
+      acc = k == (uint32_t)q ? c : g1q_add(acc, c, cr);
+    }
+    reinterpret_cast<Fq*>(&sh[q])[cr] = acc;
     __syncthreads();
-    for (int s = 32; s >= 1; s >>= 1) {
-      if ((int)threadIdx.x < s && (uint32_t)(threadIdx.x + s) < r.nseg) sh[threadIdx.x] = g1_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    for (int sp = 8; sp >= 1; sp >>= 1) {
+      if (q < sp && (uint32_t)(q + sp) < r.npart) {
+        Fq* pa = reinterpret_cast<Fq*>(&sh[q]) + cr;
+        *pa = g1q_add(*pa, reinterpret_cast<const Fq*>(&sh[q + sp])[cr], cr);
+      }
       __syncthreads();
     }
-    if (threadIdx.x == 0) buckets[r.bucket] = sh[0];
+    if (threadIdx.x < 4) reinterpret_cast<Fq*>(&buckets[r.bucket])[threadIdx.x] = reinterpret_cast<const Fq*>(&sh[0])[threadIdx.x];
     __syncthreads();
   }
 }
@@ -1035,17 +1111,16 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
       stage_cap = 2048;
       while (stage_cap < 32768 && (long)stage_cap < mean + mean / 2) stage_cap *= 2;
     }
-    LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, 256, (size_t)stage_cap * 4, st, batch, (const uint2*)ws.digits.as<uint2>(),
+    LAUNCH(k_part_sort, nparts < PART_SORT_GRID ? nparts : PART_SORT_GRID, PART_SORT_THREADS, (size_t)stage_cap * 4, st, batch, (const uint2*)ws.digits.as<uint2>(),
            (const uint32_t*)hbase, (const uint32_t*)total, hn, P, jobstride, off, ws.entries.as<uint32_t>(), hm->class_hist, stage_cap);
   }
   LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
          ws.order.as<uint32_t>());
   const int accum_block = (pl.accum_block == 64 || pl.accum_block == 128) ? pl.accum_block : 256;
   LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
-         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs,
-         ws.heavy_items.as<HeavyItem>());
-  LAUNCH(k_heavy_accum, HEAVY_GRID, 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
-         pl.table_stride, (const HeavyMeta*)hm, (const HeavyItem*)ws.heavy_items.as<HeavyItem>(), ws.heavy_partial.as<G1XYZZ>());
+         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs);
+  LAUNCH(k_heavy_accum, HEAVY_GRID, HEAVY_THREADS, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
+         pl.table_stride, (const HeavyMeta*)hm, hrecs, ws.heavy_partial.as<G1XYZZ>());
   LAUNCH(k_heavy_finish, HEAVY_GRID / 2, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
   if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)

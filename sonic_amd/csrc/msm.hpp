@@ -68,7 +68,7 @@ struct MsmSlot {
 };
 
 struct MsmWorkspace {
-  DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, heavy_meta, heavy_items, heavy_partial, endo_scalars;
+  DevBuf count, off, digits, entries, buckets, segres, scan_tmp, order, heavy_meta, heavy_partial, endo_scalars;
   // n = total terms over the k jobs of a batch
   void reserve(long n, const MsmPlan& pl, int k = 1);
 };

@@ -361,3 +361,35 @@ def test_msm_protocol_shaped_scalars_2p20(sonic, orc):
         got = msm_g1_srs(srs, basis, e0, sc)
         assert got == orc.msm_srs(osrs, basis, e0, sc, 1, NCPU), (basis, e0)
     srs.close()
+
+
+@pytest.mark.parametrize("log2d,values,copies", [(16, 40, 1000), (16, 3, 20000), (12, 5, 1500)])
+def test_msm_many_heavy_buckets(sonic, orc, log2d, values, copies):
+    """The heavy-bucket path itself (k_heavy_accum / k_heavy_finish): `values` repeated scalars with run lengths from `copies` down to a
+    third of it, scattered among uniform ones -- at d = 2^16 with 40 values more heavy buckets (40 values x 16 windows = 640) than one
+    pass of the kernel's record scan takes (512), stretches that cross several bucket borders, buckets cut by several stretches -- and
+    the same with the runs ALSO equal to their neighbours' negatives (r - v: the same bucket, opposite sign).  Against the oracle."""
+    from sonic_amd.commitment import msm_g1_srs
+    d = 1 << log2d
+    pyr = random.Random(1000 + values)
+    x, alpha = pyr.randrange(1, R), pyr.randrange(1, R)
+    srs = sonic.SRS.new(d, x, alpha)
+    osrs = orc.SRS.from_points(d, srs.points(0, -d, 2 * d + 1), srs.points(1, -d, 2 * d + 1))
+    N = 2 * d
+    rng = np.random.default_rng(values)
+    sc = rand_fr_array(rng, N)
+    perm = rng.permutation(N)
+    pos = 0
+    for v in range(values):
+        val = pyr.randrange(1, R)
+        cnt = copies - (2 * copies // 3) * v // max(values - 1, 1)
+        idx = perm[pos:pos + cnt]
+        pos += cnt
+        sc[idx] = np.frombuffer(val.to_bytes(32, "little"), np.uint8)
+        if v % 2:
+            sc[idx[: cnt // 4]] = np.frombuffer((R - val).to_bytes(32, "little"), np.uint8)
+    assert pos <= N
+    for basis, e0 in ((0, -d), (1, 1 - d)):
+        got = msm_g1_srs(srs, basis, e0, sc)
+        assert got == orc.msm_srs(osrs, basis, e0, sc, 1, NCPU), (basis, e0)
+    srs.close()

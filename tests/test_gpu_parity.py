@@ -304,6 +304,15 @@ def test_window_tables(sonic, orc, srs_pair):
         plain.points(2, 0, 1)                    # no table 1
     sc = rand_fr_array(np.random.default_rng(77), 5000)
     assert msm_g1_srs(plain, 1, -2500, sc) == msm_g1_srs(g, 1, -2500, sc) == orc.msm_srs(o, 1, -2500, sc, 1, NCPU)
+    # SONIC_MSM_TABLE_C: another window width for the tables (the A/B knob behind profiles/r05_table_c_ab.txt): other windows, same sums
+    os.environ["SONIC_MSM_TABLE_C"] = "9"
+    try:
+        narrow = sonic.SRS.new(d, x, alpha)
+    finally:
+        del os.environ["SONIC_MSM_TABLE_C"]
+    _lib.check(_lib.lib().sonic_msm_plan(narrow._h, 5000, C.byref(pc), C.byref(pw), C.byref(pb)))
+    assert (pc.value, pw.value, pb.value) == (9, 29, 1) and (c, W) != (9, 29)
+    assert msm_g1_srs(narrow, 1, -2500, sc) == msm_g1_srs(g, 1, -2500, sc)
 
 
 @pytest.mark.parametrize("c", [4, 7, 11, 16])
