@@ -184,7 +184,11 @@ struct sonic_prover {
   Fr* h_pairs = nullptr;         // {v, v^-1} of the evaluation points, computed on the host (prove_enqueue)
   MsmSlot* h_slots = nullptr;
   uint8_t* h_fr = nullptr;
-  int* h_flags = nullptr;
+  int* h_flags = nullptr;                  // [0] the proof's flags, [1] those of a circuit uploaded inside the proof (pend_circuit)
+  // one-shot calls into a parked shell (sonic_prove): the circuit of THIS call, still in the caller's host buffers.  prove_enqueue
+  // uploads it after it has queued the group of MSMs that needs the assignment only (R, W_a, W_b), so the 2 Q n + Q weights cross
+  // PCIe under those kernels instead of in front of the proof
+  const uint8_t* pend_circuit[4] = {nullptr, nullptr, nullptr, nullptr};
   // SONIC_PROVE_GRAPH=1 (read when the handle is made): capture the enqueue of the second proof and replay it.  Off by default:
   // on ROCm 7.2 the replay of this ~220-node, 7-stream graph is slower than the direct launches (n = 2^10: 9.0 vs 4.9 ms per proof,
   // n = 2^14: 9.6 vs 6.5 ms).
@@ -321,7 +325,7 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   HIP_OK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&p->ts, hipStreamNonBlocking));
   hipStream_t st = p->st;
-  p->flags.alloc(4);
+  p->flags.alloc(8);
   int rc_c = prover_load_circuit(p.get(), wL, wR, wO, cs);
   if (rc_c) return rc_c;
   // workspaces
@@ -346,7 +350,8 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   HIP_OK(hipHostMalloc((void**)&p->h_pairs, sizeof(Fr) * 2 * (5 + 2 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_slots, sizeof(MsmSlot) * (7 + 5 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_fr, 32 * (3 + 2 * Q), hipHostMallocDefault));
-  HIP_OK(hipHostMalloc((void**)&p->h_flags, 4, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&p->h_flags, 8, hipHostMallocDefault));
+  p->h_flags[0] = p->h_flags[1] = 0;
   p->frout.alloc(sizeof(Fr) * (3 + 2 * Q));
   p->frstd.alloc(sizeof(Fr) * (3 + 2 * Q));
   HIP_OK(hipMemsetAsync(p->frout.p, 0, sizeof(Fr) * (3 + 2 * Q), st));
@@ -447,7 +452,8 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
   // first one grows the workspaces), every address in it is owned by the handle.
-  const bool want_graph = p->use_graph && p->proofs_done >= 1 && !profiler().on && p->phases == PH_ALL;
+  const bool pending = p->pend_circuit[0] != nullptr;
+  const bool want_graph = p->use_graph && p->proofs_done >= 1 && !profiler().on && p->phases == PH_ALL && !pending;
   const bool replay = want_graph && p->graph != nullptr;
   const bool capturing = want_graph && !replay && !p->graph_tried;
   struct CaptureGuard {        // an error while capturing must not leave the stream in capture mode
@@ -456,7 +462,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   } capture{st};
   if (capturing) { p->graph_tried = true; HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed)); capture.active = true; }
   if (!replay) {
-  HIP_OK(hipMemsetAsync(flags, 0, 4, st));
+  HIP_OK(hipMemsetAsync(flags, 0, 8, st));
   Fr* S = p->S.as<Fr>();
   HIP_OK(hipMemcpyAsync(S, p->h_tr, 32 * (8 + 2 * Q), hipMemcpyHostToDevice, st));
   fr_to_mont_enqueue(st, S, 8 + 2 * Q, flags);
@@ -549,6 +555,26 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // from y_j, s(u,Y) from u)
   if ((need_g0 || need_T) && on(PH_R)) build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
   ready(p->ev_r1);
+  // the group that needs nothing but r(X,1): queued here, ahead of the other polynomials, when this call's circuit is still on the host
+  bool g0_queued = false;
+  auto group0 = [&] {
+    if (!need_g0 || g0_queued) return;
+    g0_queued = true;
+    begin_group(p->ev_r1);
+    commit(PH_R, r1, r_lo, r_len, n, 0);                                               // R            :63
+    open(PH_OPEN, r1, r_lo, r_len, pZ, 0, 2);                                          // (a, W_a)     :79
+    open(PH_OPEN, r1, r_lo, r_len, pYZ, 1, 3);                                         // (b, W_b)     :80
+    flush_group(last_group == 0);
+  };
+  if (pending) {
+    group0();
+    const uint8_t* const* c = p->pend_circuit;
+    upload_fr_mont(ms, p->wL, c[0], Q * n, flags + 1);
+    upload_fr_mont(ms, p->wR, c[1], Q * n, flags + 1);
+    upload_fr_mont(ms, p->wO, c[2], Q * n, flags + 1);
+    upload_fr_mont(ms, p->cs, c[3], Q, flags + 1);
+    p->pend_circuit[0] = nullptr;
+  }
   // s(X,y)                                                                           Protocol.hs:69-70
   if (need_T && on(PH_T)) {
     poly_scale_powers_enqueue(ms, nullptr, pw, 2 * n + Q + 1, -n, pY, pY + 1);       // y^e, e in [-n, n+Q]
@@ -595,13 +621,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);
     p->fr_valid[2] = 1;
   }
-  if (need_g0) {
-    begin_group(p->ev_r1);
-    commit(PH_R, r1, r_lo, r_len, n, 0);                                               // R            :63
-    open(PH_OPEN, r1, r_lo, r_len, pZ, 0, 2);                                          // (a, W_a)     :79
-    open(PH_OPEN, r1, r_lo, r_len, pYZ, 1, 3);                                         // (b, W_b)     :80
-    flush_group(last_group == 0);
-  }
+  group0();
   for (long j = 0; j < Q; j++) {
     if (!need_j[(size_t)j]) continue;
     Fr* syj = p->syj[j].as<Fr>();
@@ -641,7 +661,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   fr_from_mont_enqueue(ms, frstd, 3 + 2 * Q);
   HIP_OK(hipMemcpyAsync(p->h_slots, slots, sizeof(MsmSlot) * KS, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(p->h_fr, frstd, 32 * (3 + 2 * Q), hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(p->h_flags, flags, 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(p->h_flags, flags, 8, hipMemcpyDeviceToHost, st));
   }  // !replay
   if (capturing) {
     hipGraph_t g = nullptr;
@@ -791,6 +811,7 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
   if (timing) fprintf(stderr, "[sonic] prove: enqueue %.3f ms, then waited %.3f ms for the device\n",
                       std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
+  if (p->h_flags[1]) return flags_to_status(p->h_flags[1], "sonic_prover_new");        // the circuit that was uploaded inside this proof
   if (hflags) return flags_to_status(hflags, "prove");
   std::vector<uint8_t> pts(96 * (size_t)K);
   {
@@ -1364,7 +1385,7 @@ int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL,
     }
   }
   int rc = SONIC_OK;
-  if (sh) rc = prover_load_circuit(sh->p, wL, wR, wO, cs);
+  if (sh) { sh->p->pend_circuit[1] = wR; sh->p->pend_circuit[2] = wO; sh->p->pend_circuit[3] = cs; sh->p->pend_circuit[0] = wL; }   // uploaded inside the proof
   else {
     sonic_prover_t* p = nullptr;
     rc = sonic_prover_new(srs, n, Q, wL, wR, wO, cs, &p);
@@ -1373,6 +1394,7 @@ int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL,
   }
   if (!rc) rc = sonic_prover_set_assignment(sh->p, aL, aR, aO);
   if (!rc) rc = sonic_prover_prove(sh->p, transcript, out_proof);
+  sh->p->pend_circuit[0] = nullptr;           // (a call that failed before its upload: the caller's buffers end with the call)
   // park the shell (also after a failed call: the next one loads its own circuit and assignment); the oldest parked shell makes room
   OneShotShell* evict = nullptr;
   {

@@ -566,6 +566,36 @@ def test_prove_error_contract(sonic, ref, srs_pair):
     assert e.value.code == 2
 
 
+def test_one_shot_calls_into_a_parked_shell(sonic, orc, ref, srs_pair):
+    """sonic_prove (Protocol.hs:47-52: everything per call) re-uses the shell of the previous call with the same SRS and (n, Q) and uploads
+    the new circuit INSIDE the proof, under the MSMs that need the assignment only: different circuits through one shell give the oracle's
+    bytes each; a non-canonical weight is reported with the status the circuit upload always had (and no proof), and the shell still
+    serves the next call"""
+    import ctypes as C
+    from sonic_amd import _lib
+    d, x, alpha, g, o = srs_pair
+    n, Q = 150, 3
+    pyr = random.Random(77)
+    L = _lib.lib()
+    out = (C.c_uint8 * L.sonic_proof_size(Q))()
+    for trial in range(4):
+        circ, asg, enc = circuit_arrays(ref, pyr, n, Q)
+        tr = fr_bytes([pyr.randrange(1, R) for _ in range(8 + 2 * Q)])
+        args = [np.ascontiguousarray(enc[k]) for k in ("wL", "wR", "wO", "cs", "aL", "aR", "aO")]
+        if trial == 2:
+            args[1] = args[1].copy()
+            args[1].reshape(-1, 32)[n + 5] = np.frombuffer(R.to_bytes(32, "little"), np.uint8)        # wR[1][5] = r: not < r
+        C.memset(out, 0, len(out))
+        rc = L.sonic_prove(g._h, n, Q, *[a.ctypes.data for a in args], tr.ctypes.data, out)
+        if trial == 2:
+            assert rc == 3 and bytes(out) == bytes(len(out))                 # SONIC_ERR_BAD_ENCODING
+            msg = C.create_string_buffer(512); L.sonic_last_error(msg, 512)
+            assert b"non-canonical" in msg.value
+        else:
+            assert rc == 0
+            assert bytes(out) == orc.prove(o, n, Q, enc["wL"], enc["wR"], enc["wO"], enc["cs"], enc["aL"], enc["aR"], enc["aO"], tr)
+
+
 def test_prover_handle_reuse(sonic, orc, ref, srs_pair):
     """circuit resident in HBM, several assignments / transcripts through one handle"""
     d, x, alpha, g, o = srs_pair
