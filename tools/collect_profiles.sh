@@ -68,6 +68,9 @@ python3 tools/prove_strong.py --log2n 20 --worlds 2,3,4,6,8 --steps 3 --fit > $O
 python3 tools/prove_strong.py --log2n 18 --worlds 2,4,8 --steps 3 >> $OUT/prove_strong_emulated.txt 2>&1
 # one process, the C ABI, a device list: two handles standing in for two GPUs on this one (overheads of the in-process form, not scaling)
 python3 bench.py --gpus 2 --in-process --devices 0,0 --no-cpu > $OUT/in_process_one_gpu.json 2> $OUT/in_process_one_gpu.err
+# the protocol-shaped stand-alone MSMs alone, and the kernels of the heavy-bucket one (s(X,y): 2n of 3n + 1 scalars are two values)
+python3 tools/msm_shaped.py --steps 20 > $OUT/msm_shaped.json 2> $OUT/msm_shaped.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/shaped_sy -o t -- python3 tools/msm_shaped.py --which sy --no-uniform --steps 20 > /dev/null 2> $OUT/shaped_sy.err
 ./tools/mfma_bound > $OUT/mfma_bound.txt 2>&1
 python3 tools/criterion_shape.py > $OUT/criterion_shape.txt 2>&1
 python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1

@@ -4,11 +4,12 @@
 TAG=${1:-r05}
 IN=gpurun_out/$TAG
 P=profiles
-for f in bench.json lds_counters.txt microbench.txt ba_bench.txt in_process_one_gpu.json prove_strong_emulated.txt mfma_bound.txt criterion_shape.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt; do
+for f in bench.json lds_counters.txt microbench.txt ba_bench.txt in_process_one_gpu.json prove_strong_emulated.txt mfma_bound.txt criterion_shape.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt msm_shaped.json; do
   [ -f $IN/$f ] && cp $IN/$f $P/${TAG}_$f
 done
 cp $(find $IN/msm_only -name "*kernel_stats.csv" | head -1) $P/${TAG}_msm_only_kernel_stats.csv
 cp $(find $IN/bench_prof -name "*kernel_stats.csv" | head -1) $P/${TAG}_bench_kernel_stats.csv
+[ -d $IN/shaped_sy ] && cp $(find $IN/shaped_sy -name "*kernel_stats.csv" | head -1) $P/${TAG}_msm_shaped_sy_kernel_stats.csv
 [ -d $IN/ntt_only ] && cp $(find $IN/ntt_only -name "*kernel_stats.csv" | head -1) $P/${TAG}_ntt_only_kernel_stats.csv && cp $IN/ntt_only.txt $P/${TAG}_ntt_only.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   [ -d $IN/ntt_pmc_$C ] && cp $(find $IN/ntt_pmc_$C -name "*counter_collection.csv" | head -1) $P/${TAG}_ntt_pmc_${C}_counter_collection.csv
