@@ -240,6 +240,7 @@ struct sonic_srs {
   // sizes whose full tables do not fit; every MSM then runs as two half-scalar MSMs (msm_enqueue_batch)
   bool tab_endo = false;
   DevBuf g, ga;
+  DevBuf ps;                 // running sums of the alpha basis (srs.hip, srs_build_prefix); empty when memory was short
   // verifier half: generated on first use from the trapdoor SRS.new was given -- which is wiped as soon as that has
   // happened -- or attached by sonic_srs_set_g2_points / read from a version-2 file
   mutable bool have_trapdoor = false;
@@ -306,8 +307,14 @@ sonic_srs* srs_alloc(int64_t d) {
   s->tab_c = c; s->tab_W = W; s->tab_endo = endo;
   s->g.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
   s->ga.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
+  // the running sums of the alpha basis: one more table, where 1/13 of what the window tables took is still to be had
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const char* penv = getenv("SONIC_SRS_PREFIX");
+  if (!(penv && atoi(penv) == 0) && (size_t)SONIC_SRS_POINT_BYTES * n <= free_b / 4) s->ps.alloc((size_t)SONIC_SRS_POINT_BYTES * n);
   return s;
 }
+PointArrayMut srs_prefix_mut(sonic_srs* s) { return PointArrayMut{s->ps.as<char>(), SONIC_SRS_POINT_BYTES}; }
+PointArray srs_prefix(const sonic_srs* s) { return PointArray{s->ps.as<char>(), SONIC_SRS_POINT_BYTES}; }
 PointArrayMut srs_basis_mut(sonic_srs* s, int b) { return PointArrayMut{(b ? s->ga : s->g).as<char>(), SONIC_SRS_POINT_BYTES}; }
 void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std) { s->have_trapdoor = true; s->x_std = x_std; s->alpha_std = alpha_std; }
 
@@ -411,6 +418,13 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
   CallLease lease;
   hipStream_t st = lease.st();
   DevBuf raw(96 * n);
+  if (basis == SONIC_BASIS_ALPHA_PREFIX) {     // diagnostic: the running sums of the alpha basis (srs_build_prefix)
+    if (!srs->ps.p) { set_error("sonic_srs_get_points: this SRS holds no running sums"); return SONIC_ERR_INVALID_ARG; }
+    LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs_prefix(srs) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
+    HIP_OK(hipMemcpyAsync(out, raw.p, 96 * n, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return SONIC_OK;
+  }
   // diagnostic: basis = b + 2 w reads window table w (2^(c w) multiples) of basis b
   const int w = basis >> 1;
   if (w >= srs->tab_W) { set_error("sonic_srs_get_points: no window table %d", w); return SONIC_ERR_INVALID_ARG; }
@@ -554,6 +568,7 @@ int sonic_srs_replicate(const sonic_srs_t* srs, int device, sonic_srs_t** out) {
   r->g.alloc(srs->g.bytes); r->ga.alloc(srs->ga.bytes);
   HIP_OK(hipMemcpyPeer(r->g.p, ctx.dev, srs->g.p, srs->device, srs->g.bytes));
   HIP_OK(hipMemcpyPeer(r->ga.p, ctx.dev, srs->ga.p, srs->device, srs->ga.bytes));
+  if (srs->ps.p) { r->ps.alloc(srs->ps.bytes); HIP_OK(hipMemcpyPeer(r->ps.p, ctx.dev, srs->ps.p, srs->device, srs->ps.bytes)); }
   {
     std::lock_guard<std::mutex> g2(srs->g2_mu);
     if (srs->h.p) {

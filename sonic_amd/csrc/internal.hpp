@@ -95,6 +95,8 @@ bool srs_tab_endo(const sonic_srs* s);
 MsmPlan srs_msm_plan(const sonic_srs* s, long n);
 // fills window tables 1 .. W-1 of both bases from table 0 (srs.hip)
 void srs_build_tables(hipStream_t st, sonic_srs* s);
+PointArrayMut srs_prefix_mut(sonic_srs* s);      // running sums of the alpha basis (p == nullptr: not held)
+PointArray srs_prefix(const sonic_srs* s);
 void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std);
 struct G2Affine;
 // G2 half (srs_g2.hip)

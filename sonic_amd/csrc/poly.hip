@@ -274,6 +274,60 @@ void flag_nonzero_enqueue(hipStream_t st, const Fr* a, long n, int* flags, int b
   if (n > 0) LAUNCH(k_flag_nonzero, ceil_div(n, 256), 256, 0, st, a, n, flags, bit);
 }
 
+// ---- runs of equal coefficients (round 5) ---------------------------------------------------------------------------------------
+// commitPoly of a coefficient vector that holds RUNS of one value c -- s(X, y_j) of a circuit whose weight rows repeat a value: n copies
+// of two values among 3n + 1 coefficients for the reference's rndCircuit (test/Test/Reference.hs:141-155) -- needs only the two ends of a
+// run: c (A[a] + ... + A[b]) = c ps[b] - c ps[a - 1] with the running sums ps of the basis (srs.hip).  Runs are found tile by tile
+// (RUN_TILE consecutive coefficients all equal and non-zero); a tile's coefficients are zeroed in the copy the large MSM reads, and the
+// tile contributes its closing term (+c, ps[last]) unless the next tile continues the run and its opening term (-c, ps[first - 1])
+// unless the previous one does: 2 * ntiles slots, zero scalars where nothing is emitted, for one small MSM over gathered points.
+__global__ __launch_bounds__(RUN_TILE) void k_run_tiles(const Fr* __restrict__ poly, long len, Fr* __restrict__ masked, Fr* __restrict__ val,
+                                                       uint32_t* __restrict__ uniform, long ntiles) {
+  __shared__ Fr first;
+  const long t = blockIdx.x, i = t * RUN_TILE + threadIdx.x;
+  const bool in = i < len;
+  const Fr v = in ? poly[i] : Fr::zero();
+  if (threadIdx.x == 0) first = v;
+  __syncthreads();
+  const Fr f = first;
+  bool eq = in;
+#pragma unroll
+  for (int k = 0; k < 8; k++) eq = eq && v.l[k] == f.l[k];
+  const bool uni = __syncthreads_and(eq ? 1 : 0) != 0 && !f.is_zero();
+  if (in) masked[i] = uni ? Fr::zero() : v;
+  if (threadIdx.x == 0 && t < ntiles) { uniform[t] = uni ? 1u : 0u; val[t] = f; }
+}
+__device__ __forceinline__ bool fr_same(const Fr& a, const Fr& b) {
+  bool eq = true;
+#pragma unroll
+  for (int k = 0; k < 8; k++) eq = eq && a.l[k] == b.l[k];
+  return eq;
+}
+// ps: the running sums, positioned at the point of coefficient 0; ps_first: that point's index in the table (no ps[-1] at index 0)
+__global__ __launch_bounds__(256) void k_run_terms(const Fr* __restrict__ val, const uint32_t* __restrict__ uniform, long ntiles, PointArray ps,
+                                                   long ps_first, Fr* __restrict__ scal, G1Affine* __restrict__ pts) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  Fr s_close = Fr::zero(), s_open = Fr::zero();
+  G1Affine p_close = G1Affine::inf(), p_open = G1Affine::inf();
+  if (uniform[t]) {
+    const Fr v = val[t];
+    const bool cont_next = t + 1 < ntiles && uniform[t + 1] && fr_same(val[t + 1], v);
+    const bool cont_prev = t > 0 && uniform[t - 1] && fr_same(val[t - 1], v);
+    if (!cont_next) { s_close = v; p_close = ps[(size_t)((t + 1) * RUN_TILE - 1)]; }
+    if (!cont_prev && ps_first + t * RUN_TILE > 0) { s_open = fp_neg(v); p_open = (ps + (t * RUN_TILE - 1))[0]; }
+  }
+  scal[2 * t] = s_close; scal[2 * t + 1] = s_open;
+  pts[2 * t] = p_close; pts[2 * t + 1] = p_open;
+}
+void run_tiles_enqueue(hipStream_t st, const Fr* poly, long len, Fr* masked, Fr* val, uint32_t* uniform) {
+  if (len <= 0) return;
+  LAUNCH(k_run_tiles, ceil_div(len, (long)RUN_TILE), RUN_TILE, 0, st, poly, len, masked, val, uniform, len / RUN_TILE);
+}
+void run_terms_enqueue(hipStream_t st, const Fr* val, const uint32_t* uniform, long ntiles, PointArray ps, long ps_first, Fr* scal, G1Affine* pts) {
+  if (ntiles > 0) LAUNCH(k_run_terms, ceil_div(ntiles, 256L), 256, 0, st, val, uniform, ntiles, ps, ps_first, scal, pts);
+}
+
 // small scalar prep: out = {v, v^-1} for each of k inputs (Montgomery in, Montgomery out); 0^-1 := 0
 __global__ __launch_bounds__(64) void k_fr_with_inverse(const Fr* __restrict__ in, int k, Fr* __restrict__ out) {
   int i = blockIdx.x * 64 + threadIdx.x;

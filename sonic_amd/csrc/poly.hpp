@@ -2,6 +2,7 @@
 #pragma once
 #include "common.hpp"
 #include "field.hpp"
+#include "g1.hpp"
 
 namespace sonic {
 
@@ -13,6 +14,11 @@ void s_of_u_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, co
 void add_into_enqueue(hipStream_t st, Fr* dst, const Fr* src, long n);
 void sub_k_of_y_enqueue(hipStream_t st, Fr* slot, const Fr* cs, const Fr* ypow_nq, long Q, int* flags, int flag_bit);
 void flag_nonzero_enqueue(hipStream_t st, const Fr* a, long n, int* flags, int bit);
+// runs of equal coefficients (poly.hip): tiles of RUN_TILE coefficients that hold one non-zero value are zeroed in `masked` and recorded;
+// run_terms turns the records into 2 * (len / RUN_TILE) (scalar, running-sum point) slots
+constexpr int RUN_TILE = 256;
+void run_tiles_enqueue(hipStream_t st, const Fr* poly, long len, Fr* masked, Fr* val, uint32_t* uniform);
+void run_terms_enqueue(hipStream_t st, const Fr* val, const uint32_t* uniform, long ntiles, PointArray ps, long ps_first, Fr* scal, G1Affine* pts);
 void fr_with_inverse_enqueue(hipStream_t st, const Fr* in, int k, Fr* out);
 void fr_mul_scalar_enqueue(hipStream_t st, const Fr* a, const Fr* b, Fr* out);
 void scale_terms_enqueue(hipStream_t st, const int64_t* e, const Fr* c, long nt, const Fr* pair, Fr* out);

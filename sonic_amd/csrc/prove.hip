@@ -189,6 +189,20 @@ struct sonic_prover {
   // uploads it after it has queued the group of MSMs that needs the assignment only (R, W_a, W_b), so the 2 Q n + Q weights cross
   // PCIe under those kernels instead of in front of the proof
   const uint8_t* pend_circuit[4] = {nullptr, nullptr, nullptr, nullptr};
+  // runs of equal coefficients in the S_j of a handle that is not prepared (poly.hip, k_run_tiles): per j the masked copy of s(X, y_j),
+  // the tile records and the (scalar, running-sum point) slots of the small MSM that stands for the runs; its sum lands in slot
+  // (7 + 4Q) + j, where a prepared handle keeps sum_q y_j^{n+q} C_q, and the host adds it the same way
+  // The small MSM runs on the handle's MAIN stream, which has built all polynomials by then and only waits for the lanes: behind the
+  // batch of the lane that reads the masked copy its ~13 short launches and the chained sums of its per-window buckets added 0.6-1.3 ms
+  // to a proof's latency; a stream of its own (two more streams per handle than the 8 hardware queues the runtime is given) cost
+  // 1-5 ms per streamed proof.
+  struct RunBufs {
+    DevBuf masked, val, uniform, scal, pts;
+    hipEvent_t masked_ev = nullptr;
+  };
+  MsmWorkspace runs_ws;
+  std::vector<RunBufs> runs;
+  bool runs_on = false;
   // SONIC_PROVE_GRAPH=1 (read when the handle is made): capture the enqueue of the second proof and replay it.  Off by default:
   // on ROCm 7.2 the replay of this ~220-node, 7-stream graph is slower than the direct launches (n = 2^10: 9.0 vs 4.9 ms per proof,
   // n = 2^14: 9.6 vs 6.5 ms).
@@ -238,6 +252,7 @@ struct sonic_prover {
   }
   ~sonic_prover() {
     for (auto& l : lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); }
+    for (auto& r : runs) if (r.masked_ev) (void)hipEventDestroy(r.masked_ev);
     for (hipEvent_t e : {ev_r1, ev_sy0, ev_t, ev_su}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_syj) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -449,7 +464,17 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     }
   }
   const int K = (int)(7 + 4 * Q);
-  const int KS = K + (p->prepared ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j
+  // runs of equal coefficients in S_j go through the running sums of the alpha basis: not for a piece of a shared proof (its term
+  // ranges cut the runs), and by default from n = 2^16 (measured, unprepared ms per proof with / without: n = 2^18 32.9 / 36.7,
+  // 2^17 19.8 / 20.8, 2^16 12.2 / 12.3, 2^14 6.8 / 6.0 -- below, the extra launches cost more than the additions they save;
+  // profiles/r05_runs_ab.txt).  SONIC_PROVE_RUNS=0: never (the plain 3n + 1-term MSM); =1: whenever there are 8 tiles (tests).
+  {
+    const char* re = getenv("SONIC_PROVE_RUNS");
+    const int mode = re ? atoi(re) : -1;
+    const bool size_ok = mode == 1 ? 3 * p->n + 1 >= 8 * RUN_TILE : p->n >= (1L << 16);
+    p->runs_on = mode != 0 && size_ok && !p->prepared && p->share_world <= 1 && srs_prefix(p->srs).p != nullptr;
+  }
+  const int KS = K + ((p->prepared || p->runs_on) ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j (or their runs)
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
   // first one grows the workspaces), every address in it is owned by the handle.
   const bool pending = p->pend_circuit[0] != nullptr;
@@ -535,6 +560,31 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     if (!on(ph) || !own(slot)) return;
     if (cur->njobs == MSM_MAX_JOBS) flush_now();
     MsmJob job = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
+    if (my_piece(job, slot)) cur->jobs[cur->njobs++] = job;
+  };
+  // commitPoly with the runs of equal coefficients taken out (S_j of a handle that is not prepared): the flag checks read the
+  // coefficients themselves, the large MSM a copy with the uniform tiles zeroed, and a small MSM over gathered running sums -- on the
+  // main stream, beside this lane's batch -- adds c (ps[b] - ps[a - 1]) per run
+  auto commit_runs = [&](int ph, const Fr* poly, long lo, long len, long maxm, long slot, long j) {
+    if (!on(ph) || !own(slot)) return;
+    if (cur->njobs == MSM_MAX_JOBS) flush_now();
+    MsmJob job = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
+    const long ntiles = job.n / RUN_TILE;
+    if (ntiles > 0) {
+      if ((long)p->runs.size() < Q) p->runs.resize((size_t)Q);
+      sonic_prover::RunBufs& rb = p->runs[(size_t)j];
+      if (!rb.masked_ev) HIP_OK(hipEventCreateWithFlags(&rb.masked_ev, hipEventDisableTiming));
+      rb.masked.ensure(sizeof(Fr) * job.n); rb.val.ensure(sizeof(Fr) * ntiles); rb.uniform.ensure(4 * ntiles);
+      rb.scal.ensure(sizeof(Fr) * 2 * ntiles); rb.pts.ensure(sizeof(G1Affine) * 2 * ntiles);
+      run_tiles_enqueue(cur->st, job.scalars, job.n, rb.masked.as<Fr>(), rb.val.as<Fr>(), rb.uniform.as<uint32_t>());
+      HIP_OK(hipEventRecord(rb.masked_ev, cur->st));
+      HIP_OK(hipStreamWaitEvent(ms, rb.masked_ev, 0));
+      const long first = (long)((job.points.p - srs_basis(srs, 1).p) / (long)job.points.stride);
+      run_terms_enqueue(ms, rb.val.as<Fr>(), rb.uniform.as<uint32_t>(), ntiles, srs_prefix(srs) + first, first, rb.scal.as<Fr>(), rb.pts.as<G1Affine>());
+      msm_enqueue(ms, p->runs_ws, msm_plan(2 * ntiles), PointArray::packed(rb.pts.as<G1Affine>()), rb.scal.as<Fr>(), 2 * ntiles, true, &slots[(7 + 4 * Q) + j]);
+      job.scalars = rb.masked.as<Fr>();
+      p->slot_ran[(size_t)((7 + 4 * Q) + j)] = 1;
+    }
     if (my_piece(job, slot)) cur->jobs[cur->njobs++] = job;
   };
   // fr: index of the evaluation in frout (-1: not reported); every rank with a piece of the opening computes it (the quotient
@@ -627,6 +677,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     Fr* syj = p->syj[j].as<Fr>();
     begin_group(p->ev_syj[j]);
     if (p->prepared) commit(PH_HSCS, p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);   // S_j (diagonal part)   Signature.hs:42
+    else if (p->runs_on) commit_runs(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j, j);    // S_j, runs through the running sums   :42
     else commit(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j                   :42
     open(PH_HSCS, syj, s_lo, s_len, pZj(j), 3 + j, 6 + 2 * j);                       // (s_j, W_j)    :43
     open(PH_HSCW, syj, s_lo, s_len, pU, -1, 5 + 2 * Q + 2 * j);                      // W'_j          :54
@@ -819,23 +870,32 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
     // over <= 64 window sums (255 doublings each) run on threads.  One shared inversion normalises all results.
     auto t0 = std::chrono::steady_clock::now();
     std::vector<G1XYZZ> sums((size_t)K);
-    auto tail = [&](int i) {
-      G1XYZZ s = msm_finish_host(hs[i]);
-      const int j = (i - 5) / 2;
-      if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0) s = g1_add(s, msm_finish_host(hs[K + j]));
-      sums[i] = s;
-    };
-    bool folded = true;
-    const int KS = K + (p->prepared ? (int)Q : 0);          // the C_q halves of the S_j are folded by tail() too
-    for (int i = 0; i < KS; i++) folded = folded && (hs[i].W == 1 || hs[i].pad1 != 0);
-    if (folded) {
-      for (int i = 0; i < K; i++) tail(i);
-    } else {
-      std::vector<std::thread> th;
-      const int nt = K < 16 ? K : 16;
-      for (int w = 0; w < nt; w++) th.emplace_back([&, w] { for (int i = w; i < K; i += nt) tail(i); });
-      for (auto& x : th) x.join();
+    // S_j = slot 5 + 2j + slot K + j on a prepared handle (sum_q y_j^{n+q} C_q) and on one that takes the runs of equal coefficients
+    // out (their small MSM over gathered running sums: per-window sums, a Horner walk).  Slot K + j persists over the passes of
+    // sonic_prover_prove_fs: not tied to this pass's slot_ran; a slot whose MSM never ran is W = 0, the empty sum.
+    const bool has_extra = p->prepared || p->runs_on;
+    std::vector<G1XYZZ> extra((size_t)(has_extra ? Q : 0));
+    auto is_folded = [&](int i) { return hs[i].W <= 1 || hs[i].pad1 != 0; };
+    bool main_folded = true, extra_folded = true;
+    for (int i = 0; i < K; i++) main_folded = main_folded && is_folded(i);
+    for (int j = 0; has_extra && j < (int)Q; j++) extra_folded = extra_folded && is_folded(K + j);
+    std::vector<std::thread> th;
+    if (has_extra && !extra_folded) {                      // the Horner walks of the extra slots beside the main thread's tails
+      const int nt = (int)std::min<long>(Q, 8);
+      for (int w = 0; w < nt; w++) th.emplace_back([&, w] { for (long j = w; j < Q; j += nt) extra[(size_t)j] = msm_finish_host(hs[K + j]); });
+    } else if (has_extra) {
+      for (long j = 0; j < Q; j++) extra[(size_t)j] = msm_finish_host(hs[K + j]);
     }
+    if (main_folded) {
+      for (int i = 0; i < K; i++) sums[i] = msm_finish_host(hs[i]);
+    } else {
+      std::vector<std::thread> th2;
+      const int nt = K < 16 ? K : 16;
+      for (int w = 0; w < nt; w++) th2.emplace_back([&, w] { for (int i = w; i < K; i += nt) sums[i] = msm_finish_host(hs[i]); });
+      for (auto& x : th2) x.join();
+    }
+    for (auto& x : th) x.join();
+    for (long j = 0; has_extra && j < Q; j++) sums[(size_t)(5 + 2 * j)] = g1_add(sums[(size_t)(5 + 2 * j)], extra[(size_t)j]);
     g1_canonical_bytes_host_batch(sums.data(), K, pts.data());
     if (timing) fprintf(stderr, "[sonic] host tails of %d MSMs: %.3f ms\n", K, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }

@@ -89,7 +89,62 @@ __global__ __launch_bounds__(256) void k_table_step(PointArray src, G1XYZZ* __re
   dst[i] = acc;
 }
 
+// ---- running sums of the alpha basis (round 5): ps[i] = A[0] + ... + A[i] in storage order (exponents -d .. i - d) ---------------
+// commitPoly of a polynomial with a RUN of equal coefficients c over exponents [a, b] contributes c (A[a] + ... + A[b]) =
+// c ps[b] - c ps[a - 1]: two terms instead of b - a + 1 (prove.hip, the unprepared S_j: rndCircuit's all-ones weight rows make 2n of
+// the 3n + 1 coefficients of s(X, y_j) two values, test/Test/Reference.hs:141-155).  One more table of 2d + 1 affine points.
+// Built slab by slab: serial sums inside 16-point chunks, a Hillis-Steele scan of the chunk totals, then every element takes the sum of
+// the chunks (and slabs) before it.  The omitted g^alpha (infinity) adds nothing.
+constexpr int PS_CHUNK = 16;
+__global__ __launch_bounds__(64) void k_ps_chunk(PointArray src, G1XYZZ* __restrict__ x, G1XYZZ* __restrict__ tot, long m) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x, lo = c * PS_CHUNK;
+  if (lo >= m) return;
+  const long hi = lo + PS_CHUNK < m ? lo + PS_CHUNK : m;
+  G1XYZZ acc = G1XYZZ::inf();
+  for (long i = lo; i < hi; i++) { acc = g1_add_mixed(acc, src[i]); x[i] = acc; }
+  tot[c] = acc;
+}
+__global__ __launch_bounds__(256) void k_ps_step(const G1XYZZ* __restrict__ in, G1XYZZ* __restrict__ out, long m, long off) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  out[i] = i >= off ? g1_add(in[i - off], in[i]) : in[i];
+}
+// x[i] += the inclusive scan of the chunk totals at the chunk before i's (+ the slabs before: carry)
+__global__ __launch_bounds__(256) void k_ps_apply(G1XYZZ* __restrict__ x, const G1XYZZ* __restrict__ totscan, const G1XYZZ* __restrict__ carry, long m) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const long c = i / PS_CHUNK;
+  G1XYZZ before = *carry;
+  if (c > 0) before = g1_add(before, totscan[c - 1]);
+  x[i] = g1_add(before, x[i]);
+}
+
+void srs_build_prefix(hipStream_t st, sonic_srs* s) {
+  PointArrayMut ps = srs_prefix_mut(s);
+  if (!ps.p) return;
+  const long n = 2 * srs_d(s) + 1;
+  const long SLAB = 1L << 20;
+  const long cap = n < SLAB ? n : SLAB, ccap = ceil_div(cap, PS_CHUNK);
+  DevBuf x(sizeof(G1XYZZ) * cap), pref(sizeof(Fq) * cap), t0(sizeof(G1XYZZ) * ccap), t1(sizeof(G1XYZZ) * ccap), carry(sizeof(G1XYZZ));
+  HIP_OK(hipMemsetAsync(carry.p, 0, sizeof(G1XYZZ), st));            // the point at infinity
+  const PointArray src = srs_basis(s, 1);
+  for (long base = 0; base < n; base += SLAB) {
+    const long m = n - base < SLAB ? n - base : SLAB, nc = ceil_div(m, PS_CHUNK);
+    LAUNCH(k_ps_chunk, ceil_div(nc, 64), 64, 0, st, src + base, x.as<G1XYZZ>(), t0.as<G1XYZZ>(), m);
+    G1XYZZ *a = t0.as<G1XYZZ>(), *b = t1.as<G1XYZZ>();
+    for (long off = 1; off < nc; off <<= 1) {
+      LAUNCH(k_ps_step, ceil_div(nc, 256), 256, 0, st, (const G1XYZZ*)a, b, nc, off);
+      G1XYZZ* t = a; a = b; b = t;
+    }
+    LAUNCH(k_ps_apply, ceil_div(m, 256), 256, 0, st, x.as<G1XYZZ>(), (const G1XYZZ*)a, (const G1XYZZ*)carry.as<G1XYZZ>(), m);
+    HIP_OK(hipMemcpyAsync(carry.p, x.as<G1XYZZ>() + (m - 1), sizeof(G1XYZZ), hipMemcpyDeviceToDevice, st));
+    LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), ps + base, pref.as<Fq>(), m);
+  }
+  HIP_OK(hipStreamSynchronize(st));
+}
+
 void srs_build_tables(hipStream_t st, sonic_srs* s) {
+  srs_build_prefix(st, s);
   const int W = srs_tab_W(s), c = srs_tab_c(s);
   if (getenv("SONIC_DEBUG_TIMING")) fprintf(stderr, "[sonic] window tables: c=%d W=%d d=%ld\n", c, W, (long)srs_d(s));
   if (W <= 1) return;
