@@ -779,7 +779,7 @@ static int prove_finish_share(sonic_prover_t* p, uint8_t* out_share) {
     G1XYZZ sum = G1XYZZ::inf();
     if (p->slot_ran[(size_t)i]) sum = msm_finish_host(hs[i]);
     const int j = (i - 5) / 2;
-    if (p->prepared && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0 && p->slot_ran[(size_t)(K + j)]) sum = g1_add(sum, msm_finish_host(hs[K + j]));
+    if ((p->prepared || p->runs_on) && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0 && p->slot_ran[(size_t)(K + j)]) sum = g1_add(sum, msm_finish_host(hs[K + j]));
     memcpy(o, &sum, 192);
   }
   for (int i = 0; i < F; i++, o += 32) if (p->fr_valid[(size_t)i]) memcpy(o, p->h_fr + 32 * i, 32);

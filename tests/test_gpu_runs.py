@@ -79,6 +79,8 @@ def _prove_all_ways(sonic, srs, circ_enc, tr, n, Q):
         p.set_assignment(asg)
         out.append(p.prove_bytes(tr))
         out.append(p.prove_bytes(tr))                                  # second proof through the same handle (buffers re-used)
+        p.set_share(0, 1)                                              # the share path with a world of one: the whole proof as one share
+        out.append(sonic.proof_from_shares(Q, [p.prove_share(tr)], tr))
         p.close()
     return out
 
