@@ -385,8 +385,13 @@ def main(argv=None):
             L.sonic_device_sync()
             dt_ = time.perf_counter() - t0_
             pp.close()
+            # a handle that is not prepared takes the runs of equal coefficients out of S_j from n = 2^16 (prove.hip, commit_runs): of rndCircuit's
+            # two runs of n coefficients per S_j the whole 256-coefficient tiles -- n and n - 256 terms -- become at most four terms over the
+            # SRS's running sums
+            runs = n >= (1 << 16) and os.environ.get("SONIC_PROVE_RUNS", "") != "0" and os.environ.get("SONIC_SRS_PREFIX", "") != "0"
+            executed = scalar_muls_executed(n, Q, False) - (Q * (2 * n - 256 - 4) if runs else 0)
             return {"proofs_per_s_per_gpu": round(K / dt_, 4), "ms_per_proof": round(1e3 * dt_ / K, 2), "same_bytes_as_prepared": outs_[-1] == proof,
-                    "scalar_muls_executed_per_proof": scalar_muls_executed(n, Q, False)}
+                    "scalar_muls_executed_per_proof": executed, "runs_of_equal_coefficients_through_running_sums": bool(runs)}
 
         def oneshot():
             psz = L.sonic_proof_size(Q)
