@@ -64,8 +64,14 @@ void msm_set_window_override(int c) { g_window_override = c; }
 // (g1_quad.hpp), four lanes per addition.
 // Usually there is nothing heavy and the launch only has to notice that; on a chip full of other MSMs' accumulation every
 // workgroup still waits for a free slot (1024 idle workgroups delayed the chain behind them by 1.4-3.4 ms in prove()).
-static constexpr int HEAVY_THREADS = 512;
-static constexpr int HEAVY_GRID = 256;
+#ifndef SONIC_HEAVY_THREADS
+#define SONIC_HEAVY_THREADS 512
+#endif
+#ifndef SONIC_HEAVY_GRID
+#define SONIC_HEAVY_GRID 256
+#endif
+static constexpr int HEAVY_THREADS = SONIC_HEAVY_THREADS;
+static constexpr int HEAVY_GRID = SONIC_HEAVY_GRID;
 static constexpr uint32_t HEAVY_MIN_STRETCH = 4 * HEAVY_THREADS;
 
 // header of a chain, cleared by one memset at its start: the heavy-bucket counter and the size-class histogram / cursors of the
