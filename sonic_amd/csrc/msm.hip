@@ -48,7 +48,16 @@ constexpr uint32_t PART_SORT_GRID = 2048;
 #ifndef SONIC_PART_SORT_THREADS
 #define SONIC_PART_SORT_THREADS 1024
 #endif
-constexpr int PART_SORT_THREADS = SONIC_PART_SORT_THREADS;   // lanes of a pass-2 workgroup (its LDS stage allows one workgroup per CU)
+constexpr int PART_SORT_THREADS = SONIC_PART_SORT_THREADS;
+#ifndef SONIC_PART_SCATTER_THREADS
+#define SONIC_PART_SCATTER_THREADS 512
+#endif
+// lanes of a staged pass-1 workgroup (PART_TILE scalars per tile: a multiple of it).  Its 148-KB stage allows one workgroup per CU: 8 waves
+// instead of 4 to hide the loads and LDS atomics.  Measured (N = 2^20 MSM, ms in this kernel; n = 2^20 proofs streamed): 256 lanes 0.126, 117.6-118.1;
+// 512 lanes 0.0955, 116.7-116.9; 1024 lanes 0.0865, 117.5 (and n = 2^18 proofs 32.9-33.2 against 32.2-32.7: a 16-wave workgroup waits longer
+// for a CU beside the accumulations)
+constexpr int PART_SCATTER_THREADS = SONIC_PART_SCATTER_THREADS;
+static_assert(PART_TILE % PART_SCATTER_THREADS == 0 && PART_SCATTER_THREADS >= 256, "a tile is a whole number of rounds of the workgroup");   // lanes of a pass-2 workgroup (its LDS stage allows one workgroup per CU)
 static_assert(PART_LOW_BITS >= 8 && PART_LOW_BITS <= 10, "k_part_sort scans 256 x {1, 2, 4} counters");
 
 static int g_window_override = 0;
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
 // consecutive addresses.  LDS: records 8 B + partition id 2 B per (scalar, window) + two words per partition -- 148 KB at 13 windows
 // and 2048 partitions, one workgroup per CU (the pass is short); plans that need more than SORT_STAGE_MAX_LDS use the direct kernel.
 constexpr size_t SORT_STAGE_MAX_LDS = 156 * 1024;
-__global__ __launch_bounds__(256) void k_part_scatter_staged(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
+__global__ __launch_bounds__(PART_SCATTER_THREADS) void k_part_scatter_staged(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
                                                              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ base,
                                                              uint2* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_stage[];
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(256) void k_part_scatter_staged(const MsmBatchDev b
   uint16_t* pid = reinterpret_cast<uint16_t*>(recs + (size_t)PART_TILE * W);  // [PART_TILE * W]
   __shared__ uint32_t sc[256];
   __shared__ uint32_t total_sh;
+  constexpr int T = PART_SCATTER_THREADS;       // (the first 256 threads scan the tile's partition counts; all of them place records)
   for (TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, batch.tile0[batch.k]); tw.cur < tw.end; tw.cur += tw.step) {
     const uint32_t tile = tw.cur;
     const int job = batch_job_of_tile(batch, tile);
@@ -345,18 +355,19 @@ __global__ __launch_bounds__(256) void k_part_scatter_staged(const MsmBatchDev b
     const size_t row0 = (size_t)P * batch.tile0[job] + blk;
     // local exclusive scan of this tile's per-partition counts: ceil(P / 256) consecutive partitions per thread
     const int per = (P + 255) / 256;
+    const bool scans = threadIdx.x < 256;
     uint32_t sum = 0;
-    for (int k = 0; k < per; k++) { const int t = threadIdx.x * per + k; if (t < P) sum += hist[row0 + (size_t)t * nblk]; }
+    for (int k = 0; scans && k < per; k++) { const int t = threadIdx.x * per + k; if (t < P) sum += hist[row0 + (size_t)t * nblk]; }
     uint32_t tot;
     uint32_t ex = block_exclusive_scan_256(sum, sc, &tot);
-    for (int k = 0; k < per; k++) {
+    for (int k = 0; scans && k < per; k++) {
       const int t = threadIdx.x * per + k;
       if (t < P) { cur[t] = ex; delta[t] = base[row0 + (size_t)t * nblk] - ex; ex += hist[row0 + (size_t)t * nblk]; }
     }
     if (threadIdx.x == 0) total_sh = tot;
     __syncthreads();
-    for (int k = 0; k < PART_TILE / 256; k++) {
-      const long i = (long)blk * PART_TILE + k * 256 + threadIdx.x;
+    for (int k = 0; k < PART_TILE / T; k++) {
+      const long i = (long)blk * PART_TILE + k * T + threadIdx.x;
       DigitStream ds;
       ds.init(scal, i, i < n, mont, fold);
       for (int w = 0; w < W; w++) {
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(256) void k_part_scatter_staged(const MsmBatchDev b
     }
     __syncthreads();
     const uint32_t total = total_sh;
-    for (uint32_t i = threadIdx.x; i < total; i += 256) part[delta[pid[i]] + i] = recs[i];
+    for (uint32_t i = threadIdx.x; i < total; i += T) part[delta[pid[i]] + i] = recs[i];
     __syncthreads();
   }
 }
@@ -1101,7 +1112,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     const bool staged_on = dctx.sort_staged == 1;
     const size_t stage_lds = (size_t)P * 8 + (size_t)PART_TILE * pl.W * 10;
     if (staged_on && stage_lds <= SORT_STAGE_MAX_LDS && P <= 65535) {
-      LAUNCH(k_part_scatter_staged, pgrid, 256, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,
+      LAUNCH(k_part_scatter_staged, pgrid, PART_SCATTER_THREADS, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,
              (const uint32_t*)hbase, ws.digits.as<uint2>());
     } else {
       LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hbase,
