@@ -116,8 +116,10 @@ int sonic_srs_device(const sonic_srs_t* srs);       /* the GPU the handle lives 
 int sonic_srs_pairing(const sonic_srs_t* srs, uint8_t out[576]);
 /* basis: 0 = g^{x^e}, 1 = g^{alpha x^e} (the four reference vectors, SRS.hs:33-39); diagnostics: b + 2w = window table w of basis b,
  * SONIC_BASIS_ALPHA_PREFIX = the running sums of the alpha basis, entry e = sum of g^{alpha x^k} over k in [-d, e] (what a run of equal
- * coefficients is committed with: DESIGN.md section 4) */
+ * coefficients is committed with: DESIGN.md section 4),
+ * SONIC_BASIS_ALPHA_SYM = the symmetric sums g^{alpha x^e} + g^{alpha x^-e}, e in [1, d] (what hscProve's C is committed with) */
 #define SONIC_BASIS_ALPHA_PREFIX 1000
+#define SONIC_BASIS_ALPHA_SYM 1001
 int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t n, uint8_t* out);
 /* the G2 half (SRS.hs:35-36,40-41): basis 0 = h^{x^e}, basis 1 = h^{alpha x^e}, e in [-d, d]; hNegativeX[k] = basis0[-(k+1)],
  * hPositiveX[k] = basis0[k], hPositiveAlphaX[k] = basis1[k], hNegativeAlphaX[k] = basis1[-(k+1)].  G2 encoding: 192 bytes

@@ -241,6 +241,7 @@ struct sonic_srs {
   bool tab_endo = false;
   DevBuf g, ga;
   DevBuf ps;                 // running sums of the alpha basis (srs.hip, srs_build_prefix); empty when memory was short
+  DevBuf gs;                 // symmetric sums A[e] + A[-e] of the alpha basis with their window tables (srs_build_sym); empty when memory was short
   // verifier half: generated on first use from the trapdoor SRS.new was given -- which is wiped as soon as that has
   // happened -- or attached by sonic_srs_set_g2_points / read from a version-2 file
   mutable bool have_trapdoor = false;
@@ -311,8 +312,15 @@ sonic_srs* srs_alloc(int64_t d) {
   (void)hipMemGetInfo(&free_b, &total_b);
   const char* penv = getenv("SONIC_SRS_PREFIX");
   if (!(penv && atoi(penv) == 0) && (size_t)SONIC_SRS_POINT_BYTES * n <= free_b / 4) s->ps.alloc((size_t)SONIC_SRS_POINT_BYTES * n);
+  // the symmetric sums of the alpha basis with window tables of their own: half of what the two bases took, where a quarter of the rest holds it
+  // (only with the full tables: the job over them shares a batched chain with jobs over the bases)
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const char* senv = getenv("SONIC_SRS_SYM");
+  if (!(senv && atoi(senv) == 0) && W > 1 && !endo && (size_t)SONIC_SRS_POINT_BYTES * n * W <= free_b / 4) s->gs.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
   return s;
 }
+PointArrayMut srs_sym_mut(sonic_srs* s) { return PointArrayMut{s->gs.as<char>(), SONIC_SRS_POINT_BYTES}; }
+PointArray srs_sym(const sonic_srs* s) { return PointArray{s->gs.as<char>(), SONIC_SRS_POINT_BYTES}; }
 PointArrayMut srs_prefix_mut(sonic_srs* s) { return PointArrayMut{s->ps.as<char>(), SONIC_SRS_POINT_BYTES}; }
 PointArray srs_prefix(const sonic_srs* s) { return PointArray{s->ps.as<char>(), SONIC_SRS_POINT_BYTES}; }
 PointArrayMut srs_basis_mut(sonic_srs* s, int b) { return PointArrayMut{(b ? s->ga : s->g).as<char>(), SONIC_SRS_POINT_BYTES}; }
@@ -418,6 +426,13 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
   CallLease lease;
   hipStream_t st = lease.st();
   DevBuf raw(96 * n);
+  if (basis == SONIC_BASIS_ALPHA_SYM) {        // diagnostic: the symmetric sums of the alpha basis (srs_build_sym; entries e <= 0 are empty)
+    if (!srs->gs.p) { set_error("sonic_srs_get_points: this SRS holds no symmetric sums"); return SONIC_ERR_INVALID_ARG; }
+    LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs_sym(srs) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
+    HIP_OK(hipMemcpyAsync(out, raw.p, 96 * n, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return SONIC_OK;
+  }
   if (basis == SONIC_BASIS_ALPHA_PREFIX) {     // diagnostic: the running sums of the alpha basis (srs_build_prefix)
     if (!srs->ps.p) { set_error("sonic_srs_get_points: this SRS holds no running sums"); return SONIC_ERR_INVALID_ARG; }
     LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs_prefix(srs) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
@@ -569,6 +584,7 @@ int sonic_srs_replicate(const sonic_srs_t* srs, int device, sonic_srs_t** out) {
   HIP_OK(hipMemcpyPeer(r->g.p, ctx.dev, srs->g.p, srs->device, srs->g.bytes));
   HIP_OK(hipMemcpyPeer(r->ga.p, ctx.dev, srs->ga.p, srs->device, srs->ga.bytes));
   if (srs->ps.p) { r->ps.alloc(srs->ps.bytes); HIP_OK(hipMemcpyPeer(r->ps.p, ctx.dev, srs->ps.p, srs->device, srs->ps.bytes)); }
+  if (srs->gs.p) { r->gs.alloc(srs->gs.bytes); HIP_OK(hipMemcpyPeer(r->gs.p, ctx.dev, srs->gs.p, srs->device, srs->gs.bytes)); }
   {
     std::lock_guard<std::mutex> g2(srs->g2_mu);
     if (srs->h.p) {

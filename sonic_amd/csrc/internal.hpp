@@ -97,6 +97,8 @@ MsmPlan srs_msm_plan(const sonic_srs* s, long n);
 void srs_build_tables(hipStream_t st, sonic_srs* s);
 PointArrayMut srs_prefix_mut(sonic_srs* s);      // running sums of the alpha basis (p == nullptr: not held)
 PointArray srs_prefix(const sonic_srs* s);
+PointArrayMut srs_sym_mut(sonic_srs* s);         // symmetric sums A[e] + A[-e] of the alpha basis, laid out like a basis with its window tables
+PointArray srs_sym(const sonic_srs* s);
 void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std);
 struct G2Affine;
 // G2 half (srs_g2.hip)

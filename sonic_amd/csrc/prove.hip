@@ -203,6 +203,10 @@ struct sonic_prover {
   MsmWorkspace runs_ws;
   std::vector<RunBufs> runs;
   bool runs_on = false;
+  // C = commitPoly(s(u, Y)) through the SRS's symmetric sums (srs.hip, srs_build_sym): s(u, Y) has the same coefficient at Y^i and Y^-i
+  // (i <= n), so n terms over A[i] + A[-i] and a Q-term MSM for Y^{n+1} .. Y^{n+Q} stand for its 2n + Q + 1 terms; the Q-term sum lands
+  // in slot 7 + 5Q and the host adds it
+  bool sym_on = false;
   // SONIC_PROVE_GRAPH=1 (read when the handle is made): capture the enqueue of the second proof and replay it.  Off by default:
   // on ROCm 7.2 the replay of this ~220-node, 7-stream graph is slower than the direct launches (n = 2^10: 9.0 vs 4.9 ms per proof,
   // n = 2^14: 9.6 vs 6.5 ms).
@@ -359,19 +363,19 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   p->pw.alloc(sizeof(Fr) * (3 * n + Q + 2));
   p->kpow.alloc(sizeof(Fr) * Q);
   p->S.alloc(sizeof(Fr) * (8 + 2 * Q)); p->PAIRS.alloc(sizeof(Fr) * 2 * (5 + 2 * Q));
-  p->slots.alloc(sizeof(MsmSlot) * (7 + 5 * Q));
+  p->slots.alloc(sizeof(MsmSlot) * (7 + 5 * Q + 1));        // 7 + 4Q results, Q second halves of the S_j, 1 second half of C
   p->use_graph = getenv("SONIC_PROVE_GRAPH") && atoi(getenv("SONIC_PROVE_GRAPH")) != 0;
   HIP_OK(hipHostMalloc((void**)&p->h_tr, 32 * (8 + 2 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_pairs, sizeof(Fr) * 2 * (5 + 2 * Q), hipHostMallocDefault));
-  HIP_OK(hipHostMalloc((void**)&p->h_slots, sizeof(MsmSlot) * (7 + 5 * Q), hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&p->h_slots, sizeof(MsmSlot) * (7 + 5 * Q + 1), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_fr, 32 * (3 + 2 * Q), hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&p->h_flags, 8, hipHostMallocDefault));
   p->h_flags[0] = p->h_flags[1] = 0;
   p->frout.alloc(sizeof(Fr) * (3 + 2 * Q));
   p->frstd.alloc(sizeof(Fr) * (3 + 2 * Q));
   HIP_OK(hipMemsetAsync(p->frout.p, 0, sizeof(Fr) * (3 + 2 * Q), st));
-  HIP_OK(hipMemsetAsync(p->slots.p, 0, sizeof(MsmSlot) * (7 + 5 * Q), st));          // W = 0: an empty sum until the slot's MSM has run
-  memset(p->h_slots, 0, sizeof(MsmSlot) * (7 + 5 * Q));
+  HIP_OK(hipMemsetAsync(p->slots.p, 0, sizeof(MsmSlot) * (7 + 5 * Q + 1), st));      // W = 0: an empty sum until the slot's MSM has run
+  memset(p->h_slots, 0, sizeof(MsmSlot) * (7 + 5 * Q + 1));
   auto mkev = [](hipEvent_t* e) { HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming)); };
   mkev(&p->ev_r1); mkev(&p->ev_sy0); mkev(&p->ev_t); mkev(&p->ev_su);
   p->ev_syj.resize(Q, nullptr);
@@ -474,7 +478,15 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     const bool size_ok = mode == 1 ? 3 * p->n + 1 >= 8 * RUN_TILE : p->n >= (1L << 16);
     p->runs_on = mode != 0 && size_ok && !p->prepared && p->share_world <= 1 && srs_prefix(p->srs).p != nullptr;
   }
-  const int KS = K + ((p->prepared || p->runs_on) ? (int)Q : 0);        // + the sum_q y_j^{n+q} C_q halves of the S_j (or their runs)
+  {
+    // by default from n = 2^17: the Q-term MSM's launches cost a small proof more than n additions save it (ms per proof streamed with /
+    // without, profiles/r05_sym_ab.txt: n = 2^20 113.0-113.4 / 115.6-115.7, 2^18 31.35-31.6 / 31.95-32.0, 2^16 11.3-11.5 / 10.9-11.1,
+    // 2^14 6.1-6.6 / 5.8-6.1).  SONIC_PROVE_SYM=0: never; =1: always (tests).  Not for a piece of a shared proof (the plan counts C's terms).
+    const char* se = getenv("SONIC_PROVE_SYM");
+    const int mode = se ? atoi(se) : -1;
+    p->sym_on = mode != 0 && (mode == 1 || p->n >= (1L << 17)) && p->share_world <= 1 && srs_sym(p->srs).p != nullptr;
+  }
+  const int KS = p->sym_on ? K + (int)Q + 1 : K + ((p->prepared || p->runs_on) ? (int)Q : 0);        // + the second halves of the S_j and of C
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
   // first one grows the workspaces), every address in it is owned by the handle.
   const bool pending = p->pend_circuit[0] != nullptr;
@@ -526,7 +538,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     p->slot_ran[(size_t)slot] = 1;
     return true;
   };
-  p->slot_ran.assign((size_t)(7 + 5 * Q), 0);
+  p->slot_ran.assign((size_t)(7 + 5 * Q + 1), 0);
   p->fr_valid.assign((size_t)(3 + 2 * Q), 0);
   bool need_j_any = false, need_su = own(6 + 4 * Q) || own(5 + 4 * Q);
   std::vector<uint8_t> need_j((size_t)Q, 0);
@@ -694,7 +706,16 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   }
   if (need_su) {
     begin_group(p->ev_su);
-    commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                  // C             :52
+    if (p->sym_on && on(PH_HSCW) && own(6 + 4 * Q)) {                                  // C             :52, over the symmetric sums
+      if (cur->njobs == MSM_MAX_JOBS) flush_now();
+      MsmJob job = commit_job(cur->st, srs, su, u_lo, u_len, d, &slots[6 + 4 * Q], flags);      // (the index checks of the whole range)
+      job.points = srs_sym(srs) + (d + 1); job.scalars = su + (n + 1); job.n = n;               // exponents 1 .. n: c_i (A[i] + A[-i])
+      p->slot_ran[(size_t)(6 + 4 * Q)] = 1;
+      cur->jobs[cur->njobs++] = job;
+      p->slot_ran[(size_t)(7 + 5 * Q)] = 1;                                                     // exponents n+1 .. n+Q, on the main stream (su was built there)
+      msm_enqueue(ms, p->runs_ws, msm_plan(Q), srs_basis(srs, 1) + (d + n + 1), su + (2 * n + 1), Q, true, &slots[7 + 5 * Q]);
+    } else
+      commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                // C             :52
     for (long j = 0; j < Q; j++) open(PH_HSCW, su, u_lo, u_len, pYj(j), 3 + Q + j, 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
     open(PH_QV, su, u_lo, u_len, pV, -1, 5 + 4 * Q);                                 // Q_v           :63
   }
@@ -780,6 +801,7 @@ static int prove_finish_share(sonic_prover_t* p, uint8_t* out_share) {
     if (p->slot_ran[(size_t)i]) sum = msm_finish_host(hs[i]);
     const int j = (i - 5) / 2;
     if ((p->prepared || p->runs_on) && i >= 5 && i < 5 + 2 * Q && ((i - 5) & 1) == 0 && p->slot_ran[(size_t)(K + j)]) sum = g1_add(sum, msm_finish_host(hs[K + j]));
+    if (p->sym_on && i == 6 + 4 * Q && p->slot_ran[(size_t)(K + Q)]) sum = g1_add(sum, msm_finish_host(hs[K + Q]));      // C's Q-term half
     memcpy(o, &sum, 192);
   }
   for (int i = 0; i < F; i++, o += 32) if (p->fr_valid[(size_t)i]) memcpy(o, p->h_fr + 32 * i, 32);
@@ -880,6 +902,8 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
     for (int i = 0; i < K; i++) main_folded = main_folded && is_folded(i);
     for (int j = 0; has_extra && j < (int)Q; j++) extra_folded = extra_folded && is_folded(K + j);
     std::vector<std::thread> th;
+    G1XYZZ extra_c = G1XYZZ::inf();                        // the Q-term half of C (per-window sums: a Horner walk, on a thread of its own)
+    if (p->sym_on) th.emplace_back([&] { extra_c = msm_finish_host(hs[K + Q]); });
     if (has_extra && !extra_folded) {                      // the Horner walks of the extra slots beside the main thread's tails
       const int nt = (int)std::min<long>(Q, 8);
       for (int w = 0; w < nt; w++) th.emplace_back([&, w] { for (long j = w; j < Q; j += nt) extra[(size_t)j] = msm_finish_host(hs[K + j]); });
@@ -896,6 +920,7 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
     }
     for (auto& x : th) x.join();
     for (long j = 0; has_extra && j < Q; j++) sums[(size_t)(5 + 2 * j)] = g1_add(sums[(size_t)(5 + 2 * j)], extra[(size_t)j]);
+    if (p->sym_on) sums[(size_t)(6 + 4 * Q)] = g1_add(sums[(size_t)(6 + 4 * Q)], extra_c);
     g1_canonical_bytes_host_batch(sums.data(), K, pts.data());
     if (timing) fprintf(stderr, "[sonic] host tails of %d MSMs: %.3f ms\n", K, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
@@ -1160,7 +1185,7 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   p->diag.resize(Q); p->yq.resize(Q);
   for (auto& b : p->diag) b.alloc(sizeof(Fr) * n);
   for (auto& b : p->yq) b.alloc(sizeof(Fr) * Q);
-  p->slots.ensure(sizeof(MsmSlot) * (7 + 5 * Q));
+  p->slots.ensure(sizeof(MsmSlot) * (7 + 5 * Q + 1));
   p->prepared = true;
   API_END
 }

@@ -16,11 +16,14 @@ def _runs_at_any_size():
     """by default prove() takes the runs out from n = 2^16 (below, the extra launches cost more than they save); SONIC_PROVE_RUNS=1 takes
     them out wherever there are 8 tiles, so that seconds-sized cases reach the path.  Read at every proof."""
     os.environ["SONIC_PROVE_RUNS"] = "1"
+    os.environ["SONIC_PROVE_SYM"] = "1"              # (and C over the SRS's symmetric sums: same default rule, same switch values)
     yield
     os.environ.pop("SONIC_PROVE_RUNS", None)
+    os.environ.pop("SONIC_PROVE_SYM", None)
 
 
 PREFIX = 1000          # SONIC_BASIS_ALPHA_PREFIX (include/sonic_hip.h)
+SYM = 1001             # SONIC_BASIS_ALPHA_SYM
 INF = bytes(96)
 
 
@@ -46,6 +49,32 @@ def test_running_sums_small(sonic, orc, d, x):
     got = s.points(PREFIX, -d, n)
     for i in range(n):
         assert got[i].tobytes() == want[i], i
+    s.close()
+
+
+@pytest.mark.parametrize("d,x", [(100, None), (40, 1)])
+def test_symmetric_sums_small(sonic, orc, d, x):
+    """sym[e] = A[e] + A[-e] for e in [1, d], empty below; x = 1 makes them doublings"""
+    pyr = random.Random(d + 7)
+    s = sonic.SRS.new(d, x or pyr.randrange(2, R), pyr.randrange(2, R))
+    pts = s.points(1, -d, 2 * d + 1)
+    got = s.points(SYM, -d, 2 * d + 1)
+    for e in range(-d, d + 1):
+        want = orc.g1_add(pts[d + e].tobytes(), pts[d - e].tobytes()) if e >= 1 else INF
+        assert got[d + e].tobytes() == want, e
+    s.close()
+
+
+def test_symmetric_sums_tables_at_scale(sonic, orc):
+    """d = 2^20 + 3 (two slabs of the builder, the second one short): an MSM over the symmetric sums' WINDOW TABLES -- reached through prove()'s
+    C only, so checked here through a proof: n = 2^17 with the commitments of the oracle -- is covered by test_runs_by_default_at_2p16 and the
+    full-size byte tests; here the table itself at slab borders"""
+    d = (1 << 20) + 3
+    s = sonic.SRS.new(d, 0x1234567, 0x7654321)
+    for e in (1, 2, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, d):
+        a, b = s.points(1, e, 1)[0].tobytes(), s.points(1, -e, 1)[0].tobytes()
+        assert s.points(SYM, e, 1)[0].tobytes() == orc.g1_add(a, b), e
+    assert s.points(SYM, 0, 1)[0].tobytes() == INF and s.points(SYM, -5, 1)[0].tobytes() == INF
     s.close()
 
 
@@ -127,25 +156,33 @@ def test_prove_with_runs_matches_oracle(sonic, orc, n, Q, shape):
 
 
 def test_runs_knobs_give_the_same_bytes(sonic):
-    """SONIC_SRS_PREFIX=0: an SRS without the running sums (its S_j are plain MSMs); SONIC_PROVE_RUNS=0: the handle ignores them; unset:
-    the default rule (this n is below it: plain).  All give the same proof."""
+    """SONIC_SRS_PREFIX=0 / SONIC_SRS_SYM=0: an SRS without the running / symmetric sums (its S_j and C are plain MSMs); SONIC_PROVE_RUNS=0 /
+    SONIC_PROVE_SYM=0: the handle ignores them; unset: the default rule (this n is below it: plain).  All give the same proof."""
     n, Q = 3000, 2
     d = 8 * n
     c = big_circuit(5, n, Q)
     tr = fr_bytes([random.Random(1).randrange(1, R) for _ in range(8 + 2 * Q)])
     os.environ["SONIC_SRS_PREFIX"] = "0"
+    os.environ["SONIC_SRS_SYM"] = "0"
     try:
         plain = sonic.SRS.new(d, 77, 99)
     finally:
         del os.environ["SONIC_SRS_PREFIX"]
+        del os.environ["SONIC_SRS_SYM"]
     with pytest.raises(sonic.SonicError):
         plain.points(PREFIX, 0, 1)
+    with pytest.raises(sonic.SonicError):
+        plain.points(SYM, 1, 1)
     full = sonic.SRS.new(d, 77, 99)
     a = _prove_all_ways(sonic, plain, c, tr, n, Q)
     b = _prove_all_ways(sonic, full, c, tr, n, Q)
     os.environ["SONIC_PROVE_RUNS"] = "0"
+    os.environ["SONIC_PROVE_SYM"] = "0"
     b += _prove_all_ways(sonic, full, c, tr, n, Q)
+    os.environ["SONIC_PROVE_SYM"] = "1"
+    b += _prove_all_ways(sonic, full, c, tr, n, Q)                      # C over the symmetric sums, S_j plain
     del os.environ["SONIC_PROVE_RUNS"]
+    del os.environ["SONIC_PROVE_SYM"]
     b += _prove_all_ways(sonic, full, c, tr, n, Q)
     assert len(set(a + b)) == 1
     plain.close(); full.close()
@@ -154,6 +191,7 @@ def test_runs_knobs_give_the_same_bytes(sonic):
 def test_runs_by_default_at_2p16(sonic, orc):
     """the default rule: at n = 2^16 a handle that is not prepared takes the runs out without being asked to; bytes against the oracle"""
     os.environ.pop("SONIC_PROVE_RUNS", None)
+    os.environ.pop("SONIC_PROVE_SYM", None)
     n, Q = 1 << 16, 2
     d = 8 * n
     srs = sonic.SRS.new(d, 12345, 67890)

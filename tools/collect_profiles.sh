@@ -72,6 +72,7 @@ python3 bench.py --gpus 2 --in-process --devices 0,0 --no-cpu > $OUT/in_process_
 python3 tools/msm_shaped.py --steps 20 > $OUT/msm_shaped.json 2> $OUT/msm_shaped.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/shaped_sy -o t -- python3 tools/msm_shaped.py --which sy --no-uniform --steps 20 > /dev/null 2> $OUT/shaped_sy.err
 bash tools/ab_runs.sh > $OUT/runs_ab.txt 2>&1
+bash tools/ab_sym.sh > $OUT/sym_ab.txt 2>&1
 ./tools/mfma_bound > $OUT/mfma_bound.txt 2>&1
 python3 tools/criterion_shape.py > $OUT/criterion_shape.txt 2>&1
 python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1

@@ -4,7 +4,7 @@
 TAG=${1:-r05}
 IN=gpurun_out/$TAG
 P=profiles
-for f in bench.json lds_counters.txt microbench.txt ba_bench.txt in_process_one_gpu.json prove_strong_emulated.txt mfma_bound.txt criterion_shape.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt msm_shaped.json runs_ab.txt; do
+for f in bench.json lds_counters.txt microbench.txt ba_bench.txt in_process_one_gpu.json prove_strong_emulated.txt mfma_bound.txt criterion_shape.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt msm_shaped.json runs_ab.txt sym_ab.txt; do
   [ -f $IN/$f ] && cp $IN/$f $P/${TAG}_$f
 done
 cp $(find $IN/msm_only -name "*kernel_stats.csv" | head -1) $P/${TAG}_msm_only_kernel_stats.csv
