@@ -74,9 +74,10 @@ typedef struct sonic_srs sonic_srs_t;
 typedef struct sonic_prover sonic_prover_t;
 
 /* ---- library ---- */
-#define SONIC_ABI_VERSION 5
+#define SONIC_ABI_VERSION 6
 /* the SONIC_ABI_VERSION the library was built as; no device needed.  History: 5 = round 5 (devices; sonic_msm_submit_dev_v2,
- * sonic_msm_reduce_slices_dev_v2 and sonic_fs_challenges_v2 replace the symbols whose meaning changed in round 4; share format 2) */
+ * sonic_msm_reduce_slices_dev_v2 and sonic_fs_challenges_v2 replace the symbols whose meaning changed in round 4; share format 2);
+ * 6 = round 6 (additions only: sonic_prove_batch fuses the proofs of a handle group, sonic_one_shot_trim) */
 int sonic_abi_version(void);
 int sonic_init(int device_ordinal);                 /* choose the DEFAULT GPU (first call wins) and make it the thread's HIP device; idempotent */
 int sonic_device_count(int* out);                   /* GPUs this process can see; SONIC_ERR_NO_DEVICE (and 0) without one */

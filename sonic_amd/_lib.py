@@ -188,7 +188,7 @@ def lib() -> C.CDLL:
 
 
 HIP_RUNTIME_NOTE = None
-ABI_VERSION = 5          # SONIC_ABI_VERSION of include/sonic_hip.h
+ABI_VERSION = 6          # SONIC_ABI_VERSION of include/sonic_hip.h
 
 
 def _hipver(v: int) -> str:
