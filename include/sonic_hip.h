@@ -229,6 +229,10 @@ size_t sonic_proof_size(int64_t Q);
 int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR,
                 const uint8_t* wO, const uint8_t* cs, const uint8_t* aL, const uint8_t* aR,
                 const uint8_t* aO, const uint8_t* transcript, uint8_t* out_proof);
+/* sonic_prove parks the shell of a finished call (streams, workspaces of a proof of that shape, twiddle tables: several GB at n = 2^20)
+ * for the next call with the same SRS handle and (n, Q); at most four per GPU stay parked, and freeing an SRS frees the shells over it.
+ * sonic_one_shot_trim frees the parked shells now -- of one GPU, or of all (device < 0) -- and returns how many there were. */
+int sonic_one_shot_trim(int device);
 /* the same split so that circuit and assignment stay resident in HBM across proofs */
 int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR,
                      const uint8_t* wO, const uint8_t* cs, sonic_prover_t** out);

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
         "sonic_prove_shared": [vp, i32, vp, vp],
         "sonic_prove_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp],
         "sonic_prove_many": [vp, i32, i64, i64, vp, i64, vp, vp],
+        "sonic_one_shot_trim": [i32],
         "sonic_msm_g1_srs_multi": [vp, i32, i32, i64, vp, i64, i32, vp],
         "sonic_msm_g1_srs_multi_dev": [vp, i32, i32, vp, vp, vp, i32, vp],
         "sonic_prover_device": [vp],
@@ -198,7 +199,7 @@ def _hipver(v: int) -> str:
 EXPORTED = [
     "sonic_abi_version", "sonic_device_count", "sonic_srs_new_on", "sonic_srs_from_points_on", "sonic_srs_replicate", "sonic_srs_device", "sonic_srs_pairing",
     "sonic_srs_load_on", "sonic_msm_lane_new_on", "sonic_msm_submit_dev_v2", "sonic_msm_reduce_slices_dev_v2", "sonic_fs_challenges_v2",
-    "sonic_prove_shared", "sonic_prove_batch", "sonic_prove_many", "sonic_msm_g1_srs_multi", "sonic_msm_g1_srs_multi_dev", "sonic_prover_device", "sonic_dev_alloc_on",
+    "sonic_prove_shared", "sonic_prove_batch", "sonic_prove_many", "sonic_one_shot_trim", "sonic_msm_g1_srs_multi", "sonic_msm_g1_srs_multi_dev", "sonic_prover_device", "sonic_dev_alloc_on",
     "sonic_init", "sonic_last_error", "sonic_device_sync", "sonic_hip_versions", "sonic_srs_new", "sonic_srs_from_points",
     "sonic_srs_free", "sonic_srs_d", "sonic_srs_get_points", "sonic_srs_get_g2_points", "sonic_srs_set_g2_points", "sonic_srs_save", "sonic_srs_has_g2", "sonic_srs_load", "sonic_commit_poly", "sonic_open_poly",
     "sonic_msm_g1", "sonic_msm_g1_srs", "sonic_msm_g1_srs_dev", "sonic_msm_g1_srs_partial_dev",

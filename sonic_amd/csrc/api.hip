@@ -73,6 +73,17 @@ static DeviceCtx* ctx_locked(int dev) {
   return g_ctx[(size_t)dev];
 }
 int default_device_ordinal() { std::lock_guard<std::mutex> g(g_init_mu); return g_device; }
+void unlink_one_shot_of(const sonic_srs* s) {
+  std::lock_guard<std::mutex> g(g_init_mu);
+  for (DeviceCtx* c : g_ctx) {
+    if (!c) continue;
+    std::lock_guard<std::mutex> g2(c->one_shot_mu);
+    for (size_t i = 0; i < c->one_shot.size();) {
+      if (static_cast<OneShotShell*>(c->one_shot[i])->srs == s) c->one_shot.erase(c->one_shot.begin() + (long)i);      // (leaked: its device is out of reach)
+      else i++;
+    }
+  }
+}
 
 DeviceScope::DeviceScope(int dev) : ctx_(nullptr), prev_ctx_(t_ctx), prev_dev_(-1) {
   if (t_ctx && (dev < 0 || t_ctx->dev == dev)) { ctx_ = t_ctx; return; }      // nested call: a handle-less callee inherits the caller's device
@@ -230,8 +241,8 @@ struct sonic_srs {
   int64_t d;
   int device = 0;             // the GPU that holds the handle's memory: every call that takes the handle runs there (DeviceScope)
   // Fiat-Shamir id of the reference string (fs.hpp): constant for an SRS, made on first use (four point fetches) and cached
-  mutable std::once_flag id_once;
-  mutable int id_rc = 0;
+  mutable std::mutex id_mu;
+  mutable bool have_id = false;
   mutable uint8_t id[32] = {0};
   // basis b, window table w, exponent e  ->  tab[b][w * (2d+1) + e + d] = 2^(msm_even_shift(tab_W, w)) * g^{(alpha^b) x^e}
   // (w = 0 is the basis itself; tab_W = 1 when the window tables are switched off)
@@ -262,9 +273,17 @@ PointArray srs_basis(const sonic_srs* s, int b) { return s->basis(b); }
 int64_t srs_d(const sonic_srs* s) { return s->d; }
 int srs_device(const sonic_srs* s) { return s ? s->device : -1; }
 int srs_cached_id(const sonic_srs* s, int (*make)(const sonic_srs*, uint8_t*), uint8_t out[32]) {
-  // (a failed first attempt -- e.g. the device went away -- is remembered with its status: the id of a handle never changes)
-  std::call_once(s->id_once, [&] { s->id_rc = make(s, s->id); });
-  if (s->id_rc) return s->id_rc;
+  // only a success is kept (a transient failure of the first attempt -- no memory for the leased context, a busy device --
+  // used to be remembered with its status, and sonic_prover_prove_fs / sonic_verify_fs failed on that handle from then on although its
+  // points were fine): a failed attempt is simply made again by the next call
+  std::lock_guard<std::mutex> g(s->id_mu);
+  if (!s->have_id) {
+    uint8_t tmp[32];
+    const int rc = make(s, tmp);
+    if (rc) return rc;
+    memcpy(s->id, tmp, 32);
+    s->have_id = true;
+  }
   memcpy(out, s->id, 32);
   return SONIC_OK;
 }
@@ -285,6 +304,13 @@ sonic_srs* srs_alloc(int64_t d) {
   // bucket walks (c = 17: one to two waves per SIMD, short reduction); from d = 2^20 the two windows saved by c = 20 win (prove at
   // n = 2^17 20.2 -> 19.2 ms; a stand-alone MSM of 0.9 d terms 5.7 -> 2.9 ms: 2^16 walks of 210 entries are one wave per SIMD).
   int c = lg >= 20 ? 20 : (lg > 17 ? 17 : lg);
+  // round 6, d = 2^16, 2^17: c = 16.  A proof's MSMs over such an SRS run as ONE chain (prove.hip, fused) whose accumulation is 45 n W
+  // additions and whose butterfly costs ~2.8 additions' worth per bucket of 15 bucket sets: at n = d/8 = 2^14 the 2^16-bucket plan (c = 17)
+  // spent 0.82 ms reducing beside 1.75 ms accumulating (profiles/r06_small_proofs.txt).  Measured at n = 2^14, ms per proof streamed / one
+  // at a time: c = 17 4.09-4.18 / 4.27-4.54, c = 16 3.91-3.98 / 4.23-4.33, c = 15 4.09-4.11 / 4.44-4.51, c = 14 8.5 / 9.0 (15 x 2^13 bucket
+  // walks are less than one round of the chip's wave slots and 350-800 entries long); at n = 2^16 c = 16 11.1 against 10.5-10.7 at 17
+  // (profiles/r06_ab_small.txt).
+  if (lg >= 15 && lg <= 17) c = lg == 15 ? 15 : 16;
   if (c < 9) c = 9;
   if (const char* tc = getenv("SONIC_MSM_TABLE_C")) { const int v = atoi(tc); if (v >= 9 && v <= 22) c = v; }
   // W windows of even width (msm.hpp): the widest is ceil(255 / W) <= c
@@ -332,7 +358,11 @@ void srs_set_trapdoor(sonic_srs* s, const Fr& x_std, const Fr& alpha_std) { s->h
 // the window into 5, without tables the index has 31 bits.  MSMs of 2^26 terms and more therefore run over per-window buckets
 // even when the SRS has tables, and 2^31 terms are refused (msm_enqueue_batch, sonic_msm_plan).
 MsmPlan srs_msm_plan(const sonic_srs* s, long n) {
-  if (s->tab_W > 1 && s->tab_W <= MSM_TABLE_MAX_WINDOWS && n < MSM_TABLE_MAX_TERMS && msm_window_override() == 0 && n >= (1L << (s->tab_c - 1)) / 16)
+  // (up to round 5 an MSM of fewer than 1/16 of the bucket count fell back to per-window buckets without the tables: 64 four-bit windows,
+  // 64 bucket sets, a chain that cannot be batched and 255 doublings of host tail per MSM -- 0.9 ms each, which is what the reference's
+  // own criterion shape, n = 1 / d = 25, paid fifteen times per proof: profiles/r05_criterion_shape.txt.  Over the tables the same MSM
+  // is a batchable job whose cost is the butterfly over the shared bucket set: 0.12 ms at 2^16 buckets, 0.55 ms at 2^19.)
+  if (s->tab_W > 1 && s->tab_W <= MSM_TABLE_MAX_WINDOWS && n < MSM_TABLE_MAX_TERMS && msm_window_override() == 0)
     return msm_plan_tables(n > 0 ? n : 1, s->tab_c, s->tab_W, 2 * s->d + 1, s->tab_endo);
   return msm_plan(n > 0 ? n : 1);
 }
@@ -413,7 +443,9 @@ int sonic_srs_from_points_on(int device, int64_t d, const uint8_t* basis0, const
 
 void sonic_srs_free(sonic_srs_t* srs) {
   if (!srs) return;
-  try { DeviceScope scope(srs->device); drop_one_shot_of(srs); delete srs; } catch (const HipFail&) { delete srs; }
+  // (when the handle's device cannot be made current the parked one-shot shells over this SRS must still be unlinked -- a later
+  // SRS allocated at the same address would otherwise match a shell whose tables are gone)
+  try { DeviceScope scope(srs->device); drop_one_shot_of(srs); delete srs; } catch (const HipFail&) { unlink_one_shot_of(srs); delete srs; }
 }
 int64_t sonic_srs_d(const sonic_srs_t* srs) { return srs ? srs->d : -1; }
 int sonic_srs_device(const sonic_srs_t* srs) { return srs ? srs->device : -1; }

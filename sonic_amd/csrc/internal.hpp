@@ -1,10 +1,12 @@
 // Cross-translation-unit declarations inside libsonic_hip.so.
 #pragma once
+#include <atomic>
 #include "common.hpp"
 #include "g1.hpp"
 #include "msm.hpp"
 
 struct sonic_srs;
+struct sonic_prover;
 
 namespace sonic {
 
@@ -26,8 +28,8 @@ struct DeviceCtx {
   std::vector<void*> lanes;              // idle lanes of the blocking MSM entry points (sonic_msm_lane*, under pool_mu)
   NttTables* ntt = nullptr;              // sonic_ntt_fr / sonic_poly_mul_fr[_dev] (under call_mu)
   DevBuf mul_a, mul_b, mul_flags;        // scratch of sonic_poly_mul_fr_dev (under call_mu)
-  int sort_staged = -1;                  // msm.hip: the LDS-staged sort passes got their dynamic-LDS attribute on this device (-1: not asked yet)
-  int ntt_big = -1;                      // ntt.hip: the same for the 128-KB block of k_ntt_wide_big
+  std::atomic<int> sort_staged{-1};      // msm.hip: the LDS-staged sort passes got their dynamic-LDS attribute on this device (-1: not asked yet)
+  std::atomic<int> ntt_big{-1};          // ntt.hip: the same for the 128-KB block of k_ntt_wide_big
   // twiddle tables of the prover handles, one set per transform size, shared by every handle on the device and never freed (64 + 64 MB
   // at 2^21 points: two streaming handles used to hold one copy each) (under pool_mu)
   std::map<int, NttTables*> prover_ntt;
@@ -38,6 +40,8 @@ struct DeviceCtx {
 };
 const NttTables& device_ntt_tables(int log2n);          // of the current device; built on first use (blocks until they are complete)
 void drop_one_shot_of(const sonic_srs* s);              // an SRS handle is going away: the parked one-shot shells over it go first
+struct OneShotShell { const sonic_srs* srs; sonic_prover* p; };      // an entry of DeviceCtx::one_shot (prove.hip)
+void unlink_one_shot_of(const sonic_srs* s);            // the same when no device scope can be opened: the shells are forgotten (leaked), never matched again
 // dev < 0: the process's default device (sonic_init, else LOCAL_RANK % device count, else 0).  Throws HipFail{SONIC_ERR_NO_DEVICE}
 // without a GPU -- the library has no CPU fallback -- and HipFail{SONIC_ERR_INVALID_ARG} for an ordinal the node does not have.
 class DeviceScope {

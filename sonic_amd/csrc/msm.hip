@@ -863,6 +863,11 @@ __global__ __launch_bounds__(256, 2) void k_group_sum(const G1XYZZ* __restrict__
 // does anyway.  Measured: profiles/r04_bucket_tree.txt.
 constexpr int TREE_BLOCK_LOG = 10;          // buckets per workgroup of the first launch: 1024 (4 per thread)
 constexpr int TREE_MID_LOG = 14;            // second launch: one workgroup per 2^14 buckets, levels 11..14; third: one per set
+#ifndef SONIC_TREE_LATENCY_MAX
+#define SONIC_TREE_LATENCY_MAX (1L << 17)
+#endif
+constexpr long TREE_LATENCY_MAX_BUCKETS = SONIC_TREE_LATENCY_MAX;     // up to here (all sets of a launch together) the all-quad form below
+constexpr int TREE_LATENCY_BLOCK_LOG = 7, TREE_LATENCY_MID_LOG = 12;
 
 // item `it` of level m inside the span that starts at s0: pair = it / m, component = it % m (0: total, j: bit j - 1)
 __device__ __forceinline__ void tree_item(G1XYZZ* __restrict__ Z, size_t s0, int m, uint32_t it) {
@@ -927,7 +932,8 @@ __global__ __launch_bounds__(256, 2) void k_bucket_tree_block(G1XYZZ* __restrict
 // later launches: levels m_lo .. m_hi over spans of 2^span_log buckets, one workgroup per span.  final_L > 0 (then span_log == final_L:
 // one workgroup per bucket set): the set's sums go to its job's slot -- win[j] = bs_j (j < L), win[L] = total, W = L, c = 1,
 // pad0 = the total's weight (1, or base + 1 for a bucket range that starts at `base`), pad1 = 1 marks the form (msm_finish_host)
-__global__ __launch_bounds__(256, 2) void k_bucket_tree_levels(G1XYZZ* __restrict__ Z, int span_log, int m_lo, int m_hi, int final_L,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 2 : 1) void k_bucket_tree_levels(G1XYZZ* __restrict__ Z, int span_log, int m_lo, int m_hi, int final_L,
                                                                uint32_t tot_mul, int quads, const MsmBatchDev batch) {
   const size_t s0 = (size_t)blockIdx.x << span_log;
   for (int m = m_lo; m <= m_hi; m++) {
@@ -950,6 +956,25 @@ __global__ __launch_bounds__(256, 2) void k_bucket_tree_levels(G1XYZZ* __restric
 
 // reduces `sets` bucket sets of 2^L buckets each (consecutive in Z) into the jobs' slots
 static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint32_t tot_mul, const MsmBatchDev& batch) {
+  if (((long)sets << L) <= TREE_LATENCY_MAX_BUCKETS) {
+    // Few buckets (round 6): the chip has more lanes than the tree has additions on ANY level -- level 1 of 2^16 buckets is 32768
+    // additions against 131072 lanes at two waves per SIMD -- so every level runs on quads (a quad's addition is 5 products deep instead
+    // of 14: g1_quad.hpp) and the blocks are small enough to spread the early levels over the whole chip: 128 buckets per workgroup
+    // (one round of 64 quads per level), then 512-lane workgroups over spans of 2^12, then one per set.  The form above -- 1024-bucket
+    // blocks whose four leaf additions a lane runs one after the other, whole additions while a level has more of them than the
+    // workgroup has lanes -- is the one that does least WORK, which is what counts when the bucket sets of a batch fill the chip.
+    // One 2^16-bucket set (an eighth of a bucket-sharded MSM's buckets, a stand-alone small MSM): 0.29 -> see profiles/r06_tree_latency.txt
+    constexpr int all_quads = 1 << 20;
+    const int LB = L < TREE_LATENCY_BLOCK_LOG ? L : TREE_LATENCY_BLOCK_LOG;
+    LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB, all_quads);
+    int done = LB;
+    if (L > TREE_LATENCY_MID_LOG) {
+      LAUNCH(k_bucket_tree_levels<512>, (uint32_t)sets << (L - TREE_LATENCY_MID_LOG), 512, 0, st, Z, TREE_LATENCY_MID_LOG, done + 1, TREE_LATENCY_MID_LOG, 0, 0u, all_quads, batch);
+      done = TREE_LATENCY_MID_LOG;
+    }
+    LAUNCH(k_bucket_tree_levels<512>, (uint32_t)sets, 512, 0, st, Z, L, done + 1, L, L, tot_mul, all_quads, batch);
+    return;
+  }
   const int LB = L < TREE_BLOCK_LOG ? L : TREE_BLOCK_LOG;
   // (a first launch with 8 buckets per thread -- 11 additions in registers, blocks of 2048, one wave per SIMD -- measured the same:
   // 0.51 + 2 x 0.09 ms against 0.52 + 2 x 0.10 ms at 2^19 buckets)
@@ -962,12 +987,12 @@ static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint
   if (L > done) {
     const int mid = L < TREE_MID_LOG ? L : TREE_MID_LOG;
     if (mid < L) {
-      LAUNCH(k_bucket_tree_levels, (uint32_t)sets << (L - mid), 256, 0, st, Z, mid, done + 1, mid, 0, 0u, quads, batch);
+      LAUNCH(k_bucket_tree_levels<256>, (uint32_t)sets << (L - mid), 256, 0, st, Z, mid, done + 1, mid, 0, 0u, quads, batch);
       done = mid;
     }
   }
   // last launch: one workgroup per set finishes the levels that are left (none when L <= TREE_BLOCK_LOG) and fills the slot
-  LAUNCH(k_bucket_tree_levels, (uint32_t)sets, 256, 0, st, Z, L, done + 1, L, L, tot_mul, quads, batch);
+  LAUNCH(k_bucket_tree_levels<256>, (uint32_t)sets, 256, 0, st, Z, L, done + 1, L, L, tot_mul, quads, batch);
 }
 
 // ---- tail (host) -----------------------------------------------------------------------------
@@ -1134,12 +1159,22 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
          ws.order.as<uint32_t>());
   const int accum_block = (pl.accum_block == 64 || pl.accum_block == 128) ? pl.accum_block : 256;
-  LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
+  hipStream_t sa = st;
+  if (pl.accum_stream && pl.accum_ev[0] && pl.accum_ev[1]) {
+    sa = pl.accum_stream;
+    HIP_OK(hipEventRecord(pl.accum_ev[0], st));
+    HIP_OK(hipStreamWaitEvent(sa, pl.accum_ev[0], 0));
+  }
+  LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, sa, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
          (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs);
-  LAUNCH(k_heavy_accum, HEAVY_GRID, HEAVY_THREADS, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
+  LAUNCH(k_heavy_accum, HEAVY_GRID, HEAVY_THREADS, 0, sa, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
          pl.table_stride, (const HeavyMeta*)hm, hrecs, ws.heavy_partial.as<G1XYZZ>());
-  LAUNCH(k_heavy_finish, HEAVY_GRID / 2, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
+  LAUNCH(k_heavy_finish, HEAVY_GRID / 2, 64, 0, sa, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
+  if (sa != st) {
+    HIP_OK(hipEventRecord(pl.accum_ev[1], sa));
+    HIP_OK(hipStreamWaitEvent(st, pl.accum_ev[1], 0));
+  }
   if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)
   const int sets = k * pl.Wb;
   if ((pl.tree && pl.Wb == 1 && pl.NB >= 4) || pl.endo) {
@@ -1174,6 +1209,29 @@ __global__ __launch_bounds__(256, 1) void k_sum_slices(const G1XYZZ* __restrict_
   out[i] = acc;
 }
 
+// The same with TWO lanes per bucket (round 6): lane j adds slices j, j + 2, .. and the pair folds its two sums with one whole-point exchange
+// over DPP (no LDS): 4 additions deep at k = 8 instead of 7 and twice the waves -- 65536 buckets are one wave per SIMD otherwise, where a
+// wave's dependent instructions leave half of the issue slots empty.  8 additions of issue per bucket instead of 7.  (FOUR lanes per bucket --
+// 3 additions deep, 12 of issue -- measured slower than one: 0.211 against 0.149 ms at 65536 buckets x 8 slices, profiles/r06_msm_strong.txt;
+// two waves per SIMD already fill the issue slots, and beyond that the extra additions are simply more work.)
+template <int CTRL>
+__device__ __forceinline__ G1XYZZ g1_quad_perm(const G1XYZZ& p) {
+  G1XYZZ r;
+  r.x = fq_quad<CTRL>(p.x); r.y = fq_quad<CTRL>(p.y); r.zz = fq_quad<CTRL>(p.zz); r.zzz = fq_quad<CTRL>(p.zzz);
+  return r;
+}
+__global__ __launch_bounds__(256, 2) void k_sum_slices2(const G1XYZZ* __restrict__ slices, int k, long len, G1XYZZ* __restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = t >> 1;
+  const int j = (int)(t & 1);
+  if (i >= len) return;                                     // (whole pairs: len is a multiple of MSM_SLICE_QUANTUM)
+  G1XYZZ acc = j < k ? slices[(size_t)j * len + i] : G1XYZZ::inf();
+  for (int s = j + 2; s < k; s += 2) acc = g1_add(acc, slices[(size_t)s * len + i]);
+  constexpr int QP_SWAP1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);     // [1,0,3,2]
+  acc = g1_add(acc, g1_quad_perm<QP_SWAP1>(acc));            // both lanes: the bucket's sum
+  if (j == 0) out[i] = acc;
+}
+
 void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot) {
   (void)c;
   if (k < 1 || len < 4 || len % MSM_SLICE_QUANTUM || base % MSM_SLICE_QUANTUM || base + len >= (1L << 31))
@@ -1187,7 +1245,9 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
   if (P > len) HIP_OK(hipMemsetAsync(ws.buckets.as<G1XYZZ>() + len, 0, (size_t)(P - len) * sizeof(G1XYZZ), st));
   // (a quad per bucket, and four lanes per bucket with an LDS tree, both measured slower at 65536 buckets x 8 slices -- 0.21 / 0.22 against
   // 0.15 ms: the kernel reads 100 MB once and is bound by that, not by its chain of 7 additions)
-  LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+  static const int two = getenv("SONIC_SUM_SLICES2") ? atoi(getenv("SONIC_SUM_SLICES2")) : 1;
+  if (two && k > 2) LAUNCH(k_sum_slices2, ceil_div(2 * len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+  else LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
   MsmBatchDev b1;
   memset(&b1, 0, sizeof b1);
   b1.k = 1;

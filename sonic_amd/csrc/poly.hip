@@ -25,14 +25,23 @@ namespace sonic {
 #define SONIC_SCALE_PER 32
 #endif
 constexpr int SCALE_PER = SONIC_SCALE_PER;
+// ... for arrays long enough to fill the chip with threads of that length.  A short array (n = 2^14: 49 K coefficients = 6 workgroups at
+// 32 per thread) runs as ONE dependent chain of 45 + 2 PER products on a few waves -- 80 us per launch, twenty launches on a proof's
+// critical path (profiles/r06_small_proofs.txt) -- so the elements per thread shrink until ~256 workgroups exist (never below 2).
+static int scale_per(long n) {
+  long per = n / (256L * 256L);
+  if (per > SCALE_PER) per = SCALE_PER;
+  if (per < 2) per = 2;
+  return (int)per;
+}
 
 // out[i] = v(i) * x^(e0 + i); v(i) depends on mode:
 //   0: in[i]                     1: 1 (pure power table)
 //   2: quotient numerator: j = lo_q + i >= 0 ? F - P[i] : -P[i], with F = in[nF-1] (the last prefix)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_scale_powers(const Fr* __restrict__ in, Fr* __restrict__ out, long n, long e0,
-                                                      const Fr* __restrict__ px, const Fr* __restrict__ pxinv, long lo_q, long nF) {
-  constexpr int PER = SCALE_PER;                // elements per thread, strided by the block size
+                                                      const Fr* __restrict__ px, const Fr* __restrict__ pxinv, long lo_q, long nF, int PER) {
+  // PER elements per thread, strided by the block size
   const long base = (long)blockIdx.x * (256 * PER) + threadIdx.x;
   if (base >= n) return;
   const Fr x = *px, xinv = *pxinv;
@@ -56,15 +65,17 @@ __global__ __launch_bounds__(256) void k_scale_powers(const Fr* __restrict__ in,
 
 void poly_scale_powers_enqueue(hipStream_t st, const Fr* in, Fr* out, long n, long e0, const Fr* d_x, const Fr* d_xinv) {
   if (n <= 0) return;
-  if (in) LAUNCH(k_scale_powers<0>, ceil_div(n, 256 * SCALE_PER), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
-  else LAUNCH(k_scale_powers<1>, ceil_div(n, 256 * SCALE_PER), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L);
+  const int per = scale_per(n);
+  if (in) LAUNCH(k_scale_powers<0>, ceil_div(n, 256L * per), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L, per);
+  else LAUNCH(k_scale_powers<1>, ceil_div(n, 256L * per), 256, 0, st, in, out, n, e0, d_x, d_xinv, 0L, 0L, per);
 }
 
 // q[i] (exponent lo + i, i < n - 1) from the prefix sums P (n entries, exponents lo .. lo + n - 1)
 void poly_quotient_enqueue(hipStream_t st, const Fr* prefix, Fr* q, long n, long lo, const Fr* d_z, const Fr* d_zinv) {
   if (n <= 1) return;
   // z^{-1-j} = (z^-1)^{1+j}: base z^-1 (inverse base z), first exponent 1 + lo
-  LAUNCH(k_scale_powers<2>, ceil_div(n - 1, 256 * SCALE_PER), 256, 0, st, prefix, q, n - 1, 1 + lo, d_zinv, d_z, lo, n);
+  const int per = scale_per(n - 1);
+  LAUNCH(k_scale_powers<2>, ceil_div(n - 1, 256L * per), 256, 0, st, prefix, q, n - 1, 1 + lo, d_zinv, d_z, lo, n, per);
 }
 
 // ---- inclusive prefix sums in Fr (tile = 1024) -----------------------------------------------
@@ -124,6 +135,87 @@ void poly_prefix_sum_enqueue(hipStream_t st, Fr* d, long n, DevBuf& tmp) {
     LAUNCH(k_prefix_top, 1, 256, 0, st, tmp.as<Fr>(), ntiles);
     LAUNCH(k_prefix_apply, ceil_div(n, 256), 256, 0, st, d, n, (const Fr*)tmp.as<Fr>());
   }
+}
+
+// ---- the same three steps for several openings at once (blockIdx.y = opening) -----------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scale_powers_b(const OpenBatch b, long n, long e0, long lo_q, long nF, int PER) {
+  const int y = blockIdx.y;
+  const long base = (long)blockIdx.x * (256 * PER) + threadIdx.x;
+  if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) *b.fz[y] = b.D[y][nF - 1];      // f(z): the last prefix
+  if (base >= n) return;
+  // MODE 0: D = poly * z^(e0 + i);  MODE 2: q = numerator(P) * (z^-1)^(e0 + i), P = D (the prefix sums), F = P[nF - 1]
+  const Fr* __restrict__ in = MODE == 0 ? b.poly[y] : b.D[y];
+  Fr* __restrict__ out = MODE == 0 ? b.D[y] : b.q[y];
+  const Fr x = MODE == 0 ? b.zpair[y][0] : b.zpair[y][1], xinv = MODE == 0 ? b.zpair[y][1] : b.zpair[y][0];
+  const long e = e0 + base;
+  Fr p = e >= 0 ? fp_pow_u64(x, (uint64_t)e) : fp_pow_u64(xinv, (uint64_t)(-e));
+  const Fr step = fp_pow_u64(x, 256);
+  Fr F;
+  if (MODE == 2) F = in[nF - 1];
+#pragma unroll 1
+  for (int k = 0; k < PER; k++) {
+    const long i = base + (long)k * 256;
+    if (i >= n) break;
+    Fr v;
+    if (MODE == 0) v = fp_mul(in[i], p);
+    else { Fr P = in[i]; v = fp_mul((lo_q + i >= 0) ? fp_sub(F, P) : fp_neg(P), p); }
+    out[i] = v;
+    p = fp_mul(p, step);
+  }
+}
+__global__ __launch_bounds__(256) void k_prefix_tiles_b(const OpenBatch b, long n) {
+  __shared__ Fr sh[256];
+  Fr* __restrict__ d = b.D[blockIdx.y];
+  const long base = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+  Fr v[4], s = Fr::zero();
+  for (int k = 0; k < 4; k++) { v[k] = base + k < n ? d[base + k] : Fr::zero(); s = fp_add(s, v[k]); v[k] = s; }
+  Fr incl = block_inclusive_scan_fr(s, sh);
+  Fr excl = fp_sub(incl, s);
+  for (int k = 0; k < 4; k++) if (base + k < n) d[base + k] = fp_add(v[k], excl);
+  if (threadIdx.x == 255) b.tiles[blockIdx.y][blockIdx.x] = incl;
+}
+__global__ __launch_bounds__(256) void k_prefix_top_b(const OpenBatch b, long ntiles) {
+  __shared__ Fr sh[256];
+  __shared__ Fr carry_sh;
+  Fr* __restrict__ tile_sums = b.tiles[blockIdx.x];
+  if (threadIdx.x == 0) carry_sh = Fr::zero();
+  __syncthreads();
+  for (long base = 0; base < ntiles; base += 256) {
+    long idx = base + threadIdx.x;
+    Fr v = idx < ntiles ? tile_sums[idx] : Fr::zero();
+    Fr incl = block_inclusive_scan_fr(v, sh);
+    Fr carry = carry_sh;
+    if (idx < ntiles) tile_sums[idx] = fp_add(fp_sub(incl, v), carry);   // exclusive
+    __syncthreads();
+    if (threadIdx.x == 255) carry_sh = fp_add(carry, incl);
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_prefix_apply_b(const OpenBatch b, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long tile = i >> 10;
+  if (tile == 0) return;
+  Fr* __restrict__ d = b.D[blockIdx.y];
+  d[i] = fp_add(d[i], b.tiles[blockIdx.y][tile]);
+}
+void open_batch_enqueue(hipStream_t st, const OpenBatch& b, long lo, long len) {
+  if (b.k <= 0 || len <= 0) return;
+  const unsigned k = (unsigned)b.k;
+  const int per = scale_per(len);
+  LAUNCH(k_scale_powers_b<0>, dim3((unsigned)ceil_div(len, 256L * per), k), 256, 0, st, b, len, lo, 0L, 0L, per);
+  const long ntiles = (len + 1023) / 1024;
+  LAUNCH(k_prefix_tiles_b, dim3((unsigned)ntiles, k), 256, 0, st, b, len);
+  if (ntiles > 1) {
+    LAUNCH(k_prefix_top_b, k, 256, 0, st, b, ntiles);
+    LAUNCH(k_prefix_apply_b, dim3((unsigned)ceil_div(len, 256), k), 256, 0, st, b, len);
+  }
+  // (quotient exponents [lo, lo + len - 2]: z^{-1-j} = (z^-1)^{1 + j}; the launch also writes f(z) = the last prefix.  A polynomial of
+  // ONE coefficient has an empty quotient: the launch then only writes f(z))
+  const long qn = len > 1 ? len - 1 : 1;
+  const int per2 = scale_per(qn);
+  LAUNCH(k_scale_powers_b<2>, dim3((unsigned)ceil_div(qn, 256L * per2), k), 256, 0, st, b, len - 1 > 0 ? len - 1 : 0, 1 + lo, lo, len, per2);
 }
 
 // ---- prover-specific builders ----------------------------------------------------------------

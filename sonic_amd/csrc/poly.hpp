@@ -24,4 +24,20 @@ void fr_mul_scalar_enqueue(hipStream_t st, const Fr* a, const Fr* b, Fr* out);
 void scale_terms_enqueue(hipStream_t st, const int64_t* e, const Fr* c, long nt, const Fr* pair, Fr* out);
 void sparse_to_dense_enqueue(hipStream_t st, const int64_t* exps, const Fr* coeffs, long nt, long lo, Fr* dense);
 
+// Several openings of polynomials over ONE exponent range [lo, lo + len) as one launch per step (round 6): D_k[i] = poly_k[i] z_k^(lo + i),
+// inclusive prefix sums of every D_k, fz_k = the last prefix, q_k = the quotient (f_k(X) - f_k(z_k)) / (X - z_k) over [lo, lo + len - 2].
+// What poly_scale_powers / poly_prefix_sum / poly_quotient do for one opening in six launches, for up to OPEN_BATCH_MAX openings in
+// five: the openings of a group (r(X,1) at z and yz; s(X,y_j) at z_j and u; s(u,Y) at y_1 .. y_Q and v) share their polynomial.
+constexpr int OPEN_BATCH_MAX = 16;
+struct OpenBatch {
+  int k;
+  const Fr* poly[OPEN_BATCH_MAX];
+  Fr* D[OPEN_BATCH_MAX];            // len + 1 entries each
+  Fr* q[OPEN_BATCH_MAX];            // len + 1 entries each
+  Fr* tiles[OPEN_BATCH_MAX];        // ceil(len / 1024) + 1 entries each
+  const Fr* zpair[OPEN_BATCH_MAX];  // {z, z^-1}
+  Fr* fz[OPEN_BATCH_MAX];           // where f(z) goes (never null)
+};
+void open_batch_enqueue(hipStream_t st, const OpenBatch& b, long lo, long len);
+
 }  // namespace sonic

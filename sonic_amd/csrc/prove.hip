@@ -87,7 +87,10 @@ static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, con
   // profiles/r04_valu_budget.txt); the butterfly is one addition deep instead of ~2K + 30, the segments touch every bucket once.
   // Butterfly in EVERY group, measured again in round 5 (same box, alternating, ms per proof): streamed 33.76 / 33.91 against
   // 33.67 / 33.76, one at a time 34.75 / 34.98 against 34.21 / 34.50, n = 2^20 127.6 / 127.5 against 126.6 / 127.2 -- not adopted.
-  const bool tree = last || exposed;
+  // Small bucket sets (<= 2^17, round 6): always the butterfly.  Their running sums are pure latency -- K = 16 segments and the 256-lane
+  // window tree took 0.95 + 0.43 ms per group at 2^16 buckets, whatever ran beside them, against 0.12 + 0.12 ms for the butterfly
+  // (profiles/r06_small_proofs.txt) -- and a small proof has little accumulation to hide 1.4 ms under.
+  const bool tree = last || exposed || pl.NB <= (1 << 17);
   if (k > 1 && msm_can_batch(pl)) {
     // the group that finishes last reduces with nothing left to hide under: shortest chain instead of least work
     msm_plan_set_segment(pl, prove_segment(pl, k, last));
@@ -145,6 +148,43 @@ static MsmJob open_job_at_zero(hipStream_t st, const sonic_srs* srs, const Fr* p
   return MsmJob{srs_basis(srs, 0) + d, poly + 1, i1, slot};
 }
 
+// openPoly for several openings over one exponent range as one batched set of launches (poly.hip, open_batch_enqueue); the jobs
+// that are left to run come back in jobs_out, in the order of `ops`
+struct PendingOpen { const Fr* poly; long lo, len; const Fr* zp; Fr* fz; MsmSlot* slot; long slot_index; Scratch* sc; };
+static void open_jobs_batched(hipStream_t st, const sonic_srs* srs, const PendingOpen* ops, int k, int* d_flags, MsmJob* jobs_out) {
+  const long d = srs_d(srs);
+  for (int at = 0; at < k;) {
+    int e = at;
+    OpenBatch b;
+    memset(&b, 0, sizeof b);
+    while (e < k && e - at < OPEN_BATCH_MAX && ops[e].lo == ops[at].lo && ops[e].len == ops[at].len) {
+      Scratch& sc = *ops[e].sc;
+      const long len = ops[e].len;
+      sc.reserve(len);
+      sc.scan.ensure(sizeof(Fr) * (len / 1024 + 2));
+      const int i = e - at;
+      b.poly[i] = ops[e].poly; b.D[i] = sc.D.as<Fr>(); b.q[i] = sc.q.as<Fr>(); b.tiles[i] = sc.scan.as<Fr>();
+      b.zpair[i] = ops[e].zp; b.fz[i] = ops[e].fz ? ops[e].fz : sc.fz_discard.as<Fr>();
+      e++;
+    }
+    b.k = e - at;
+    const long lo = ops[at].lo, len = ops[at].len;
+    open_batch_enqueue(st, b, lo, len);
+    for (int i = at; i < e; i++) {
+      const long qn = len - 1;
+      long i0 = -d - lo, i1 = d - lo + 1;
+      if (i0 < 0) i0 = 0;
+      if (i1 > qn) i1 = qn;
+      if (i1 < i0) i1 = i0;
+      const Fr* q = ops[i].sc->q.as<Fr>();
+      flag_nonzero_enqueue(st, q, i0, d_flags, FLAG_SRS_INDEX);
+      flag_nonzero_enqueue(st, q + i1, qn - i1, d_flags, FLAG_SRS_INDEX);
+      jobs_out[i] = MsmJob{srs_basis(srs, 0) + (lo + i0 + d), q + i0, i1 - i0, ops[i].slot};
+    }
+    at = e;
+  }
+}
+
 static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
 }  // namespace sonic
@@ -158,6 +198,7 @@ using namespace sonic;
 struct Lane {
   hipStream_t st = nullptr;
   hipEvent_t done = nullptr;
+  hipEvent_t prep = nullptr;     // fused proofs: the lane's openings (evaluation, quotient) are queued; the proof's ONE chain waits for it
   MsmWorkspace ws;
   Scratch sc[MSM_MAX_JOBS];       // one per opening of the group in flight (grown on first use)
   MsmJob jobs[MSM_MAX_JOBS];
@@ -174,6 +215,15 @@ struct sonic_prover {
   bool have_assignment = false;
   DevBuf wL, wR, wO, cs, aL, aR, aO;        // Montgomery, resident across proofs
   Lane lanes[N_LANES];
+  // fused proofs (below): the proof's ONE chain runs on a stream of its own.  (Stream priorities -- the chain lowest, everything that builds
+  // polynomials and openings highest, so that the next streamed proof's preparation would get wave slots beside a running accumulation --
+  // were measured and made things WORSE on this runtime: n = 2^16 streamed 10.6 against 9.75 ms, n = 2^14 4.1 against 3.55,
+  // profiles/r06_ab_small.txt; SONIC_PROVE_PRIORITIES=1 still asks for them.)
+  Lane chain[2];
+  // ... and its bucket accumulation on a stream that leaves some of the chip's CUs alone (hipExtStreamCreateWithCUMask): see prove_enqueue
+  hipStream_t accum_st[2] = {nullptr, nullptr};
+  hipEvent_t accum_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  bool small_plan = false;                   // decided when the handle is made: the SRS plans 2^17 buckets or fewer for this n
   int next_lane = 0;
   const NttTables* ntt = nullptr;            // the device's shared tables for 2^log2m points (device_ntt_tables)
   DevBuf S, PAIRS, r1, sy0, su, pw, kpow, fa, fb, slots, frout, flags, tmp;
@@ -207,6 +257,23 @@ struct sonic_prover {
   // (i <= n), so n terms over A[i] + A[-i] and a Q-term MSM for Y^{n+1} .. Y^{n+Q} stand for its 2n + Q + 1 terms; the Q-term sum lands
   // in slot 7 + 5Q and the host adds it
   bool sym_on = false;
+  // Small proofs (round 6): ALL the MSMs of a proof as ONE batched kernel chain.  With 2^16 shared buckets and fewer (c <= 18: d < 2^20,
+  // n <= 2^16) a group of two or three MSMs is 2048-3072 one-thread-per-bucket waves -- one round of the chip's 2048 wave slots, half
+  // empty on its second -- and a proof is five such chains whose sorts, heavy-bucket launches and reductions (each ~15 launches of
+  // 5-20 us, plus ~1.4 ms of latency-bound running sums) queue behind each other's accumulation for wave slots: n = 2^14 measured 5.5 ms
+  // per proof for 1.8 ms of additions at the full-chip rate, n = 2^16 11.1 ms for 7.2 (profiles/r06_small_proofs.txt).  Fused, the lanes
+  // only prepare the openings (evaluation, prefix sums, quotient: they still run side by side); their jobs are collected here and run as
+  // one chain of up to MSM_MAX_JOBS jobs on the t lane: one sort, ONE accumulation launch that keeps every wave slot filled until its
+  // tail, one butterfly over all bucket sets.  Larger plans (2^19 buckets per set) fill the chip per group and keep the lanes
+  // (packing their groups was measured slower in round 3).  SONIC_PROVE_FUSED=0 / 1: never / whenever the plan batches.
+  bool fused = false;
+  std::vector<MsmJob> fused_jobs;
+  std::vector<std::unique_ptr<Scratch>> fused_sc;      // one per opening of the proof: a quotient lives until the chain has read it
+  size_t fused_sc_next = 0;
+  Scratch& fused_scratch() {
+    if (fused_sc_next == fused_sc.size()) fused_sc.emplace_back(new Scratch());
+    return *fused_sc[fused_sc_next++];
+  }
   // SONIC_PROVE_GRAPH=1 (read when the handle is made): capture the enqueue of the second proof and replay it.  Off by default:
   // on ROCm 7.2 the replay of this ~220-node, 7-stream graph is slower than the direct launches (n = 2^10: 9.0 vs 4.9 ms per proof,
   // n = 2^14: 9.6 vs 6.5 ms).
@@ -255,7 +322,10 @@ struct sonic_prover {
     return l;
   }
   ~sonic_prover() {
-    for (auto& l : lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); }
+    for (auto& l : lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); if (l.prep) (void)hipEventDestroy(l.prep); }
+    for (auto& l : chain) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); if (l.prep) (void)hipEventDestroy(l.prep); }
+    for (hipStream_t s_ : accum_st) if (s_) (void)hipStreamDestroy(s_);
+    for (auto& pr : accum_ev) for (hipEvent_t e : pr) if (e) (void)hipEventDestroy(e);
     for (auto& r : runs) if (r.masked_ev) (void)hipEventDestroy(r.masked_ev);
     for (hipEvent_t e : {ev_r1, ev_sy0, ev_t, ev_su}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_syj) if (e) (void)hipEventDestroy(e);
@@ -341,8 +411,20 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   std::unique_ptr<sonic_prover> p(new sonic_prover());
   p->srs = srs; p->n = n; p->Q = Q;
   p->device = srs_device(srs);
-  HIP_OK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&p->ts, hipStreamNonBlocking));
+  {
+    const MsmPlan probe = srs_msm_plan(srs, 3 * n);
+    p->small_plan = msm_can_batch(probe) && probe.NB <= (1 << 17);
+  }
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);        // (numerically lowest = highest priority)
+  const char* pe = getenv("SONIC_PROVE_PRIORITIES");
+  const bool use_prio = p->small_plan && pe && atoi(pe) == 1 && prio_low != prio_high;
+  auto mkstream = [&](hipStream_t* s, int prio) {
+    if (use_prio) HIP_OK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio));
+    else HIP_OK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  };
+  mkstream(&p->st, prio_high);
+  mkstream(&p->ts, prio_high);
   hipStream_t st = p->st;
   p->flags.alloc(8);
   int rc_c = prover_load_circuit(p.get(), wL, wR, wO, cs);
@@ -382,8 +464,28 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   for (auto& e : p->ev_syj) mkev(&e);
   // MSM workspaces and opening scratch grow on first use: every proof maps the same group of MSMs to the same lane
   for (auto& l : p->lanes) {
-    HIP_OK(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+    mkstream(&l.st, prio_high);
     mkev(&l.done);
+    mkev(&l.prep);
+  }
+  if (p->small_plan) {
+    for (auto& l : p->chain) {
+      mkstream(&l.st, prio_low);
+      mkev(&l.done);
+    }
+    // SONIC_ACCUM_CU_RESERVE=R: the accumulation's stream may use all but R of the device's CUs (every (count / R)-th bit of the mask cleared)
+    const char* re = getenv("SONIC_ACCUM_CU_RESERVE");
+    const int reserve = re ? atoi(re) : 0;
+    hipDeviceProp_t prop;
+    if (reserve > 0 && hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 2 * reserve) {
+      const int ncu = prop.multiProcessorCount, every = ncu / reserve;
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      for (int cu = 0; cu < ncu; cu++) if (cu % every != every - 1) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+      for (int c = 0; c < 2; c++) {
+        if (hipExtStreamCreateWithCUMask(&p->accum_st[c], (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); p->accum_st[c] = nullptr; break; }
+        mkev(&p->accum_ev[c][0]); mkev(&p->accum_ev[c][1]);
+      }
+    }
   }
   HIP_OK(hipStreamSynchronize(st));
   *out = p.release();
@@ -484,7 +586,17 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     // 2^14 6.1-6.6 / 5.8-6.1).  SONIC_PROVE_SYM=0: never; =1: always (tests).  Not for a piece of a shared proof (the plan counts C's terms).
     const char* se = getenv("SONIC_PROVE_SYM");
     const int mode = se ? atoi(se) : -1;
-    p->sym_on = mode != 0 && (mode == 1 || p->n >= (1L << 17)) && p->share_world <= 1 && srs_sym(p->srs).p != nullptr;
+    // (round 6: from n = 2^16 -- a proof of that size is one fused chain now and the Q-term MSM runs beside it: streamed 10.40-10.45 against
+    // 10.52-10.66 ms, profiles/r06_ab_small.txt)
+    p->sym_on = mode != 0 && (mode == 1 || p->n >= (1L << 16)) && p->share_world <= 1 && srs_sym(p->srs).p != nullptr;
+  }
+  {
+    const MsmPlan probe = srs_msm_plan(srs, 3 * n);
+    const char* fe = getenv("SONIC_PROVE_FUSED");
+    const int mode = fe ? atoi(fe) : -1;
+    p->fused = mode != 0 && p->small_plan && msm_can_batch(probe) && p->share_world <= 1;
+    p->fused_jobs.clear();
+    p->fused_sc_next = 0;
   }
   const int KS = p->sym_on ? K + (int)Q + 1 : K + ((p->prepared || p->runs_on) ? (int)Q : 0);        // + the second halves of the S_j and of C
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
@@ -556,9 +668,20 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // (packing consecutive groups into ONE batched chain -- fewer, wider chains -- was measured in round 3 and removed in round 5: n = 2^18
   // 35.9 / 38.9 ms streamed / one at a time packed against 35.0 / 35.9: the chains of one proof overlap less)
   std::vector<std::function<void()>> after_flush;       // small MSMs that use the lane's workspace after the batch (stream order)
+  // the openings of the group that is being assembled: evaluated and divided together when the group is flushed
+  std::vector<PendingOpen> pend;
+  auto issue_opens = [&] {
+    if (pend.empty()) return;
+    MsmJob oj[MSM_MAX_JOBS];
+    open_jobs_batched(cur->st, srs, pend.data(), (int)pend.size(), flags, oj);
+    for (size_t i = 0; i < pend.size(); i++) if (my_piece(oj[i], pend[i].slot_index)) cur->jobs[cur->njobs++] = oj[i];
+    pend.clear();
+  };
   auto flush_now = [&](bool last = false) {
     if (!cur) return;
-    run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last, /*exposed=*/p->share_world >= 4);
+    issue_opens();
+    if (p->fused) p->fused_jobs.insert(p->fused_jobs.end(), cur->jobs, cur->jobs + cur->njobs);      // run at the end, as one chain
+    else run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last, /*exposed=*/p->share_world >= 4);
     cur->njobs = 0;
     for (auto& f : after_flush) f();
     after_flush.clear();
@@ -568,9 +691,10 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     cur = &p->pick(e); cur->njobs = 0;
   };
   auto flush_group = [&](bool last = false) { flush_now(last); };
+  auto full = [&] { return cur->njobs + (int)pend.size() == MSM_MAX_JOBS; };
   auto commit = [&](int ph, const Fr* poly, long lo, long len, long maxm, long slot) {
     if (!on(ph) || !own(slot)) return;
-    if (cur->njobs == MSM_MAX_JOBS) flush_now();
+    if (full()) flush_now();
     MsmJob job = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
     if (my_piece(job, slot)) cur->jobs[cur->njobs++] = job;
   };
@@ -579,7 +703,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // main stream, beside this lane's batch -- adds c (ps[b] - ps[a - 1]) per run
   auto commit_runs = [&](int ph, const Fr* poly, long lo, long len, long maxm, long slot, long j) {
     if (!on(ph) || !own(slot)) return;
-    if (cur->njobs == MSM_MAX_JOBS) flush_now();
+    if (full()) flush_now();
     MsmJob job = commit_job(cur->st, srs, poly, lo, len, maxm, &slots[slot], flags);
     const long ntiles = job.n / RUN_TILE;
     if (ntiles > 0) {
@@ -603,11 +727,10 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // needs the prefix sums anyway), the rank whose piece starts at term 0 reports it
   auto open = [&](int ph, const Fr* poly, long lo, long len, const Fr* zp, long fr, long slot) {
     if (!on(ph) || !own(slot)) return;
-    if (cur->njobs == MSM_MAX_JOBS) flush_now();
-    Scratch& sc = cur->sc[cur->njobs];
-    MsmJob job = open_job(cur->st, srs, sc, poly, lo, len, zp, fr >= 0 ? &frout[fr] : nullptr, &slots[slot], flags);
+    if (full()) flush_now();
+    Scratch& sc = p->fused ? p->fused_scratch() : cur->sc[cur->njobs + (int)pend.size()];
+    pend.push_back(PendingOpen{poly, lo, len, zp, fr >= 0 ? &frout[fr] : nullptr, &slots[slot], slot, &sc});
     if (fr >= 0 && first_piece(slot)) p->fr_valid[(size_t)fr] = 1;
-    if (my_piece(job, slot)) cur->jobs[cur->njobs++] = job;
   };
   Fr* sy = p->sy0.as<Fr>();
   // ---- all polynomials first (small kernels; queued behind a bucket accumulation they would each wait ~0.5 ms for CUs) ----
@@ -707,7 +830,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   if (need_su) {
     begin_group(p->ev_su);
     if (p->sym_on && on(PH_HSCW) && own(6 + 4 * Q)) {                                  // C             :52, over the symmetric sums
-      if (cur->njobs == MSM_MAX_JOBS) flush_now();
+      if (full()) flush_now();
       MsmJob job = commit_job(cur->st, srs, su, u_lo, u_len, d, &slots[6 + 4 * Q], flags);      // (the index checks of the whole range)
       job.points = srs_sym(srs) + (d + 1); job.scalars = su + (n + 1); job.n = n;               // exponents 1 .. n: c_i (A[i] + A[-i])
       p->slot_ran[(size_t)(6 + 4 * Q)] = 1;
@@ -727,7 +850,26 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     open(PH_OPEN, t, t_lo, t_len, pZ, -1, 4);                                          // W_t          :81
     flush_group(true);
   }
+  if (p->fused && !p->fused_jobs.empty()) {
+    // the proof's chain(s): every lane has queued its openings by now; chunks of at most MSM_MAX_JOBS jobs (one chunk up to Q = 2),
+    // on the two chain streams in turn so that two chunks overlap like two groups did
+    for (auto& l : p->lanes) HIP_OK(hipEventRecord(l.prep, l.st));
+    const int total = (int)p->fused_jobs.size();
+    const int nchunks = (total + MSM_MAX_JOBS - 1) / MSM_MAX_JOBS, per = (total + nchunks - 1) / nchunks;
+    for (int c = 0, at = 0; c < nchunks; c++, at += per) {
+      Lane& cl = p->chain[c & 1];
+      if (c < 2) for (auto& l : p->lanes) HIP_OK(hipStreamWaitEvent(cl.st, l.prep, 0));
+      const int k = std::min(per, total - at);
+      long nmax = 0;
+      for (int j = 0; j < k; j++) nmax = std::max(nmax, p->fused_jobs[(size_t)(at + j)].n);
+      MsmPlan pl = srs_msm_plan(srs, nmax);
+      pl.tree = true;
+      if (p->accum_st[c & 1]) { pl.accum_stream = p->accum_st[c & 1]; pl.accum_ev[0] = p->accum_ev[c & 1][0]; pl.accum_ev[1] = p->accum_ev[c & 1][1]; }
+      msm_enqueue_batch(cl.st, cl.ws, pl, &p->fused_jobs[(size_t)at], k, true);
+    }
+  }
   for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
+  if (p->fused) for (auto& l : p->chain) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   Fr* frstd = p->frstd.as<Fr>();
   HIP_OK(hipMemcpyAsync(frstd, frout, sizeof(Fr) * (3 + 2 * Q), hipMemcpyDeviceToDevice, ms));
   fr_from_mont_enqueue(ms, frstd, 3 + 2 * Q);
@@ -1437,7 +1579,6 @@ int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t*
 // threads inside sonic_prove on one GPU each take a parked shell or make one; at most ONE_SHOT_SHELLS stay parked per device.
 }  // extern "C"
 namespace {
-struct OneShotShell { const sonic_srs* srs; sonic_prover* p; };
 constexpr size_t ONE_SHOT_SHELLS = 4;
 }
 namespace sonic {
@@ -1455,6 +1596,26 @@ void drop_one_shot_of(const sonic_srs* s) {
 }
 }
 extern "C" {
+// frees the parked one-shot shells of every device this process has used (or of one device: device >= 0).  A parked shell holds all the
+// workspaces of a proof of its shape -- several GB at n = 2^20 -- until another shape evicts it or its SRS is freed; a host that has
+// finished a burst of sonic_prove / sonic_prove_many calls gives the memory back with this.  Returns the number of shells freed.
+int sonic_one_shot_trim(int device) {
+  int freed = 0;
+  try {
+    int ndev = 0;
+    if (sonic_device_count(&ndev) != SONIC_OK) return 0;
+    for (int d = 0; d < ndev; d++) {
+      if (device >= 0 && d != device) continue;
+      DeviceScope scope(d);
+      DeviceCtx& c = scope.ctx();
+      std::vector<void*> gone;
+      { std::lock_guard<std::mutex> g(c.one_shot_mu); gone.swap(c.one_shot); }
+      for (void* v : gone) { OneShotShell* sh = static_cast<OneShotShell*>(v); delete sh->p; delete sh; freed++; }
+    }
+  } catch (const HipFail&) {}
+  return freed;
+}
+
 int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
                 const uint8_t* cs, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript,
                 uint8_t* out_proof) {

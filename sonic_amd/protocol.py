@@ -381,12 +381,20 @@ def prove(srs: SRS, assignment: Assignment, circuit: ArithCircuit, transcript: O
         raise _lib.SonicError(1, f"Parameter d is not large enough: {srs.srsD} should be greater than {7 * n}")
     if transcript is None:
         transcript = draw_transcript(Q, rng)
-    p = Prover(srs, circuit, prepare=False)   # one proof: committing the constraint rows first would only add MSMs
-    try:
-        p.set_assignment(assignment)
-        raw = p.prove_bytes(transcript)
-    finally:
-        p.close()
+    # the one-shot entry point (sonic_prove): circuit, assignment and transcript as host buffers, like the reference's call; the library
+    # parks the handle's shell (streams, workspaces, twiddle tables) for the next call of the same shape -- making and freeing a handle
+    # per call cost ~7 ms of stream / pinned-memory set-up around a 2-ms proof at the reference's own benchmark sizes
+    wL, wR, wO, cs, n_c, Q_c = _circuit_arrays(circuit)
+    aL, aR, aO = fr_array(assignment.aL), fr_array(assignment.aR), fr_array(assignment.aO)
+    if n_c != n or aL.shape[0] != n or aR.shape[0] != n or aO.shape[0] != n:
+        raise ValueError("assignment and weight rows differ in length")
+    tr = fr_array(transcript)
+    if tr.shape[0] != 8 + 2 * Q:
+        raise ValueError(f"transcript needs 8 + 2Q = {8 + 2 * Q} elements")
+    out = C.create_string_buffer(_lib.lib().sonic_proof_size(Q))
+    _lib.check(_lib.lib().sonic_prove(srs._h, n, Q, wL.ctypes.data, wR.ctypes.data, wO.ctypes.data, cs.ctypes.data,
+                                      aL.ctypes.data, aR.ctypes.data, aO.ctypes.data, tr.ctypes.data, out))
+    raw = out.raw
     t = [int(v) % R_MODULUS for v in transcript]
     oracle = RndOracle(t[4], t[5], list(zip(t[6:6 + Q], t[6 + Q:6 + 2 * Q])))
     return Proof.from_bytes(raw, Q), oracle

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-O=gpurun_out/r06_diag1; mkdir -p $O
+O=gpurun_out/r06_diag3; mkdir -p $O
 for lg in 14 16; do
   rocprofv3 --kernel-trace --output-format csv -d $O/solo$lg -o t -- python3 bench.py --log2n $lg --steps 3 --warmup 2 --no-cpu --no-pipeline --prove-only --strong-log2n 0 > $O/solo$lg.json 2> $O/solo$lg.err
   python3 tools/timeline.py $(find $O/solo$lg -name "*kernel_trace.csv" | head -1) 40 > $O/timeline_solo$lg.txt 2>&1
