@@ -342,7 +342,9 @@ sonic_srs* srs_alloc(int64_t d) {
   // (only with the full tables: the job over them shares a batched chain with jobs over the bases)
   (void)hipMemGetInfo(&free_b, &total_b);
   const char* senv = getenv("SONIC_SRS_SYM");
-  if (!(senv && atoi(senv) == 0) && W > 1 && !endo && (size_t)SONIC_SRS_POINT_BYTES * n * W <= free_b / 4) s->gs.alloc((size_t)SONIC_SRS_POINT_BYTES * n * W);
+  // (round 6: d + 1 slots per window -- exponents 0 .. d -- instead of a whole basis of 2d + 1)
+  const size_t sym_bytes = (size_t)SONIC_SRS_POINT_BYTES * (size_t)(d + 1) * W;
+  if (!(senv && atoi(senv) == 0) && W > 1 && !endo && sym_bytes <= free_b / 4) s->gs.alloc(sym_bytes);
   return s;
 }
 PointArrayMut srs_sym_mut(sonic_srs* s) { return PointArrayMut{s->gs.as<char>(), SONIC_SRS_POINT_BYTES}; }
@@ -460,7 +462,10 @@ int sonic_srs_get_points(const sonic_srs_t* srs, int basis, int64_t e0, int64_t 
   DevBuf raw(96 * n);
   if (basis == SONIC_BASIS_ALPHA_SYM) {        // diagnostic: the symmetric sums of the alpha basis (srs_build_sym; entries e <= 0 are empty)
     if (!srs->gs.p) { set_error("sonic_srs_get_points: this SRS holds no symmetric sums"); return SONIC_ERR_INVALID_ARG; }
-    LAUNCH(k_points_to_bytes, ceil_div(n, 256), 256, 0, st, srs_sym(srs) + (e0 + srs->d), raw.as<uint8_t>(), (long)n);
+    // (the table holds exponents 0 .. d: slot 0 and everything below it read as the empty sum)
+    HIP_OK(hipMemsetAsync(raw.p, 0, 96 * n, st));
+    const int64_t lo = e0 < 0 ? 0 : e0, hi = e0 + n;              // exponents [lo, hi) are in the table
+    if (hi > lo) LAUNCH(k_points_to_bytes, ceil_div(hi - lo, 256), 256, 0, st, srs_sym(srs) + lo, raw.as<uint8_t>() + 96 * (lo - e0), (long)(hi - lo));
     HIP_OK(hipMemcpyAsync(out, raw.p, 96 * n, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     return SONIC_OK;

@@ -194,6 +194,7 @@ struct MsmBatchDev {
   uint32_t tile0[MSM_MAX_JOBS + 1];
   const char* points[MSM_MAX_JOBS];
   uint32_t pt_stride;                    // bytes between the points of every job (PointArray)
+  long tstride[MSM_MAX_JOBS];            // points between a job's window tables (0: no tables)
   const Fr* scalars[MSM_MAX_JOBS];
   long n[MSM_MAX_JOBS];
   MsmSlot* slot[MSM_MAX_JOBS];
@@ -562,7 +563,7 @@ __device__ __forceinline__ size_t entry_point(uint32_t e, long stride) {
 
 __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
                                                       const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
-                                                      long stride, uint32_t nbuckets, uint32_t heavy_t,
+                                                      uint32_t nbuckets, uint32_t heavy_t,
                                                       G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nbuckets) return;
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
   const uint32_t beg = off[b], end = off[b + 1];
   const uint32_t cnt = end - beg;
   const PointArray pts{batch.points[b / jobstride], batch.pt_stride};
+  const long stride = batch.tstride[b / jobstride];
   if (cnt > heavy_t) {
     const uint32_t h = atomicAdd(&hm->n_heavy, 1u);
     hrecs[h].bucket = b;
@@ -624,7 +626,7 @@ __device__ __forceinline__ uint32_t heavy_scan(uint32_t v, uint32_t* wsum, uint3
 struct HeavyWork { uint32_t bucket, skip, len, slot; };     // entries [off[bucket] + skip, + len) -> partial[slot]
 
 __global__ __launch_bounds__(HEAVY_THREADS, 1) void k_heavy_accum(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
-                                                     const uint32_t* __restrict__ off, long stride, const HeavyMeta* hm,
+                                                     const uint32_t* __restrict__ off, const HeavyMeta* hm,
                                                      HeavyRec* hrecs, G1XYZZ* __restrict__ partial) {
   constexpr int HALF = HEAVY_THREADS / 2;
   __shared__ G1XYZZ sh[HALF];                // 48 KB: the upper half of the workgroup hands its sums to the lower half first
@@ -664,6 +666,7 @@ __global__ __launch_bounds__(HEAVY_THREADS, 1) void k_heavy_accum(const MsmBatch
     for (uint32_t wi = 0; wi < nw; wi++) {
       const HeavyWork wk = work[wi];
       const PointArray pts{batch.points[wk.bucket / jobstride], batch.pt_stride};
+      const long stride = batch.tstride[wk.bucket / jobstride];
       const uint32_t beg = off[wk.bucket] + wk.skip, end_e = beg + wk.len;
       G1XYZZ acc = G1XYZZ::inf();
       if (beg + threadIdx.x < end_e) {
@@ -1068,8 +1071,8 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
       Fr* s1 = halves; Fr* s2 = halves + jobs[j].n;
       halves += 2 * jobs[j].n;
       if (jobs[j].n > 0) LAUNCH(k_endo_split, ceil_div(jobs[j].n, 256), 256, 0, st, jobs[j].scalars, jobs[j].n, (int)scalars_mont, s1, s2);
-      split_jobs[2 * j] = MsmJob{jobs[j].points, s1, jobs[j].n, jobs[j].slot};
-      split_jobs[2 * j + 1] = MsmJob{jobs[j].points, s2, jobs[j].n, jobs[j].slot};
+      split_jobs[2 * j] = MsmJob{jobs[j].points, s1, jobs[j].n, jobs[j].slot, jobs[j].table_stride};
+      split_jobs[2 * j + 1] = MsmJob{jobs[j].points, s2, jobs[j].n, jobs[j].slot, jobs[j].table_stride};
     }
     jobs = split_jobs;
     k = 2 * k;
@@ -1095,6 +1098,7 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   for (int j = 0; j < k; j++) {
     if (jobs[j].points.stride != jobs[0].points.stride) throw std::runtime_error("msm_enqueue_batch: the jobs of a batch must share the point stride");
     batch.points[j] = jobs[j].points.p; batch.scalars[j] = jobs[j].scalars; batch.n[j] = jobs[j].n; batch.slot[j] = jobs[j].slot;
+    batch.tstride[j] = pl.table_stride == 0 ? 0 : (jobs[j].table_stride ? jobs[j].table_stride : pl.table_stride);
     batch.tile0[j + 1] = batch.tile0[j] + (uint32_t)ceil_div(jobs[j].n, PART_TILE);
     n_total += jobs[j].n;
   }
@@ -1159,22 +1163,12 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
          ws.order.as<uint32_t>());
   const int accum_block = (pl.accum_block == 64 || pl.accum_block == 128) ? pl.accum_block : 256;
-  hipStream_t sa = st;
-  if (pl.accum_stream && pl.accum_ev[0] && pl.accum_ev[1]) {
-    sa = pl.accum_stream;
-    HIP_OK(hipEventRecord(pl.accum_ev[0], st));
-    HIP_OK(hipStreamWaitEvent(sa, pl.accum_ev[0], 0));
-  }
-  LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, sa, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
-         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), pl.table_stride, (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs);
-  LAUNCH(k_heavy_accum, HEAVY_GRID, HEAVY_THREADS, 0, sa, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
-         pl.table_stride, (const HeavyMeta*)hm, hrecs, ws.heavy_partial.as<G1XYZZ>());
-  LAUNCH(k_heavy_finish, HEAVY_GRID / 2, 64, 0, sa, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
+  LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
+         (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs);
+  LAUNCH(k_heavy_accum, HEAVY_GRID, HEAVY_THREADS, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
+         (const HeavyMeta*)hm, hrecs, ws.heavy_partial.as<G1XYZZ>());
+  LAUNCH(k_heavy_finish, HEAVY_GRID / 2, 64, 0, st, (const HeavyMeta*)hm, (const HeavyRec*)hrecs,
          (const G1XYZZ*)ws.heavy_partial.as<G1XYZZ>(), buckets);
-  if (sa != st) {
-    HIP_OK(hipEventRecord(pl.accum_ev[1], sa));
-    HIP_OK(hipStreamWaitEvent(st, pl.accum_ev[1], 0));
-  }
   if (ext_buckets) return;                   // the caller reduces the buckets (msm_reduce_slices_enqueue, possibly on another rank)
   const int sets = k * pl.Wb;
   if ((pl.tree && pl.Wb == 1 && pl.NB >= 4) || pl.endo) {
@@ -1209,29 +1203,6 @@ __global__ __launch_bounds__(256, 1) void k_sum_slices(const G1XYZZ* __restrict_
   out[i] = acc;
 }
 
-// The same with TWO lanes per bucket (round 6): lane j adds slices j, j + 2, .. and the pair folds its two sums with one whole-point exchange
-// over DPP (no LDS): 4 additions deep at k = 8 instead of 7 and twice the waves -- 65536 buckets are one wave per SIMD otherwise, where a
-// wave's dependent instructions leave half of the issue slots empty.  8 additions of issue per bucket instead of 7.  (FOUR lanes per bucket --
-// 3 additions deep, 12 of issue -- measured slower than one: 0.211 against 0.149 ms at 65536 buckets x 8 slices, profiles/r06_msm_strong.txt;
-// two waves per SIMD already fill the issue slots, and beyond that the extra additions are simply more work.)
-template <int CTRL>
-__device__ __forceinline__ G1XYZZ g1_quad_perm(const G1XYZZ& p) {
-  G1XYZZ r;
-  r.x = fq_quad<CTRL>(p.x); r.y = fq_quad<CTRL>(p.y); r.zz = fq_quad<CTRL>(p.zz); r.zzz = fq_quad<CTRL>(p.zzz);
-  return r;
-}
-__global__ __launch_bounds__(256, 2) void k_sum_slices2(const G1XYZZ* __restrict__ slices, int k, long len, G1XYZZ* __restrict__ out) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long i = t >> 1;
-  const int j = (int)(t & 1);
-  if (i >= len) return;                                     // (whole pairs: len is a multiple of MSM_SLICE_QUANTUM)
-  G1XYZZ acc = j < k ? slices[(size_t)j * len + i] : G1XYZZ::inf();
-  for (int s = j + 2; s < k; s += 2) acc = g1_add(acc, slices[(size_t)s * len + i]);
-  constexpr int QP_SWAP1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);     // [1,0,3,2]
-  acc = g1_add(acc, g1_quad_perm<QP_SWAP1>(acc));            // both lanes: the bucket's sum
-  if (j == 0) out[i] = acc;
-}
-
 void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d_slices, int k, long len, long base, int c, MsmSlot* d_slot) {
   (void)c;
   if (k < 1 || len < 4 || len % MSM_SLICE_QUANTUM || base % MSM_SLICE_QUANTUM || base + len >= (1L << 31))
@@ -1245,9 +1216,10 @@ void msm_reduce_slices_enqueue(hipStream_t st, MsmWorkspace& ws, const G1XYZZ* d
   if (P > len) HIP_OK(hipMemsetAsync(ws.buckets.as<G1XYZZ>() + len, 0, (size_t)(P - len) * sizeof(G1XYZZ), st));
   // (a quad per bucket, and four lanes per bucket with an LDS tree, both measured slower at 65536 buckets x 8 slices -- 0.21 / 0.22 against
   // 0.15 ms: the kernel reads 100 MB once and is bound by that, not by its chain of 7 additions)
-  static const int two = getenv("SONIC_SUM_SLICES2") ? atoi(getenv("SONIC_SUM_SLICES2")) : 1;
-  if (two && k > 2) LAUNCH(k_sum_slices2, ceil_div(2 * len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
-  else LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
+  // (round 6: two and four lanes per bucket with the partial sums folded over DPP -- 4 and 3 additions deep instead of 7 -- measured 0.146 and
+  // 0.211 ms against 0.145-0.149: with every SIMD holding a wave the kernel is bound by the additions it issues, 7 per bucket at the least;
+  // profiles/r06_msm_strong.txt)
+  LAUNCH(k_sum_slices, ceil_div(len, 256), 256, 0, st, d_slices, k, len, ws.buckets.as<G1XYZZ>());
   MsmBatchDev b1;
   memset(&b1, 0, sizeof b1);
   b1.k = 1;

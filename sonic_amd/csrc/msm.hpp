@@ -29,11 +29,6 @@ struct MsmPlan {
   // wave slot without waiting for three more (k_bucket_accum 2.31-2.40 against 2.42-2.45 ms, MSM 2^20 streamed 3.22-3.24 against
   // 3.33-3.59 ms).
   int accum_block = 256;
-  // a second stream for the bucket accumulation alone (and the heavy-bucket kernels behind it): the chain's other kernels stay on the
-  // caller's stream, ordered with events.  prove.hip hands a stream here that may only use PART of the chip's CUs (fused proofs, streamed):
-  // the rest of the chip then belongs to whatever runs beside the accumulation
-  hipStream_t accum_stream = nullptr;
-  hipEvent_t accum_ev[2] = {nullptr, nullptr};     // (before, after) -- owned by the caller, used in stream order, so one pair serves every launch
   // reduce the shared bucket set by the bit-sum butterfly (log-depth, least work, ~4x the memory traffic) instead of running sums over
   // K-bucket segments (one pass over the buckets, a long dependent chain per segment).  The tree wins wherever the reduction is
   // exposed -- a stand-alone MSM, the last group of a proof, a rank's few pieces of a shared proof -- the segments where it hides under
@@ -89,7 +84,9 @@ void msm_enqueue(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, PointArray
 // differ in size, points and scalars; they share the plan (c, W, table stride).  k <= MSM_MAX_JOBS.
 constexpr int MSM_MAX_JOBS = 16;     // (16 since round 6: the 7 + 4Q MSMs of a Q = 2 proof as ONE chain, prove.hip `fused`)
 constexpr int MSM_ENDO_SLOT_OFFSET = 32;      // where the second half of an endomorphism pair sits in MsmSlot::win
-struct MsmJob { PointArray points; const Fr* scalars; long n; MsmSlot* slot; };      // the jobs of a batch share the point stride
+// (the jobs of a batch share the byte stride between points; table_stride != 0: this job's window tables are that many points apart instead
+// of the plan's -- the SRS's symmetric-sum tables hold d + 1 points per window where the bases hold 2d + 1)
+struct MsmJob { PointArray points; const Fr* scalars; long n; MsmSlot* slot; long table_stride = 0; };
 bool msm_can_batch(const MsmPlan& pl);
 // ext_buckets (k == 1, shared-bucket plan): the chain stops after the accumulation and leaves the NB bucket sums there
 // instead of reducing them -- the first half of an MSM whose buckets are sharded across ranks.

@@ -27,9 +27,11 @@ namespace sonic {
 constexpr int SCALE_PER = SONIC_SCALE_PER;
 // ... for arrays long enough to fill the chip with threads of that length.  A short array (n = 2^14: 49 K coefficients = 6 workgroups at
 // 32 per thread) runs as ONE dependent chain of 45 + 2 PER products on a few waves -- 80 us per launch, twenty launches on a proof's
-// critical path (profiles/r06_small_proofs.txt) -- so the elements per thread shrink until ~256 workgroups exist (never below 2).
+// critical path (profiles/r06_small_proofs.txt) -- so the elements per thread shrink until ~64 workgroups exist (never below 2).  Not more
+// workgroups than that: beside another proof's bucket accumulation (streamed proofs) wave slots come free at a few hundred workgroups
+// per millisecond, and a launch of 257 short workgroups took 1-2 ms to be handed all of them (profiles/r06_small_proofs.txt).
 static int scale_per(long n) {
-  long per = n / (256L * 256L);
+  long per = n / (256L * 64L);
   if (per > SCALE_PER) per = SCALE_PER;
   if (per < 2) per = 2;
   return (int)per;
@@ -76,6 +78,14 @@ void poly_quotient_enqueue(hipStream_t st, const Fr* prefix, Fr* q, long n, long
   // z^{-1-j} = (z^-1)^{1+j}: base z^-1 (inverse base z), first exponent 1 + lo
   const int per = scale_per(n - 1);
   LAUNCH(k_scale_powers<2>, ceil_div(n - 1, 256L * per), 256, 0, st, prefix, q, n - 1, 1 + lo, d_zinv, d_z, lo, n, per);
+}
+
+// Workgroups of an elementwise launch over `items` elements (256 threads each, grid-stride loops): short arrays get at most 64 fat
+// workgroups (see scale_per: a launch of many short workgroups waits for wave slots one by one beside a running accumulation); long ones
+// one element per thread, as before
+static unsigned elementwise_grid(long items) {
+  const long full = ceil_div(items, 256L);
+  return (unsigned)(items <= (1L << 19) && full > 64 ? 64 : (full > 0 ? full : 1));
 }
 
 // ---- inclusive prefix sums in Fr (tile = 1024) -----------------------------------------------
@@ -138,41 +148,53 @@ void poly_prefix_sum_enqueue(hipStream_t st, Fr* d, long n, DevBuf& tmp) {
 }
 
 // ---- the same three steps for several openings at once (blockIdx.y = opening) -----------------
+// Prefix sums over tiles of 256 * EPT coefficients (EPT = 4 or 16: a tile per workgroup, fewer and fatter workgroups for long arrays -- see
+// scale_per); the tile offsets are added by the quotient kernel as it reads the prefixes, so there is no separate "apply" pass.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_scale_powers_b(const OpenBatch b, long n, long e0, long lo_q, long nF, int PER) {
+__global__ __launch_bounds__(256) void k_scale_powers_b(const OpenBatch b, long n, long e0, long lo_q, long nF, int PER, int tile_log) {
   const int y = blockIdx.y;
   const long base = (long)blockIdx.x * (256 * PER) + threadIdx.x;
-  if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) *b.fz[y] = b.D[y][nF - 1];      // f(z): the last prefix
-  if (base >= n) return;
-  // MODE 0: D = poly * z^(e0 + i);  MODE 2: q = numerator(P) * (z^-1)^(e0 + i), P = D (the prefix sums), F = P[nF - 1]
+  // MODE 0: D = poly * z^(e0 + i);  MODE 2: q = numerator(P) * (z^-1)^(e0 + i), P = D + its tile's offset (the prefix sums), F = P[nF - 1]
   const Fr* __restrict__ in = MODE == 0 ? b.poly[y] : b.D[y];
+  const Fr* __restrict__ tiles = b.tiles[y];
   Fr* __restrict__ out = MODE == 0 ? b.D[y] : b.q[y];
+  Fr F;
+  if (MODE == 2) {
+    F = in[nF - 1];
+    if (((nF - 1) >> tile_log) > 0) F = fp_add(F, tiles[(nF - 1) >> tile_log]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *b.fz[y] = F;      // f(z): the last prefix
+  }
+  if (base >= n) return;
   const Fr x = MODE == 0 ? b.zpair[y][0] : b.zpair[y][1], xinv = MODE == 0 ? b.zpair[y][1] : b.zpair[y][0];
   const long e = e0 + base;
   Fr p = e >= 0 ? fp_pow_u64(x, (uint64_t)e) : fp_pow_u64(xinv, (uint64_t)(-e));
   const Fr step = fp_pow_u64(x, 256);
-  Fr F;
-  if (MODE == 2) F = in[nF - 1];
 #pragma unroll 1
   for (int k = 0; k < PER; k++) {
     const long i = base + (long)k * 256;
     if (i >= n) break;
     Fr v;
     if (MODE == 0) v = fp_mul(in[i], p);
-    else { Fr P = in[i]; v = fp_mul((lo_q + i >= 0) ? fp_sub(F, P) : fp_neg(P), p); }
+    else {
+      Fr P = in[i];
+      if ((i >> tile_log) > 0) P = fp_add(P, tiles[i >> tile_log]);
+      v = fp_mul((lo_q + i >= 0) ? fp_sub(F, P) : fp_neg(P), p);
+    }
     out[i] = v;
     p = fp_mul(p, step);
   }
 }
+template <int EPT>
 __global__ __launch_bounds__(256) void k_prefix_tiles_b(const OpenBatch b, long n) {
   __shared__ Fr sh[256];
   Fr* __restrict__ d = b.D[blockIdx.y];
-  const long base = (long)blockIdx.x * 1024 + threadIdx.x * 4;
-  Fr v[4], s = Fr::zero();
-  for (int k = 0; k < 4; k++) { v[k] = base + k < n ? d[base + k] : Fr::zero(); s = fp_add(s, v[k]); v[k] = s; }
+  const long base = (long)blockIdx.x * (256 * EPT) + threadIdx.x * EPT;
+  Fr s = Fr::zero();
+  // (two passes over the thread's EPT consecutive elements instead of EPT live values: 16 x 8 registers would not leave room for the scan)
+  for (int k = 0; k < EPT; k++) if (base + k < n) s = fp_add(s, d[base + k]);
   Fr incl = block_inclusive_scan_fr(s, sh);
-  Fr excl = fp_sub(incl, s);
-  for (int k = 0; k < 4; k++) if (base + k < n) d[base + k] = fp_add(v[k], excl);
+  Fr run = fp_sub(incl, s);
+  for (int k = 0; k < EPT; k++) if (base + k < n) { run = fp_add(run, d[base + k]); d[base + k] = run; }
   if (threadIdx.x == 255) b.tiles[blockIdx.y][blockIdx.x] = incl;
 }
 __global__ __launch_bounds__(256) void k_prefix_top_b(const OpenBatch b, long ntiles) {
@@ -192,30 +214,29 @@ __global__ __launch_bounds__(256) void k_prefix_top_b(const OpenBatch b, long nt
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void k_prefix_apply_b(const OpenBatch b, long n) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const long tile = i >> 10;
-  if (tile == 0) return;
-  Fr* __restrict__ d = b.D[blockIdx.y];
-  d[i] = fp_add(d[i], b.tiles[blockIdx.y][tile]);
+// fz_k = the last prefix, for a batch whose quotients are not wanted (an evaluation only)
+__global__ void k_last_prefix_b(const OpenBatch b, long len, int tile_log) {
+  const int y = blockIdx.x;
+  Fr F = b.D[y][len - 1];
+  if (((len - 1) >> tile_log) > 0) F = fp_add(F, b.tiles[y][(len - 1) >> tile_log]);
+  *b.fz[y] = F;
 }
-void open_batch_enqueue(hipStream_t st, const OpenBatch& b, long lo, long len) {
+void open_batch_enqueue(hipStream_t st, const OpenBatch& b, long lo, long len, bool quotient) {
   if (b.k <= 0 || len <= 0) return;
   const unsigned k = (unsigned)b.k;
+  const int tile_log = len >= 65536 ? 12 : 10;           // 4096- or 1024-coefficient tiles (OpenBatch::tiles holds len / 1024 + 2 entries)
   const int per = scale_per(len);
-  LAUNCH(k_scale_powers_b<0>, dim3((unsigned)ceil_div(len, 256L * per), k), 256, 0, st, b, len, lo, 0L, 0L, per);
-  const long ntiles = (len + 1023) / 1024;
-  LAUNCH(k_prefix_tiles_b, dim3((unsigned)ntiles, k), 256, 0, st, b, len);
-  if (ntiles > 1) {
-    LAUNCH(k_prefix_top_b, k, 256, 0, st, b, ntiles);
-    LAUNCH(k_prefix_apply_b, dim3((unsigned)ceil_div(len, 256), k), 256, 0, st, b, len);
-  }
+  LAUNCH(k_scale_powers_b<0>, dim3((unsigned)ceil_div(len, 256L * per), k), 256, 0, st, b, len, lo, 0L, 0L, per, tile_log);
+  const long ntiles = (len + (1L << tile_log) - 1) >> tile_log;
+  if (tile_log == 12) LAUNCH(k_prefix_tiles_b<16>, dim3((unsigned)ntiles, k), 256, 0, st, b, len);
+  else LAUNCH(k_prefix_tiles_b<4>, dim3((unsigned)ntiles, k), 256, 0, st, b, len);
+  if (ntiles > 1) LAUNCH(k_prefix_top_b, k, 256, 0, st, b, ntiles);
+  if (!quotient) { LAUNCH(k_last_prefix_b, k, 1, 0, st, b, len, tile_log); return; }
   // (quotient exponents [lo, lo + len - 2]: z^{-1-j} = (z^-1)^{1 + j}; the launch also writes f(z) = the last prefix.  A polynomial of
   // ONE coefficient has an empty quotient: the launch then only writes f(z))
   const long qn = len > 1 ? len - 1 : 1;
   const int per2 = scale_per(qn);
-  LAUNCH(k_scale_powers_b<2>, dim3((unsigned)ceil_div(qn, 256L * per2), k), 256, 0, st, b, len - 1 > 0 ? len - 1 : 0, 1 + lo, lo, len, per2);
+  LAUNCH(k_scale_powers_b<2>, dim3((unsigned)ceil_div(qn, 256L * per2), k), 256, 0, st, b, len - 1 > 0 ? len - 1 : 0, 1 + lo, lo, len, per2, tile_log);
 }
 
 // ---- prover-specific builders ----------------------------------------------------------------
@@ -223,19 +244,19 @@ void open_batch_enqueue(hipStream_t st, const OpenBatch& b, long lo, long len) {
 // (Constraints.hs:23-31, Protocol.hs:58-62).  Inputs Montgomery.
 __global__ __launch_bounds__(256) void k_build_r1(const Fr* __restrict__ aL, const Fr* __restrict__ aR, const Fr* __restrict__ aO,
                                                   const Fr* __restrict__ cns, long n, Fr* __restrict__ r1) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into [-2n-4, n]
   const long len = 3 * n + 5;
-  if (i >= len) return;
-  const long e = i - (2 * n + 4);
-  Fr v = Fr::zero();
-  if (e > 0) v = aL[e - 1];
-  else if (e < 0 && e >= -n) v = aR[-e - 1];
-  else if (e < -n && e >= -2 * n) v = aO[-e - n - 1];
-  else if (e < -2 * n) v = cns[-e - 2 * n - 1];
-  r1[i] = v;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256) {   // index into [-2n-4, n]
+    const long e = i - (2 * n + 4);
+    Fr v = Fr::zero();
+    if (e > 0) v = aL[e - 1];
+    else if (e < 0 && e >= -n) v = aR[-e - 1];
+    else if (e < -n && e >= -2 * n) v = aO[-e - n - 1];
+    else if (e < -2 * n) v = cns[-e - 2 * n - 1];
+    r1[i] = v;
+  }
 }
 void build_r1_enqueue(hipStream_t st, const Fr* aL, const Fr* aR, const Fr* aO, const Fr* cns, long n, Fr* r1) {
-  LAUNCH(k_build_r1, ceil_div(3 * n + 5, 256), 256, 0, st, aL, aR, aO, cns, n, r1);
+  LAUNCH(k_build_r1, elementwise_grid(3 * n + 5), 256, 0, st, aL, aR, aO, cns, n, r1);
 }
 
 // s(X,y) over [-n, 2n] given ypow[e + n] = y^e for e in [-n, n + Q]:
@@ -243,22 +264,23 @@ void build_r1_enqueue(hipStream_t st, const Fr* aL, const Fr* aR, const Fr* aO, 
 //   X^{i+n}: -y^i - y^-i + sum_q wO[q][i] y^{n+q}        (Constraints.hs:39-49, q = 1..Q)
 __global__ __launch_bounds__(256) void k_s_of_y(const Fr* __restrict__ wL, const Fr* __restrict__ wR, const Fr* __restrict__ wO,
                                                 const Fr* __restrict__ ypow, long n, long Q, Fr* __restrict__ s) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x + 1;   // 1..n
-  if (i > n) { if (i == n + 1) s[n] = Fr::zero(); return; }  // X^0 slot
-  Fr u = Fr::zero(), v = Fr::zero(), w = Fr::zero();
-  for (long q = 0; q < Q; q++) {
-    const Fr yq = ypow[2 * n + 1 + q];                       // y^{n+q+1}
-    u = fp_add(u, fp_mul(wL[q * n + i - 1], yq));
-    v = fp_add(v, fp_mul(wR[q * n + i - 1], yq));
-    w = fp_add(w, fp_mul(wO[q * n + i - 1], yq));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x + 1; i <= n + 1; i += (long)gridDim.x * 256) {   // 1..n
+    if (i > n) { s[n] = Fr::zero(); break; }                 // X^0 slot
+    Fr u = Fr::zero(), v = Fr::zero(), w = Fr::zero();
+    for (long q = 0; q < Q; q++) {
+      const Fr yq = ypow[2 * n + 1 + q];                     // y^{n+q+1}
+      u = fp_add(u, fp_mul(wL[q * n + i - 1], yq));
+      v = fp_add(v, fp_mul(wR[q * n + i - 1], yq));
+      w = fp_add(w, fp_mul(wO[q * n + i - 1], yq));
+    }
+    w = fp_sub(fp_sub(w, ypow[n + i]), ypow[n - i]);
+    s[n - i] = u;
+    s[n + i] = v;
+    s[2 * n + i] = w;
   }
-  w = fp_sub(fp_sub(w, ypow[n + i]), ypow[n - i]);
-  s[n - i] = u;
-  s[n + i] = v;
-  s[2 * n + i] = w;
 }
 void s_of_y_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* ypow, long n, long Q, Fr* s) {
-  LAUNCH(k_s_of_y, ceil_div(n + 1, 256), 256, 0, st, wL, wR, wO, ypow, n, Q, s);
+  LAUNCH(k_s_of_y, elementwise_grid(n + 1), 256, 0, st, wL, wR, wO, ypow, n, Q, s);
 }
 
 // s(X,Y) = sum_q Y^{n+q} P_q(X) + sum_i (-Y^i - Y^{-i}) X^{i+n}  with  P_q(X) = sum_i wL[q][i] X^{-i} + wR[q][i] X^i + wO[q][i] X^{i+n}
@@ -277,22 +299,25 @@ void weight_row_poly_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const F
 }
 // diag[i-1] = -(y^i + y^-i), i = 1..n (coefficients of X^{n+1..2n});  yq[q] = y^{n+1+q}
 __global__ __launch_bounds__(256) void k_s_diag_part(const Fr* __restrict__ ypow, long n, long Q, Fr* __restrict__ diag, Fr* __restrict__ yq) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t < n) diag[t] = fp_neg(fp_add(ypow[n + t + 1], ypow[n - t - 1]));
-  if (t < Q) yq[t] = ypow[2 * n + 1 + t];
+  const long m = n > Q ? n : Q;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < m; t += (long)gridDim.x * 256) {
+    if (t < n) diag[t] = fp_neg(fp_add(ypow[n + t + 1], ypow[n - t - 1]));
+    if (t < Q) yq[t] = ypow[2 * n + 1 + t];
+  }
 }
 void s_diag_part_enqueue(hipStream_t st, const Fr* ypow, long n, long Q, Fr* diag, Fr* yq) {
-  LAUNCH(k_s_diag_part, ceil_div(n > Q ? n : Q, 256), 256, 0, st, ypow, n, Q, diag, yq);
+  LAUNCH(k_s_diag_part, elementwise_grid(n > Q ? n : Q), 256, 0, st, ypow, n, Q, diag, yq);
 }
 
 // s(u,Y) over [-n, n+Q] given upow[e + n] = u^e for e in [-n, 2n]:
 //   Y^{+-i}: -u^{i+n};  Y^{n+q}: sum_i u^-i wL[q][i] + u^i wR[q][i] + u^{i+n} wO[q][i]   (Utils.hs:17-18)
 __global__ __launch_bounds__(256) void k_s_of_u_diag(const Fr* __restrict__ upow, long n, Fr* __restrict__ s) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x + 1;
-  if (i > n) { if (i == n + 1) s[n] = Fr::zero(); return; }
-  const Fr v = fp_neg(upow[2 * n + i]);
-  s[n - i] = v;
-  s[n + i] = v;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x + 1; i <= n + 1; i += (long)gridDim.x * 256) {
+    if (i > n) { s[n] = Fr::zero(); break; }
+    const Fr v = fp_neg(upow[2 * n + i]);
+    s[n - i] = v;
+    s[n + i] = v;
+  }
 }
 // grid (blocks, Q): partial[q * nblk + blk] = sum over the block's i
 __global__ __launch_bounds__(256) void k_s_of_u_rows(const Fr* __restrict__ wL, const Fr* __restrict__ wR, const Fr* __restrict__ wO,
@@ -321,20 +346,51 @@ __global__ __launch_bounds__(64) void k_s_of_u_finish(const Fr* __restrict__ par
   s[2 * n + 1 + q] = acc;
 }
 void s_of_u_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* upow, long n, long Q, Fr* s, DevBuf& tmp) {
-  LAUNCH(k_s_of_u_diag, ceil_div(n + 1, 256), 256, 0, st, upow, n, s);
+  LAUNCH(k_s_of_u_diag, elementwise_grid(n + 1), 256, 0, st, upow, n, s);
   int nblk = ceil_div(n, 256);
   if (nblk > 256) nblk = 256;
+  if (n <= (1L << 17) && nblk > 64) nblk = 64;
   tmp.ensure(sizeof(Fr) * (size_t)nblk * Q);
   LAUNCH(k_s_of_u_rows, dim3(nblk, (unsigned)Q), 256, 0, st, wL, wR, wO, upow, n, tmp.as<Fr>());
   LAUNCH(k_s_of_u_finish, ceil_div(Q, 64), 64, 0, st, (const Fr*)tmp.as<Fr>(), nblk, n, Q, s);
 }
 
+// The two operands of t(X,y)'s product (Constraints.hs:56-65 with Y := y) in ONE launch: fa = r(X,1) and fb = r(X,y) + s(X,y), both over
+// M transform points from exponent r_lo, zero beyond their coefficients.  (Two memsets of M elements, a copy, a scale-by-powers and an
+// add-into before: five launches at the head of the longest dependent chain of a proof, each of which waits for wave slots when another
+// proof's accumulation is running.)
+__global__ __launch_bounds__(256) void k_t_operands(const Fr* __restrict__ r1, long r_len, long r_lo, const Fr* __restrict__ sy, long s_off, long s_len,
+                                                    const Fr* __restrict__ ypair, Fr* __restrict__ fa, Fr* __restrict__ fb, long M, int PER) {
+  const long base = (long)blockIdx.x * (256 * PER) + threadIdx.x;
+  if (base >= M) return;
+  Fr p = Fr::zero(), step = Fr::zero();
+  if (base < r_len) {                                      // (r(X,y) = c_e y^e on the diagonal: Utils.hs:20-21)
+    const Fr y = ypair[0], yinv = ypair[1];
+    const long e = r_lo + base;
+    p = e >= 0 ? fp_pow_u64(y, (uint64_t)e) : fp_pow_u64(yinv, (uint64_t)(-e));
+    step = fp_pow_u64(y, 256);
+  }
+#pragma unroll 1
+  for (int k = 0; k < PER; k++) {
+    const long i = base + (long)k * 256;
+    if (i >= M) break;
+    Fr a = Fr::zero(), b = Fr::zero();
+    if (i < r_len) { a = r1[i]; b = fp_mul(a, p); p = fp_mul(p, step); }
+    if (i >= s_off && i < s_off + s_len) b = fp_add(b, sy[i - s_off]);
+    fa[i] = a;
+    fb[i] = b;
+  }
+}
+void t_operands_enqueue(hipStream_t st, const Fr* r1, long r_len, long r_lo, const Fr* sy, long s_off, long s_len, const Fr* ypair, Fr* fa, Fr* fb, long M) {
+  const int per = scale_per(M);
+  LAUNCH(k_t_operands, ceil_div(M, 256L * per), 256, 0, st, r1, r_len, r_lo, sy, s_off, s_len, ypair, fa, fb, M, per);
+}
+
 // dst[off + i] += src[i]
 __global__ __launch_bounds__(256) void k_add_into(Fr* __restrict__ dst, const Fr* __restrict__ src, long n) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = fp_add(dst[i], src[i]);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = fp_add(dst[i], src[i]);
 }
-void add_into_enqueue(hipStream_t st, Fr* dst, const Fr* src, long n) { if (n > 0) LAUNCH(k_add_into, ceil_div(n, 256), 256, 0, st, dst, src, n); }
+void add_into_enqueue(hipStream_t st, Fr* dst, const Fr* src, long n) { if (n > 0) LAUNCH(k_add_into, elementwise_grid(n), 256, 0, st, dst, src, n); }
 
 // *slot -= sum_q cs[q] * ypow_nq[q]   (k(y), Constraints.hs:67-68), then flags[flag_bit] if *slot != 0
 __global__ __launch_bounds__(256) void k_sub_k_of_y(Fr* __restrict__ slot, const Fr* __restrict__ cs, const Fr* __restrict__ ypow_nq, long Q, int* flags, int flag_bit) {

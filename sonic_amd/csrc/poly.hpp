@@ -12,6 +12,7 @@ void weight_row_poly_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const F
 void s_diag_part_enqueue(hipStream_t st, const Fr* ypow, long n, long Q, Fr* diag, Fr* yq);
 void s_of_u_enqueue(hipStream_t st, const Fr* wL, const Fr* wR, const Fr* wO, const Fr* upow, long n, long Q, Fr* s, DevBuf& tmp);
 void add_into_enqueue(hipStream_t st, Fr* dst, const Fr* src, long n);
+void t_operands_enqueue(hipStream_t st, const Fr* r1, long r_len, long r_lo, const Fr* sy, long s_off, long s_len, const Fr* ypair, Fr* fa, Fr* fb, long M);
 void sub_k_of_y_enqueue(hipStream_t st, Fr* slot, const Fr* cs, const Fr* ypow_nq, long Q, int* flags, int flag_bit);
 void flag_nonzero_enqueue(hipStream_t st, const Fr* a, long n, int* flags, int bit);
 // runs of equal coefficients (poly.hip): tiles of RUN_TILE coefficients that hold one non-zero value are zeroed in `masked` and recorded;
@@ -38,6 +39,6 @@ struct OpenBatch {
   const Fr* zpair[OPEN_BATCH_MAX];  // {z, z^-1}
   Fr* fz[OPEN_BATCH_MAX];           // where f(z) goes (never null)
 };
-void open_batch_enqueue(hipStream_t st, const OpenBatch& b, long lo, long len);
+void open_batch_enqueue(hipStream_t st, const OpenBatch& b, long lo, long len, bool quotient = true);      // quotient = false: only the evaluations fz_k
 
 }  // namespace sonic

@@ -215,14 +215,25 @@ struct sonic_prover {
   bool have_assignment = false;
   DevBuf wL, wR, wO, cs, aL, aR, aO;        // Montgomery, resident across proofs
   Lane lanes[N_LANES];
+  // lanes in use: all of them, or -- a handle whose proofs are ONE chain (small_plan) -- SONIC_FUSED_LANES (default 3: two for the groups'
+  // openings, one for the t group's).  The runtime multiplexes a process's streams onto 8 hardware queues in creation order; two streamed
+  // handles with ten streams each put one handle's openings behind the OTHER handle's accumulation on a shared queue (in order: 7 ms late,
+  // profiles/r06_small_proofs.txt).  More hardware queues were measured and are worse (GPU_MAX_HW_QUEUES = 12 .. 32: +1 ms on a sequential
+  // n = 2^14 / 2^16 proof, profiles/r06_ab_queues.txt), so the handles use fewer streams instead.
+  int n_lanes = N_LANES;
+  // ... down to ONE lane by default (four streams per handle, eight for the two handles of a stream of proofs: no two share a queue): the
+  // groups' openings then go to the streams that are waiting anyway -- r(X,1)'s and s(u,Y)'s to the lane, the s(X,y_j) groups to the main
+  // stream behind the polynomials, t(X,y)'s to the transform's stream -- through two lanes that only borrow those streams.  Measured, ms per
+  // proof streamed / one at a time (profiles/r06_ab_lanes.txt): six lanes 9.35 / 10.5 at n = 2^16 and 3.37 / 3.85 at 2^14, three lanes
+  // 10.85 / 10.4 and 4.28 / 3.70 (one handle's lane behind the other handle's accumulation), one lane with ALL openings on it 9.3 / 10.9
+  // and 3.25 / 4.08.
+  bool few_streams = false;
+  Lane main_lane, ts_lane;                   // st = the handle's main / transform stream (not owned)
   // fused proofs (below): the proof's ONE chain runs on a stream of its own.  (Stream priorities -- the chain lowest, everything that builds
   // polynomials and openings highest, so that the next streamed proof's preparation would get wave slots beside a running accumulation --
   // were measured and made things WORSE on this runtime: n = 2^16 streamed 10.6 against 9.75 ms, n = 2^14 4.1 against 3.55,
   // profiles/r06_ab_small.txt; SONIC_PROVE_PRIORITIES=1 still asks for them.)
   Lane chain[2];
-  // ... and its bucket accumulation on a stream that leaves some of the chip's CUs alone (hipExtStreamCreateWithCUMask): see prove_enqueue
-  hipStream_t accum_st[2] = {nullptr, nullptr};
-  hipEvent_t accum_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   bool small_plan = false;                   // decided when the handle is made: the SRS plans 2^17 buckets or fewer for this n
   int next_lane = 0;
   const NttTables* ntt = nullptr;            // the device's shared tables for 2^log2m points (device_ntt_tables)
@@ -239,6 +250,10 @@ struct sonic_prover {
   // uploads it after it has queued the group of MSMs that needs the assignment only (R, W_a, W_b), so the 2 Q n + Q weights cross
   // PCIe under those kernels instead of in front of the proof
   const uint8_t* pend_circuit[4] = {nullptr, nullptr, nullptr, nullptr};
+  // the same for the ASSIGNMENT of this call (round 6: sonic_prove_batch with per-proof assignments, sonic_prove): uploaded at the head of
+  // the proof's own queue instead of by a sonic_prover_set_assignment that waits for the device before the proof may even be queued -- beside
+  // another handle's accumulation that wait was ~1 ms per proof (config5: 99 against 113 proofs/s, profiles/r06_bench.json)
+  const uint8_t* pend_asg[3] = {nullptr, nullptr, nullptr};
   // runs of equal coefficients in the S_j of a handle that is not prepared (poly.hip, k_run_tiles): per j the masked copy of s(X, y_j),
   // the tile records and the (scalar, running-sum point) slots of the small MSM that stands for the runs; its sum lands in slot
   // (7 + 4Q) + j, where a prepared handle keeps sum_q y_j^{n+q} C_q, and the host adds it the same way
@@ -253,6 +268,10 @@ struct sonic_prover {
   MsmWorkspace runs_ws;
   std::vector<RunBufs> runs;
   bool runs_on = false;
+  // does this circuit HAVE runs?  Sampled on the host from the weights as they are handed over (circuit_runs_hint): a circuit without
+  // repeated rows would pay the masked copy, the tile scan and a small MSM per S_j and get nothing back (measured with
+  // uniformly random weights at n = 2^18: profiles/r06_runs_dense_ab.txt).  A hint only: the path is exact for any input.
+  bool circuit_has_runs = true;
   // C = commitPoly(s(u, Y)) through the SRS's symmetric sums (srs.hip, srs_build_sym): s(u, Y) has the same coefficient at Y^i and Y^-i
   // (i <= n), so n terms over A[i] + A[-i] and a Q-term MSM for Y^{n+1} .. Y^{n+Q} stand for its 2n + Q + 1 terms; the Q-term sum lands
   // in slot 7 + 5Q and the host adds it
@@ -312,20 +331,23 @@ struct sonic_prover {
   // another lane's accumulation.  Streams beyond the 4 hardware queues would serialise behind each other.
   Lane& pick(hipEvent_t ready) {
     Lane& l = lanes[next_lane];
-    next_lane = (next_lane + 1) % (N_LANES - 1);
+    next_lane = (next_lane + 1) % (n_lanes > 1 ? n_lanes - 1 : 1);
     (void)hipStreamWaitEvent(l.st, ready, 0);
     return l;
   }
   Lane& t_lane(hipEvent_t ready) {
-    Lane& l = lanes[N_LANES - 1];
+    // (few_streams: the transform's own stream, which has waited for `ready` when it took the polynomials in -- a second wait for the same
+    // event, or one for an event of the stream itself, becomes a duplicate edge when the enqueue is captured as a hipGraph, and the
+    // runtime's capture code crashed on it)
+    if (few_streams) return ts_lane;
+    Lane& l = lanes[n_lanes - 1];
     (void)hipStreamWaitEvent(l.st, ready, 0);
     return l;
   }
   ~sonic_prover() {
     for (auto& l : lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); if (l.prep) (void)hipEventDestroy(l.prep); }
     for (auto& l : chain) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); if (l.prep) (void)hipEventDestroy(l.prep); }
-    for (hipStream_t s_ : accum_st) if (s_) (void)hipStreamDestroy(s_);
-    for (auto& pr : accum_ev) for (hipEvent_t e : pr) if (e) (void)hipEventDestroy(e);
+    for (Lane* l : {&main_lane, &ts_lane}) { if (l->done) (void)hipEventDestroy(l->done); if (l->prep) (void)hipEventDestroy(l->prep); }
     for (auto& r : runs) if (r.masked_ev) (void)hipEventDestroy(r.masked_ev);
     for (hipEvent_t e : {ev_r1, ev_sy0, ev_t, ev_su}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_syj) if (e) (void)hipEventDestroy(e);
@@ -367,9 +389,33 @@ static int flags_to_status(int f, const char* who) {
 
 // the circuit of a handle: Q x n weights and Q constants, uploaded and brought to Montgomery form (sonic_prover_new; the one-shot
 // sonic_prove re-uses a cached shell by loading the next call's circuit into it)
+// 32 tiles of RUN_TILE consecutive gate indices, spread over [0, n): a tile counts when every row of wL AND of wR repeats one value across
+// it -- then s(X, y) has a run of equal coefficients there (u_i = sum_q wL[q][i] y^{n+q}, Constraints.hs:39-49) -- and the circuit "has
+// runs" when at least a quarter of the sampled tiles do.  ~0.5 MB read at Q = 2, microseconds.
+static bool circuit_runs_hint(const uint8_t* wL, const uint8_t* wR, long n, long Q) {
+  const long ntiles = n / RUN_TILE;
+  if (ntiles < 1) return false;
+  const long samples = ntiles < 32 ? ntiles : 32;
+  long uniform = 0;
+  for (long sidx = 0; sidx < samples; sidx++) {
+    const long t = sidx * ntiles / samples;
+    bool uni = true;
+    for (int m = 0; m < 2 && uni; m++) {
+      const uint8_t* w = m ? wR : wL;
+      for (long q = 0; q < Q && uni; q++) {
+        const uint8_t* row = w + 32 * (q * n + t * RUN_TILE);
+        for (long i = 1; i < RUN_TILE && uni; i++) uni = memcmp(row, row + 32 * i, 32) == 0;
+      }
+    }
+    uniform += uni ? 1 : 0;
+  }
+  return 4 * uniform >= samples;
+}
+
 static int prover_load_circuit(sonic_prover* p, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO, const uint8_t* cs) {
   hipStream_t st = p->st;
   const long n = p->n, Q = p->Q;
+  p->circuit_has_runs = circuit_runs_hint(wL, wR, n, Q);
   HIP_OK(hipMemsetAsync(p->flags.p, 0, 4, st));
   upload_fr_mont(st, p->wL, wL, Q * n, p->flags.as<int>());
   upload_fr_mont(st, p->wR, wR, Q * n, p->flags.as<int>());
@@ -463,28 +509,28 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   p->ev_syj.resize(Q, nullptr);
   for (auto& e : p->ev_syj) mkev(&e);
   // MSM workspaces and opening scratch grow on first use: every proof maps the same group of MSMs to the same lane
-  for (auto& l : p->lanes) {
+  if (p->small_plan) {
+    const char* le = getenv("SONIC_FUSED_LANES");
+    const int v = le ? atoi(le) : 0;                       // 0: one lane + the borrowed streams (few_streams); k: k lanes of their own
+    p->few_streams = v <= 0;
+    p->n_lanes = v < 1 ? 1 : (v > N_LANES ? N_LANES : v);
+    if (p->few_streams) {
+      p->main_lane.st = p->st; p->ts_lane.st = p->ts;
+      mkev(&p->main_lane.done); mkev(&p->main_lane.prep);
+      mkev(&p->ts_lane.done); mkev(&p->ts_lane.prep);
+    }
+  }
+  for (int i = 0; i < p->n_lanes; i++) {
+    Lane& l = p->lanes[i];
     mkstream(&l.st, prio_high);
     mkev(&l.done);
     mkev(&l.prep);
   }
   if (p->small_plan) {
-    for (auto& l : p->chain) {
-      mkstream(&l.st, prio_low);
-      mkev(&l.done);
-    }
-    // SONIC_ACCUM_CU_RESERVE=R: the accumulation's stream may use all but R of the device's CUs (every (count / R)-th bit of the mask cleared)
-    const char* re = getenv("SONIC_ACCUM_CU_RESERVE");
-    const int reserve = re ? atoi(re) : 0;
-    hipDeviceProp_t prop;
-    if (reserve > 0 && hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 2 * reserve) {
-      const int ncu = prop.multiProcessorCount, every = ncu / reserve;
-      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-      for (int cu = 0; cu < ncu; cu++) if (cu % every != every - 1) mask[(size_t)cu / 32] |= 1u << (cu % 32);
-      for (int c = 0; c < 2; c++) {
-        if (hipExtStreamCreateWithCUMask(&p->accum_st[c], (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); p->accum_st[c] = nullptr; break; }
-        mkev(&p->accum_ev[c][0]); mkev(&p->accum_ev[c][1]);
-      }
+    // (the second chain stream is only used by proofs of more than MSM_MAX_JOBS MSMs: Q > 2)
+    for (int c = 0; c < (7 + 4 * Q > MSM_MAX_JOBS ? 2 : 1); c++) {
+      mkstream(&p->chain[c].st, prio_low);
+      mkev(&p->chain[c].done);
     }
   }
   HIP_OK(hipStreamSynchronize(st));
@@ -578,7 +624,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     const char* re = getenv("SONIC_PROVE_RUNS");
     const int mode = re ? atoi(re) : -1;
     const bool size_ok = mode == 1 ? 3 * p->n + 1 >= 8 * RUN_TILE : p->n >= (1L << 16);
-    p->runs_on = mode != 0 && size_ok && !p->prepared && p->share_world <= 1 && srs_prefix(p->srs).p != nullptr;
+    p->runs_on = mode != 0 && size_ok && (mode == 1 || p->circuit_has_runs) && !p->prepared && p->share_world <= 1 && srs_prefix(p->srs).p != nullptr;
   }
   {
     // by default from n = 2^17: the Q-term MSM's launches cost a small proof more than n additions save it (ms per proof streamed with /
@@ -601,7 +647,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   const int KS = p->sym_on ? K + (int)Q + 1 : K + ((p->prepared || p->runs_on) ? (int)Q : 0);        // + the second halves of the S_j and of C
   // Launch-bound sizes replay the whole multi-stream enqueue as one hipGraph: captured on the second proof of a handle (the
   // first one grows the workspaces), every address in it is owned by the handle.
-  const bool pending = p->pend_circuit[0] != nullptr;
+  const bool pending = p->pend_circuit[0] != nullptr || p->pend_asg[0] != nullptr;
   const bool want_graph = p->use_graph && p->proofs_done >= 1 && !profiler().on && p->phases == PH_ALL && !pending;
   const bool replay = want_graph && p->graph != nullptr;
   const bool capturing = want_graph && !replay && !p->graph_tried;
@@ -686,9 +732,12 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     for (auto& f : after_flush) f();
     after_flush.clear();
   };
-  auto begin_group = [&](hipEvent_t e) {
+  // (few_streams: the s(X,y_j) groups ride on the main stream, which has built every polynomial by then; the others on the one lane)
+  auto begin_group = [&](hipEvent_t e, bool on_main = false) {
     flush_now();
-    cur = &p->pick(e); cur->njobs = 0;
+    if (p->few_streams && on_main) cur = &p->main_lane;
+    else cur = &p->pick(e);
+    cur->njobs = 0;
   };
   auto flush_group = [&](bool last = false) { flush_now(last); };
   auto full = [&] { return cur->njobs + (int)pend.size() == MSM_MAX_JOBS; };
@@ -738,6 +787,13 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // (a polynomial is built in the pass that first knows its challenge -- every pass when phases == PH_ALL -- and stays in the
   // handle's buffers for the later passes of sonic_prover_prove_fs: r(X,1) from the blinders, s(X,y) and t(X,y) from y, s(X,y_j)
   // from y_j, s(u,Y) from u)
+  if (p->pend_asg[0]) {
+    upload_fr_mont(ms, p->aL, p->pend_asg[0], n, flags + 1);
+    upload_fr_mont(ms, p->aR, p->pend_asg[1], n, flags + 1);
+    upload_fr_mont(ms, p->aO, p->pend_asg[2], n, flags + 1);
+    p->pend_asg[0] = nullptr;
+    p->have_witness_digest = false;
+  }
   if ((need_g0 || need_T) && on(PH_R)) build_r1_enqueue(ms, p->aL.as<Fr>(), p->aR.as<Fr>(), p->aO.as<Fr>(), S, n, r1);
   ready(p->ev_r1);
   // the group that needs nothing but r(X,1): queued here, ahead of the other polynomials, when this call's circuit is still on the host
@@ -751,7 +807,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     open(PH_OPEN, r1, r_lo, r_len, pYZ, 1, 3);                                         // (b, W_b)     :80
     flush_group(last_group == 0);
   };
-  if (pending) {
+  if (p->pend_circuit[0]) {
     group0();
     const uint8_t* const* c = p->pend_circuit;
     upload_fr_mont(ms, p->wL, c[0], Q * n, flags + 1);
@@ -771,11 +827,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     // zkP_2: t(X,y) = r(X,1) * (r(X,y) + s(X,y)) - k(y), on its own stream          Protocol.hs:69-73, Constraints.hs:56-68
     hipStream_t ts = p->ts;
     HIP_OK(hipStreamWaitEvent(ts, p->ev_sy0, 0));          // ev_sy0 follows ev_r1 on the main stream
-    HIP_OK(hipMemsetAsync(fa, 0, sizeof(Fr) * M, ts));
-    HIP_OK(hipMemsetAsync(fb, 0, sizeof(Fr) * M, ts));
-    HIP_OK(hipMemcpyAsync(fa, r1, sizeof(Fr) * r_len, hipMemcpyDeviceToDevice, ts));
-    poly_scale_powers_enqueue(ts, r1, fb, r_len, r_lo, pY, pY + 1);                  // r(X,y): c_e y^e (diagonal)
-    add_into_enqueue(ts, fb + (s_lo - r_lo), sy, s_len);
+    t_operands_enqueue(ts, r1, r_len, r_lo, sy, s_lo - r_lo, s_len, pY, fa, fb, M);     // fa = r(X,1), fb = r(X,y) + s(X,y), zero-padded
     ntt_forward_enqueue(ts, *p->ntt, fa, p->log2m);
     ntt_forward_enqueue(ts, *p->ntt, fb, p->log2m);
     ntt_inverse_of_product_enqueue(ts, *p->ntt, fa, fb, p->log2m);
@@ -803,14 +855,20 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // ---- the MSM groups, largest first where its input allows ----
   Lane& lane_t = p->t_lane(p->ev_sy0);
   if (on(PH_OPEN) && first_piece(4)) {                                                 // s(z,y)       :83  (reported by the rank that starts W_t)
-    eval_prefix_enqueue(lane_t.st, lane_t.sc[MSM_MAX_JOBS - 1], sy, s_lo, s_len, pZ, &frout[2]);
+    Scratch& es = lane_t.sc[MSM_MAX_JOBS - 1];
+    es.reserve(s_len);
+    es.scan.ensure(sizeof(Fr) * (s_len / 1024 + 2));
+    OpenBatch eb;
+    memset(&eb, 0, sizeof eb);
+    eb.k = 1; eb.poly[0] = sy; eb.D[0] = es.D.as<Fr>(); eb.q[0] = es.q.as<Fr>(); eb.tiles[0] = es.scan.as<Fr>(); eb.zpair[0] = pZ; eb.fz[0] = &frout[2];
+    open_batch_enqueue(lane_t.st, eb, s_lo, s_len, /*quotient=*/false);
     p->fr_valid[2] = 1;
   }
   group0();
   for (long j = 0; j < Q; j++) {
     if (!need_j[(size_t)j]) continue;
     Fr* syj = p->syj[j].as<Fr>();
-    begin_group(p->ev_syj[j]);
+    begin_group(p->ev_syj[j], /*on_main=*/true);
     if (p->prepared) commit(PH_HSCS, p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);   // S_j (diagonal part)   Signature.hs:42
     else if (p->runs_on) commit_runs(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j, j);    // S_j, runs through the running sums   :42
     else commit(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j                   :42
@@ -832,7 +890,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     if (p->sym_on && on(PH_HSCW) && own(6 + 4 * Q)) {                                  // C             :52, over the symmetric sums
       if (full()) flush_now();
       MsmJob job = commit_job(cur->st, srs, su, u_lo, u_len, d, &slots[6 + 4 * Q], flags);      // (the index checks of the whole range)
-      job.points = srs_sym(srs) + (d + 1); job.scalars = su + (n + 1); job.n = n;               // exponents 1 .. n: c_i (A[i] + A[-i])
+      job.points = srs_sym(srs) + 1; job.scalars = su + (n + 1); job.n = n; job.table_stride = d + 1;      // exponents 1 .. n: c_i (A[i] + A[-i])
       p->slot_ran[(size_t)(6 + 4 * Q)] = 1;
       cur->jobs[cur->njobs++] = job;
       p->slot_ran[(size_t)(7 + 5 * Q)] = 1;                                                     // exponents n+1 .. n+Q, on the main stream (su was built there)
@@ -844,7 +902,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   }
   flush_now(last_group == 2 && sh != nullptr);
   if (need_T) {
-    if (on(PH_T)) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
+    if (on(PH_T) && lane_t.st != p->ts) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
     cur = &lane_t; cur->njobs = 0;
     commit(PH_T, t, t_lo, t_len, d, 1);                                                // T            Protocol.hs:73
     open(PH_OPEN, t, t_lo, t_len, pZ, -1, 4);                                          // W_t          :81
@@ -853,23 +911,27 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   if (p->fused && !p->fused_jobs.empty()) {
     // the proof's chain(s): every lane has queued its openings by now; chunks of at most MSM_MAX_JOBS jobs (one chunk up to Q = 2),
     // on the two chain streams in turn so that two chunks overlap like two groups did
-    for (auto& l : p->lanes) HIP_OK(hipEventRecord(l.prep, l.st));
+    for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipEventRecord(p->lanes[i].prep, p->lanes[i].st));
+    if (p->few_streams) { HIP_OK(hipEventRecord(p->main_lane.prep, ms)); if (need_T) HIP_OK(hipEventRecord(p->ts_lane.prep, p->ts)); }
     const int total = (int)p->fused_jobs.size();
     const int nchunks = (total + MSM_MAX_JOBS - 1) / MSM_MAX_JOBS, per = (total + nchunks - 1) / nchunks;
     for (int c = 0, at = 0; c < nchunks; c++, at += per) {
       Lane& cl = p->chain[c & 1];
-      if (c < 2) for (auto& l : p->lanes) HIP_OK(hipStreamWaitEvent(cl.st, l.prep, 0));
+      if (c < 2) {
+        for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipStreamWaitEvent(cl.st, p->lanes[i].prep, 0));
+        if (p->few_streams) { HIP_OK(hipStreamWaitEvent(cl.st, p->main_lane.prep, 0)); if (need_T) HIP_OK(hipStreamWaitEvent(cl.st, p->ts_lane.prep, 0)); }
+      }
       const int k = std::min(per, total - at);
       long nmax = 0;
       for (int j = 0; j < k; j++) nmax = std::max(nmax, p->fused_jobs[(size_t)(at + j)].n);
       MsmPlan pl = srs_msm_plan(srs, nmax);
       pl.tree = true;
-      if (p->accum_st[c & 1]) { pl.accum_stream = p->accum_st[c & 1]; pl.accum_ev[0] = p->accum_ev[c & 1][0]; pl.accum_ev[1] = p->accum_ev[c & 1][1]; }
       msm_enqueue_batch(cl.st, cl.ws, pl, &p->fused_jobs[(size_t)at], k, true);
     }
   }
-  for (auto& l : p->lanes) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
-  if (p->fused) for (auto& l : p->chain) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
+  for (int i = 0; i < p->n_lanes; i++) { Lane& l = p->lanes[i]; HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
+  if (p->fused) for (auto& l : p->chain) if (l.st) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
+  if (p->few_streams && need_T) { HIP_OK(hipEventRecord(p->ts_lane.done, p->ts_lane.st)); HIP_OK(hipStreamWaitEvent(ms, p->ts_lane.done, 0)); }
   Fr* frstd = p->frstd.as<Fr>();
   HIP_OK(hipMemcpyAsync(frstd, frout, sizeof(Fr) * (3 + 2 * Q), hipMemcpyDeviceToDevice, ms));
   fr_from_mont_enqueue(ms, frstd, 3 + 2 * Q);
@@ -1026,7 +1088,7 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
   if (timing) fprintf(stderr, "[sonic] prove: enqueue %.3f ms, then waited %.3f ms for the device\n",
                       std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
-  if (p->h_flags[1]) return flags_to_status(p->h_flags[1], "sonic_prover_new");        // the circuit that was uploaded inside this proof
+  if (p->h_flags[1]) { p->have_assignment = false; return flags_to_status(p->h_flags[1], "prove (circuit / assignment handed over with the call)"); }
   if (hflags) return flags_to_status(hflags, "prove");
   std::vector<uint8_t> pts(96 * (size_t)K);
   {
@@ -1091,6 +1153,21 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
   if (!rc) rc = prove_enqueue(p, transcript);
   if (!rc) rc = prove_finish(p, out_proof);
   else if (p->st) (void)hipStreamSynchronize(p->st);      // an enqueue that failed half way: let what was queued drain
+  return rc;
+}
+
+// prove with the assignment of THIS call still in the caller's host buffers (uploaded inside the proof's queue: pend_asg)
+static int prove_with_assignment(sonic_prover_t* p, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript, uint8_t* out_proof) {
+  std::lock_guard<std::mutex> g(p->mu);
+  if (p->in_flight) { set_error("prove: a submitted proof has not been collected yet"); return SONIC_ERR_INVALID_ARG; }
+  int rc = whole_proof_only(p, "prove");
+  if (rc) return rc;
+  p->pend_asg[1] = aR; p->pend_asg[2] = aO; p->pend_asg[0] = aL;
+  rc = prove_enqueue(p, transcript);
+  if (!rc) rc = prove_finish(p, out_proof);
+  else if (p->st) (void)hipStreamSynchronize(p->st);
+  p->pend_asg[0] = nullptr;
+  p->have_assignment = rc == SONIC_OK;          // (a failed call may have left a partly converted assignment behind)
   return rc;
 }
 
@@ -1280,13 +1357,13 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   std::vector<DevBuf> rows(std::min<long>(Q, N_LANES));
   for (auto& b : rows) b.alloc(sizeof(Fr) * (3 * n + 1));
   for (long q = 0; q < Q; q++) {
-    Lane& l = p->lanes[q % N_LANES];
-    Fr* row = rows[q % N_LANES].as<Fr>();
+    Lane& l = p->lanes[q % p->n_lanes];
+    Fr* row = rows[q % p->n_lanes].as<Fr>();
     weight_row_poly_enqueue(l.st, p->wL.as<Fr>(), p->wR.as<Fr>(), p->wO.as<Fr>(), n, q, row);
     MsmJob job = commit_job(l.st, p->srs, row, -n, 3 * n + 1, d, slots.as<MsmSlot>() + q, flags);
     run_jobs(l.st, p->srs, l.ws, &job, 1);
   }
-  for (auto& l : p->lanes) HIP_OK(hipStreamSynchronize(l.st));
+  for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipStreamSynchronize(p->lanes[i].st));
   std::vector<MsmSlot> hs(Q);
   HIP_OK(hipMemcpy(hs.data(), slots.p, sizeof(MsmSlot) * Q, hipMemcpyDeviceToHost));
   int hflags = 0;
@@ -1631,15 +1708,17 @@ int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL,
     }
   }
   int rc = SONIC_OK;
-  if (sh) { sh->p->pend_circuit[1] = wR; sh->p->pend_circuit[2] = wO; sh->p->pend_circuit[3] = cs; sh->p->pend_circuit[0] = wL; }   // uploaded inside the proof
+  if (sh) {   // uploaded inside the proof
+    sh->p->pend_circuit[1] = wR; sh->p->pend_circuit[2] = wO; sh->p->pend_circuit[3] = cs; sh->p->pend_circuit[0] = wL;
+    sh->p->circuit_has_runs = circuit_runs_hint(wL, wR, n, Q);
+  }
   else {
     sonic_prover_t* p = nullptr;
     rc = sonic_prover_new(srs, n, Q, wL, wR, wO, cs, &p);
     if (rc) return rc;
     sh = new OneShotShell{srs, p};
   }
-  if (!rc) rc = sonic_prover_set_assignment(sh->p, aL, aR, aO);
-  if (!rc) rc = sonic_prover_prove(sh->p, transcript, out_proof);
+  if (!rc) rc = prove_with_assignment(sh->p, aL, aR, aO, transcript, out_proof);
   sh->p->pend_circuit[0] = nullptr;           // (a call that failed before its upload: the caller's buffers end with the call)
   // park the shell (also after a failed call: the next one loads its own circuit and assignment); the oldest parked shell makes room
   OneShotShell* evict = nullptr;
@@ -1757,8 +1836,8 @@ int sonic_prove_batch(sonic_prover_t* const* provers, int n_provers, int64_t K, 
     for (int64_t i = h; i < K; i += n_provers) {
       int rc = SONIC_OK;
       try {
-        if (per_proof) rc = sonic_prover_set_assignment(provers[h], aL + asz * (size_t)i, aR + asz * (size_t)i, aO + asz * (size_t)i);
-        if (!rc) rc = sonic_prover_prove(provers[h], transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
+        if (per_proof) rc = prove_with_assignment(provers[h], aL + asz * (size_t)i, aR + asz * (size_t)i, aO + asz * (size_t)i, transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
+        else rc = sonic_prover_prove(provers[h], transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
         if (rc && first_bad[(size_t)h] < 0) { first_bad[(size_t)h] = i; char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)h] = b; }
       } catch (...) { rc = SONIC_ERR_HIP; }                          // (nothing may leave a thread's body: std::terminate)
       status[(size_t)i] = rc;

@@ -146,8 +146,10 @@ void srs_build_prefix(hipStream_t st, sonic_srs* s) {
 // ---- symmetric sums of the alpha basis (round 5): sym[e] = A[e] + A[-e] for e in [1, d], with window tables like a basis ------------
 // s(u, Y) has the same coefficient -u^{i+n} at Y^i and at Y^{-i} (Constraints.hs:34-53 with X := u; poly.hip, k_s_of_u_diag), so the
 // commitment C of hscProve (Signature.hs:51-52) is sum_i c_i (A[i] + A[-i]) + Q more terms: n terms over this table instead of 2n.
-// Stored like a basis (slot e + d, the window tables behind it at the same stride) so that the job shares a batched chain with the
-// openings of the same polynomial; slots e <= 0 stay empty.
+// Stored compactly (round 6): d + 1 points per window table, slot e for exponent e (slot 0 stays empty), the tables d + 1
+// points apart -- the job over them shares a batched chain with the openings of the same polynomial and tells the kernels its own table
+// stride (MsmJob::table_stride).  Up to round 5 the tables were laid out like a basis, 2d + 1 slots each, half of them never touched:
+// 3.5 GB at d = 2^21 that were allocated, cleared and copied to every replica.
 __global__ __launch_bounds__(256) void k_sym_sum(PointArray A, long d, long e0, long m, G1XYZZ* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
@@ -158,8 +160,8 @@ void srs_build_sym(hipStream_t st, sonic_srs* s) {
   PointArrayMut sym = srs_sym_mut(s);
   if (!sym.p) return;
   const int W = srs_tab_W(s);
-  const long d = srs_d(s), n = 2 * d + 1;
-  HIP_OK(hipMemsetAsync(sym.p, 0, (size_t)sym.stride * (size_t)n * (size_t)W, st));          // infinity everywhere (slots e <= 0 stay so)
+  const long d = srs_d(s), n = d + 1;                          // points per table: exponents 0 .. d
+  for (int w = 0; w < W; w++) HIP_OK(hipMemsetAsync((sym + (long)((size_t)w * n)).p, 0, sym.stride, st));      // slot 0 of every table: infinity
   const long SLAB = 1L << 20;
   const long cap = d < SLAB ? d : SLAB;
   DevBuf x(sizeof(G1XYZZ) * cap), pref(sizeof(Fq) * cap);
@@ -167,14 +169,14 @@ void srs_build_sym(hipStream_t st, sonic_srs* s) {
   for (long base = 0; base < d; base += SLAB) {              // exponents e = 1 + base ...
     const long m = d - base < SLAB ? d - base : SLAB;
     LAUNCH(k_sym_sum, ceil_div(m, 256), 256, 0, st, A, d, 1 + base, m, x.as<G1XYZZ>());
-    LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), sym + (d + 1 + base), pref.as<Fq>(), m);
+    LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), sym + (1 + base), pref.as<Fq>(), m);
   }
   for (int w = 1; w < W; w++)
     for (long base = 0; base < d; base += SLAB) {
       const long m = d - base < SLAB ? d - base : SLAB;
-      LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (PointArray)(sym + (long)((size_t)(w - 1) * n + d + 1 + base)), x.as<G1XYZZ>(), m,
+      LAUNCH(k_table_step, ceil_div(m, 256), 256, 0, st, (PointArray)(sym + (long)((size_t)(w - 1) * n + 1 + base)), x.as<G1XYZZ>(), m,
              msm_even_width(W, w - 1, srs_tab_endo(s) ? ENDO_BITS : 255));
-      LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), sym + (long)((size_t)w * n + d + 1 + base), pref.as<Fq>(), m);
+      LAUNCH(k_batch_affine, ceil_div(ceil_div(m, 64), 64), 64, 0, st, (const G1XYZZ*)x.as<G1XYZZ>(), sym + (long)((size_t)w * n + 1 + base), pref.as<Fq>(), m);
     }
   HIP_OK(hipStreamSynchronize(st));
 }

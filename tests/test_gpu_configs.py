@@ -381,7 +381,20 @@ def test_bench_under_the_driver_launch_line_one_rank_rccl():
     assert abs(rp["scalar_muls_per_s_inside_prove"] - rp["scalar_muls_executed_per_proof"] * j["value"]) / rp["scalar_muls_per_s_inside_prove"] < 1e-3
     sv = j["sensitivities"]
     assert sv["stated_d_reading"]["n"] == n_ // 2 and sv["stated_d_reading"]["d"] == 4 * n_ and sv["Q1"]["Q"] == 1 and sv["Q4"]["Q"] == 4
-    assert sv["seed1"]["seed"] == 1 and sv["seed2"]["seed"] == 2 and all(v["ms_per_proof"] > 0 for v in sv.values())
+    assert sv["seed1"]["seed"] == 1 and sv["seed2"]["seed"] == 2 and all(v["ms_per_proof"] > 0 for k, v in sv.items() if k != "dense_weights")
+    # round 6: what the headline owes to rndCircuit's all-ones rows (uniformly random weights: prepared stream, unprepared stream, one-shot
+    # call -- all the same bytes), the integer roof of a whole proof, BASELINE configs[1] and configs[4] and the reference's own criterion shape
+    dw = sv["dense_weights"]
+    assert dw["n"] == n_ and dw["prepared_streamed"]["ms_per_proof"] > 0 and dw["resident_unprepared"]["same_bytes_as_prepared"] is True
+    assert dw["one_shot"]["same_bytes_as_streamed"] is True and dw["one_shot"]["ms_per_proof"] > 0
+    ip = j["int_roofline_prove"]
+    assert ip["bound"] == "v_mad_u64_u32" and 0 < ip["frac"] < 1 and ip["plan"]["msms"] == 7 + 4 * q_
+    c2, c5, cr = j["config2"], j["config5"], j["criterion_shape"]
+    assert c2["n"] == 1 << 14 and c2["d"] == 1 << 17 and c2["same_bytes_streamed_and_sequential"] is True and c2["streamed"]["ms_per_proof"] > 0
+    assert c5["n"] == 1 << 16 and c5["proofs"] == 64 and c5["same_bytes_as_one_handle_alone"] is True and c5["assignment_resident"]["proofs_per_s_per_gpu"] > 0
+    assert cr["example_n1_Q2"]["verified"] is True and cr["example_n2_Q5"]["verified"] is True and cr["example_n2_Q5"]["d"] == 50
+    ts = j["msm_strong"]["emulated_share"]["term_range_mode"]
+    assert ts["ms_per_share"] > 0 and j["msm_strong"]["emulated_share"]["best_mode"] in ("bucket_ranges", "term_ranges")
     mp = j["msm_protocol_shaped"]
     assert mp["W_t_quotient"]["N"] == 7 * mp["n"] + 8 and mp["s_of_X_y_coefficients"]["N"] == 3 * mp["n"] + 1
     assert mp["s_of_X_y_coefficients"]["distinct_scalars"] <= mp["n"] + 3 and mp["W_t_quotient"]["distinct_scalars"] > 7 * mp["n"]

@@ -315,6 +315,15 @@ int main(int argc, char** argv) {
     printf("g1_add_mixed:  %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
   { int it = 64; float ms = time_ms([&] { hipLaunchKernelGGL(k_madd_walk, blocks, threads, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
     printf("g1_add_mixed_walk (fused asm): %.3f ms -> %.3e add/s\n", ms, lanes * it / (ms * 1e-3)); }
+  // the same register-only walk addition with exactly ONE and exactly TWO waves resident per SIMD (one / two 256-lane workgroups per CU): what a
+  // second independent instruction stream per SIMD is worth -- the most that interleaving two buckets inside one thread could give at one wave
+  // per SIMD (round 6; tools/accum_isa.py has the issue-bound of the instruction mix)
+  for (int wps = 1; wps <= 2; wps++) {
+    int it = 256; const int bl = pr.multiProcessorCount * wps, th = 256;
+    float ms = time_ms([&] { hipLaunchKernelGGL(k_madd_walk, bl, th, 0, 0, (G1XYZZ*)buf, (const G1Affine*)pts, it); }, 3);
+    printf("g1_add_mixed_walk from registers, %d wave(s) per SIMD: %.3e add/s (%.2f us per wave-addition on a SIMD)\n", wps, (double)bl * th * it / (ms * 1e-3),
+           1e3 * ms / it / wps);
+  }
   for (int wps = 1; wps <= 4; wps *= 2) {
     int it = 2048; const int bl = pr.multiProcessorCount * wps, th = 256;
     float ms = time_ms([&] { hipLaunchKernelGGL(k_butterfly, bl, th, 0, 0, (Fr*)buf, it); }, 3);
