@@ -985,6 +985,9 @@ static void bucket_tree_enqueue(hipStream_t st, G1XYZZ* Z, int sets, int L, uint
   // 0 / 2 / 4 / 8 / 16 rounds 0.521 / 0.426 / 0.453 / 0.463 / 0.465 ms: the early levels are bound by issue, where a quad's 20 lane-products
   // per addition lose to a lane's 14)
   constexpr int quads = 2;
+  // (round 6: 512 lanes per 1024-bucket block with TWO buckets per lane at the leaf -- twice the waves, every level one round -- measured
+  // slower, 0.476 against 0.437 ms at 2^19 buckets: the levels after the second move ~300 MB of 192-byte points at power-of-two strides
+  // through L2 and that traffic, not the additions' latency, is what the block kernel waits for; profiles/r06_ab_tree.txt)
   LAUNCH(k_bucket_tree_block, (uint32_t)sets << (L - LB), 256, 0, st, Z, LB, quads);
   int done = LB;
   if (L > done) {
