@@ -608,6 +608,62 @@ __global__ __launch_bounds__(256, 2) void k_bucket_accum(const MsmBatchDev batch
   buckets[b] = acc;
 }
 
+// The same walk with T = 2 or 4 lanes per bucket (round 6): lane r takes entries r, r + T, r + 2T, .. of its bucket and the
+// T partial sums are folded with whole-point exchanges over DPP (one or two full additions, every lane of the group computes them).  For
+// launches that would leave the chip under-filled with one lane per bucket: a stand-alone MSM over a small SRS is ONE job of 2^15 or 2^16
+// buckets -- 512 or 1024 waves for 2048 wave slots, each walking 30-60 entries at the latency of a lone wave (18.5 us per addition) --
+// while four lanes per bucket are 2048-4096 waves with walks a quarter as long.  (Inside prove() such plans run as one chain of 15 jobs
+// and fill the chip by themselves.)  The entries are walked with a one-deep prefetch; exceptional additions fall back as in the kernel above.
+template <int CTRL>
+__device__ __forceinline__ G1XYZZ g1_point_quad_perm(const G1XYZZ& p) {
+  G1XYZZ r;
+  r.x = fq_quad<CTRL>(p.x); r.y = fq_quad<CTRL>(p.y); r.zz = fq_quad<CTRL>(p.zz); r.zzz = fq_quad<CTRL>(p.zzz);
+  return r;
+}
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_bucket_accum_split(const MsmBatchDev batch, uint32_t jobstride, const uint32_t* __restrict__ entries,
+                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
+                                                            uint32_t nbuckets, uint32_t heavy_t,
+                                                            G1XYZZ* __restrict__ buckets, HeavyMeta* hm, HeavyRec* hrecs) {
+  static_assert(T == 2 || T == 4, "two or four lanes per bucket (a quad holds whole groups)");
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = t / T, r = t % T;
+  if (g >= nbuckets) return;                          // (whole groups leave together: T divides the wave)
+  const uint32_t b = order[g];
+  const uint32_t beg = off[b], end = off[b + 1];
+  const uint32_t cnt = end - beg;
+  if (cnt > heavy_t) {                                // recorded once; k_heavy_accum walks it
+    if (r == 0) { const uint32_t h = atomicAdd(&hm->n_heavy, 1u); hrecs[h].bucket = b; hrecs[h].cnt = cnt; }
+    return;
+  }
+  const PointArray pts{batch.points[b / jobstride], batch.pt_stride};
+  const long stride = batch.tstride[b / jobstride];
+  G1XYZZ acc = G1XYZZ::inf();
+  uint32_t e = beg + r;
+  if (e < end) {
+    uint32_t e_cur = entries[e];
+    G1Affine p_cur = pts[entry_point(e_cur, stride)];
+    if (e_cur >> 31) p_cur.y = fp_neg(p_cur.y);
+    acc = G1XYZZ::from_affine(p_cur);                 // the lane's first entry is a copy, not an addition
+    e += T;
+    if (e < end) {
+      e_cur = entries[e];
+      p_cur = pts[entry_point(e_cur, stride)];
+      for (; e < end; e += T) {
+        const uint32_t e_n = e + T < end ? e + T : e;
+        const uint32_t e_nxt = entries[e_n];
+        const G1Affine p_nxt = pts[entry_point(e_nxt, stride)];
+        acc = g1_add_mixed_walk(acc, p_cur, e_cur >> 31);
+        p_cur = p_nxt; e_cur = e_nxt;
+      }
+    }
+  }
+  constexpr int QP_SWAP1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);     // [1,0,3,2]
+  if (T == 4) acc = g1_add(acc, g1_point_quad_perm<QP_SWAP2>(acc));   // lanes 0, 2: s0 + s2; lanes 1, 3: s1 + s3
+  acc = g1_add(acc, g1_point_quad_perm<QP_SWAP1>(acc));               // every lane of the group: the bucket's sum
+  if (r == 0) buckets[b] = acc;
+}
+
 // exclusive scan over the HEAVY_THREADS lanes of a workgroup (wave shuffles + one word per wave in LDS); *total = the sum
 __device__ __forceinline__ uint32_t heavy_scan(uint32_t v, uint32_t* wsum, uint32_t* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1166,6 +1222,16 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
   LAUNCH(k_border_place, ceil_div((long)M, 2048), 256, 0, st, (const uint32_t*)off, (uint32_t)M, (const uint32_t*)hm->class_hist, hm->class_cursor,
          ws.order.as<uint32_t>());
   const int accum_block = (pl.accum_block == 64 || pl.accum_block == 128) ? pl.accum_block : 256;
+  // lanes per bucket: enough of them for two rounds of the chip's 2048 wave slots (SONIC_ACCUM_LANES=1: always one)
+  static const int split_env = getenv("SONIC_ACCUM_LANES") ? atoi(getenv("SONIC_ACCUM_LANES")) : 0;
+  const int lanes_per_bucket = split_env == 1 ? 1 : (M <= 65536 ? 4 : (M <= 131072 ? 2 : 1));
+  if (lanes_per_bucket == 4)
+    LAUNCH(k_bucket_accum_split<4>, ceil_div(4 * (long)M, 256), 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
+           (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs);
+  else if (lanes_per_bucket == 2)
+    LAUNCH(k_bucket_accum_split<2>, ceil_div(2 * (long)M, 256), 256, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
+           (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs);
+  else
   LAUNCH(k_bucket_accum, ceil_div((long)M, accum_block), accum_block, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(),
          (const uint32_t*)off, (const uint32_t*)ws.order.as<uint32_t>(), (uint32_t)M, pl.heavy_threshold, buckets, hm, hrecs);
   LAUNCH(k_heavy_accum, HEAVY_GRID, HEAVY_THREADS, 0, st, batch, jobstride, (const uint32_t*)ws.entries.as<uint32_t>(), (const uint32_t*)off,
