@@ -108,9 +108,9 @@ def scalar_muls_reference(n, Q):
 def scalar_muls_executed(n, Q, prepared):
     """terms the kernels actually run per proof (sonic_amd/csrc/share_plan.hpp, share_line): T 7n+9, W_t 7n+8, R / W_a / W_b 3n+4 each,
     per j: S_j (n + a Q-term MSM over the committed rows when the handle is prepared, else 3n+1), W_j 3n, W'_j 3n; C 2n+Q+1 -- n + Q from
-    n = 2^16, where it runs over the SRS's symmetric sums (prove.hip, sym_on) --, Q_j 2n+Q each, Q_v 2n+Q"""
+    n = 2^17, where it runs over the SRS's symmetric sums (prove.hip, sym_on) --, Q_j 2n+Q each, Q_v 2n+Q"""
     per_j = ((n + Q) if prepared else (3 * n + 1)) + 3 * n + 3 * n + (2 * n + Q)
-    sym = n >= (1 << 16) and os.environ.get("SONIC_PROVE_SYM", "") != "0" and os.environ.get("SONIC_SRS_SYM", "") != "0"
+    sym = n >= (1 << 17) and os.environ.get("SONIC_PROVE_SYM", "") != "0" and os.environ.get("SONIC_SRS_SYM", "") != "0"
     c_terms = (n + Q) if sym else (2 * n + Q + 1)
     return (7 * n + 9) + (7 * n + 8) + 3 * (3 * n + 4) + Q * per_j + c_terms + (2 * n + Q)
 
@@ -839,7 +839,7 @@ class Bench:
                           "rule": "128 B x (27n + 28 + 2Q + Q(11n + Q)) + 288 M (SURVEY 8d: the reference's 49n terms at Q = 2)", "achieved": round(alg_p * proofs_per_s / world / 1e9, 2),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_p * proofs_per_s / world / 1e9 / HBM_PEAK_GBS, 5),
                           "scalar_muls_executed_per_proof": executed,
-                          "scalar_muls_executed_rule": "share_plan.hpp share_line: prepared handles commit S_j as an n-term + a Q-term MSM instead of 3n + 1 terms; C over the SRS's symmetric sums is n + Q terms instead of 2n + Q + 1 (from n = 2^16)",
+                          "scalar_muls_executed_rule": "share_plan.hpp share_line: prepared handles commit S_j as an n-term + a Q-term MSM instead of 3n + 1 terms; C over the SRS's symmetric sums is n + Q terms instead of 2n + Q + 1 (from n = 2^17)",
                           "scalar_muls_per_s_inside_prove": round(executed * proofs_per_s, 1)}
         int_roofline_prove = None
         model, model_src = load_profile_json("kernel_model.json")

@@ -1016,7 +1016,7 @@ static int msm_multi(const sonic_srs_t* const* srs, int world, int basis, const 
   };
   if (world == 1) body(0);
   else {
-    std::vector<std::thread> th;
+    ThreadGroup th;
     for (int r = 0; r < world; r++) th.emplace_back(body, r);
     for (auto& t : th) t.join();
   }

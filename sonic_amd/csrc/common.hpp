@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <string>
 #include <vector>
 #include "../../include/sonic_hip.h"
@@ -55,6 +57,20 @@ struct ScopedKernelTimer {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__);              \
     HIP_OK(hipGetLastError());                                                                \
   } while (0)
+
+// Host threads that are joined when the group goes out of scope -- also when the code between their start and their join throws (ADVICE
+// r05: a std::thread destroyed while joinable ends the process in std::terminate).  A drop-in for std::vector<std::thread>.
+struct ThreadGroup {
+  std::vector<std::thread> th;
+  template <class... A> void emplace_back(A&&... a) { th.emplace_back(std::forward<A>(a)...); }
+  void join() { for (auto& t : th) if (t.joinable()) t.join(); }
+  std::vector<std::thread>::iterator begin() { return th.begin(); }
+  std::vector<std::thread>::iterator end() { return th.end(); }
+  ThreadGroup() {}
+  ThreadGroup(const ThreadGroup&) = delete;
+  ThreadGroup& operator=(const ThreadGroup&) = delete;
+  ~ThreadGroup() { join(); }
+};
 
 // RAII device buffer
 struct DevBuf {

@@ -632,9 +632,9 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     // 2^14 6.1-6.6 / 5.8-6.1).  SONIC_PROVE_SYM=0: never; =1: always (tests).  Not for a piece of a shared proof (the plan counts C's terms).
     const char* se = getenv("SONIC_PROVE_SYM");
     const int mode = se ? atoi(se) : -1;
-    // (round 6: from n = 2^16 -- a proof of that size is one fused chain now and the Q-term MSM runs beside it: streamed 10.40-10.45 against
-    // 10.52-10.66 ms, profiles/r06_ab_small.txt)
-    p->sym_on = mode != 0 && (mode == 1 || p->n >= (1L << 16)) && p->share_world <= 1 && srs_sym(p->srs).p != nullptr;
+    // (round 6, n = 2^16 again, where a proof is one chain now: with / without 9.20-9.25 / 9.08-9.15 ms streamed, 10.44-10.51 / 10.49-10.80
+    // one at a time -- still no gain below 2^17; profiles/r06_ab_small_final.txt)
+    p->sym_on = mode != 0 && (mode == 1 || p->n >= (1L << 17)) && p->share_world <= 1 && srs_sym(p->srs).p != nullptr;
   }
   {
     const MsmPlan probe = srs_msm_plan(srs, 3 * n);
@@ -714,6 +714,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // (packing consecutive groups into ONE batched chain -- fewer, wider chains -- was measured in round 3 and removed in round 5: n = 2^18
   // 35.9 / 38.9 ms streamed / one at a time packed against 35.0 / 35.9: the chains of one proof overlap less)
   std::vector<std::function<void()>> after_flush;       // small MSMs that use the lane's workspace after the batch (stream order)
+  std::vector<std::function<void()>> deferred_small;    // (fused proofs: the same, queued behind the proof's chain)
   // the openings of the group that is being assembled: evaluated and divided together when the group is flushed
   std::vector<PendingOpen> pend;
   auto issue_opens = [&] {
@@ -729,7 +730,11 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     if (p->fused) p->fused_jobs.insert(p->fused_jobs.end(), cur->jobs, cur->jobs + cur->njobs);      // run at the end, as one chain
     else run_jobs(cur->st, srs, cur->ws, cur->jobs, cur->njobs, last, /*exposed=*/p->share_world >= 4);
     cur->njobs = 0;
-    for (auto& f : after_flush) f();
+    // the small MSMs beside a group (Q-term sums): at once behind the group's chain -- or, when the proof is ONE chain, after that chain has
+    // been queued: they are ~14 launches each whose results are only read at the very end, and on a stream the chain waits for they held its
+    // start back by 0.8 ms (n = 2^16 streamed: profiles/r06_streamed_handover.txt)
+    if (p->fused) deferred_small.insert(deferred_small.end(), after_flush.begin(), after_flush.end());
+    else for (auto& f : after_flush) f();
     after_flush.clear();
   };
   // (few_streams: the s(X,y_j) groups ride on the main stream, which has built every polynomial by then; the others on the one lane)
@@ -763,10 +768,14 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
       rb.scal.ensure(sizeof(Fr) * 2 * ntiles); rb.pts.ensure(sizeof(G1Affine) * 2 * ntiles);
       run_tiles_enqueue(cur->st, job.scalars, job.n, rb.masked.as<Fr>(), rb.val.as<Fr>(), rb.uniform.as<uint32_t>());
       HIP_OK(hipEventRecord(rb.masked_ev, cur->st));
-      HIP_OK(hipStreamWaitEvent(ms, rb.masked_ev, 0));
       const long first = (long)((job.points.p - srs_basis(srs, 1).p) / (long)job.points.stride);
-      run_terms_enqueue(ms, rb.val.as<Fr>(), rb.uniform.as<uint32_t>(), ntiles, srs_prefix(srs) + first, first, rb.scal.as<Fr>(), rb.pts.as<G1Affine>());
-      msm_enqueue(ms, p->runs_ws, msm_plan(2 * ntiles), PointArray::packed(rb.pts.as<G1Affine>()), rb.scal.as<Fr>(), 2 * ntiles, true, &slots[(7 + 4 * Q) + j]);
+      sonic_prover::RunBufs* rbp = &rb;
+      auto run_tail = [&, rbp, first, ntiles, j, ms, slots, Q] {
+        HIP_OK(hipStreamWaitEvent(ms, rbp->masked_ev, 0));
+        run_terms_enqueue(ms, rbp->val.as<Fr>(), rbp->uniform.as<uint32_t>(), ntiles, srs_prefix(srs) + first, first, rbp->scal.as<Fr>(), rbp->pts.as<G1Affine>());
+        msm_enqueue(ms, p->runs_ws, msm_plan(2 * ntiles), PointArray::packed(rbp->pts.as<G1Affine>()), rbp->scal.as<Fr>(), 2 * ntiles, true, &slots[(7 + 4 * Q) + j]);
+      };
+      if (p->fused) deferred_small.push_back(run_tail); else run_tail();
       job.scalars = rb.masked.as<Fr>();
       p->slot_ran[(size_t)((7 + 4 * Q) + j)] = 1;
     }
@@ -855,13 +864,17 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // ---- the MSM groups, largest first where its input allows ----
   Lane& lane_t = p->t_lane(p->ev_sy0);
   if (on(PH_OPEN) && first_piece(4)) {                                                 // s(z,y)       :83  (reported by the rank that starts W_t)
-    Scratch& es = lane_t.sc[MSM_MAX_JOBS - 1];
+    // (few_streams: on the lane, not behind the transform on its stream -- the evaluation needs s(X,y) only, and everything queued on the
+    // transform's stream is on the longest dependent chain of a proof)
+    Lane& le = p->few_streams ? p->lanes[0] : lane_t;
+    if (p->few_streams) HIP_OK(hipStreamWaitEvent(le.st, p->ev_sy0, 0));
+    Scratch& es = le.sc[MSM_MAX_JOBS - 1];
     es.reserve(s_len);
     es.scan.ensure(sizeof(Fr) * (s_len / 1024 + 2));
     OpenBatch eb;
     memset(&eb, 0, sizeof eb);
     eb.k = 1; eb.poly[0] = sy; eb.D[0] = es.D.as<Fr>(); eb.q[0] = es.q.as<Fr>(); eb.tiles[0] = es.scan.as<Fr>(); eb.zpair[0] = pZ; eb.fz[0] = &frout[2];
-    open_batch_enqueue(lane_t.st, eb, s_lo, s_len, /*quotient=*/false);
+    open_batch_enqueue(le.st, eb, s_lo, s_len, /*quotient=*/false);
     p->fr_valid[2] = 1;
   }
   group0();
@@ -894,41 +907,64 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
       p->slot_ran[(size_t)(6 + 4 * Q)] = 1;
       cur->jobs[cur->njobs++] = job;
       p->slot_ran[(size_t)(7 + 5 * Q)] = 1;                                                     // exponents n+1 .. n+Q, on the main stream (su was built there)
-      msm_enqueue(ms, p->runs_ws, msm_plan(Q), srs_basis(srs, 1) + (d + n + 1), su + (2 * n + 1), Q, true, &slots[7 + 5 * Q]);
+      auto c_tail = [&, su, d, n, Q, slots, ms] { msm_enqueue(ms, p->runs_ws, msm_plan(Q), srs_basis(srs, 1) + (d + n + 1), su + (2 * n + 1), Q, true, &slots[7 + 5 * Q]); };
+      if (p->fused) deferred_small.push_back(c_tail); else c_tail();
     } else
       commit(PH_HSCW, su, u_lo, u_len, d, 6 + 4 * Q);                                // C             :52
     for (long j = 0; j < Q; j++) open(PH_HSCW, su, u_lo, u_len, pYj(j), 3 + Q + j, 6 + 2 * Q + 2 * j);   // (s'_j, Q_j) :55
     open(PH_QV, su, u_lo, u_len, pV, -1, 5 + 4 * Q);                                 // Q_v           :63
   }
   flush_now(last_group == 2 && sh != nullptr);
-  if (need_T) {
+  static const bool split_t = getenv("SONIC_FUSED_SPLIT_T") && atoi(getenv("SONIC_FUSED_SPLIT_T")) != 0;
+  auto t_group = [&](bool own_chain) {
     if (on(PH_T) && lane_t.st != p->ts) HIP_OK(hipStreamWaitEvent(lane_t.st, p->ev_t, 0));
     cur = &lane_t; cur->njobs = 0;
     commit(PH_T, t, t_lo, t_len, d, 1);                                                // T            Protocol.hs:73
     open(PH_OPEN, t, t_lo, t_len, pZ, -1, 4);                                          // W_t          :81
-    flush_group(true);
-  }
+    if (p->fused && own_chain) {
+      issue_opens();
+      if (cur->njobs > 0) {
+        long nmax = 0;
+        for (int j = 0; j < cur->njobs; j++) nmax = std::max(nmax, cur->jobs[j].n);
+        MsmPlan pl = srs_msm_plan(srs, nmax);
+        pl.tree = true;
+        msm_enqueue_batch(cur->st, cur->ws, pl, cur->jobs, cur->njobs, true);
+        cur->njobs = 0;
+      }
+    } else
+      flush_group(true);
+  };
+  if (need_T && !(p->fused && split_t)) t_group(false);
   if (p->fused && !p->fused_jobs.empty()) {
-    // the proof's chain(s): every lane has queued its openings by now; chunks of at most MSM_MAX_JOBS jobs (one chunk up to Q = 2),
-    // on the two chain streams in turn so that two chunks overlap like two groups did
+    // the proof's chain(s): every lane has queued the openings of its groups by now; chunks of at most MSM_MAX_JOBS jobs (one chunk up to
+    // Q = 2) on the two chain streams in turn so that two chunks overlap like two groups did
     for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipEventRecord(p->lanes[i].prep, p->lanes[i].st));
-    if (p->few_streams) { HIP_OK(hipEventRecord(p->main_lane.prep, ms)); if (need_T) HIP_OK(hipEventRecord(p->ts_lane.prep, p->ts)); }
+    if (p->few_streams) { HIP_OK(hipEventRecord(p->main_lane.prep, ms)); if (need_T && !split_t) HIP_OK(hipEventRecord(p->ts_lane.prep, p->ts)); }
     const int total = (int)p->fused_jobs.size();
     const int nchunks = (total + MSM_MAX_JOBS - 1) / MSM_MAX_JOBS, per = (total + nchunks - 1) / nchunks;
     for (int c = 0, at = 0; c < nchunks; c++, at += per) {
       Lane& cl = p->chain[c & 1];
       if (c < 2) {
         for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipStreamWaitEvent(cl.st, p->lanes[i].prep, 0));
-        if (p->few_streams) { HIP_OK(hipStreamWaitEvent(cl.st, p->main_lane.prep, 0)); if (need_T) HIP_OK(hipStreamWaitEvent(cl.st, p->ts_lane.prep, 0)); }
+        if (p->few_streams) { HIP_OK(hipStreamWaitEvent(cl.st, p->main_lane.prep, 0)); if (need_T && !split_t) HIP_OK(hipStreamWaitEvent(cl.st, p->ts_lane.prep, 0)); }
       }
       const int k = std::min(per, total - at);
       long nmax = 0;
       for (int j = 0; j < k; j++) nmax = std::max(nmax, p->fused_jobs[(size_t)(at + j)].n);
       MsmPlan pl = srs_msm_plan(srs, nmax);
       pl.tree = true;
+      pl.accum_block = 128;      // (measured for this chain, n = 2^16 streamed: 128 lanes 9.19-9.27 ms, 256 9.46-9.49, 512 9.42-9.46)
       msm_enqueue_batch(cl.st, cl.ws, pl, &p->fused_jobs[(size_t)at], k, true);
     }
+    p->fused_jobs.clear();
   }
+  // (SONIC_FUSED_SPLIT_T=1, measured and not the default: T and W_t -- 14n of a proof's 45n terms, and the group whose polynomial is ready
+  // last -- as a SECOND chain on the stream that made the polynomial, so that the chain of the other thirteen MSMs need not wait for the
+  // product.  One at a time it gains 1-3 %; streamed it loses 3-10 % at n = 2^14 .. 2^16: two sorts, two accumulation tails and two
+  // butterflies per proof; profiles/r06_ab_small_final.txt)
+  if (need_T && p->fused && split_t) t_group(true);
+  for (auto& f : deferred_small) f();
+  deferred_small.clear();
   for (int i = 0; i < p->n_lanes; i++) { Lane& l = p->lanes[i]; HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   if (p->fused) for (auto& l : p->chain) if (l.st) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   if (p->few_streams && need_T) { HIP_OK(hipEventRecord(p->ts_lane.done, p->ts_lane.st)); HIP_OK(hipStreamWaitEvent(ms, p->ts_lane.done, 0)); }
@@ -1105,7 +1141,7 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
     bool main_folded = true, extra_folded = true;
     for (int i = 0; i < K; i++) main_folded = main_folded && is_folded(i);
     for (int j = 0; has_extra && j < (int)Q; j++) extra_folded = extra_folded && is_folded(K + j);
-    std::vector<std::thread> th;
+    ThreadGroup th;
     G1XYZZ extra_c = G1XYZZ::inf();                        // the Q-term half of C (per-window sums: a Horner walk, on a thread of its own)
     if (p->sym_on) th.emplace_back([&] { extra_c = msm_finish_host(hs[K + Q]); });
     if (has_extra && !extra_folded) {                      // the Horner walks of the extra slots beside the main thread's tails
@@ -1117,7 +1153,7 @@ static int prove_finish(sonic_prover_t* p, uint8_t* out_proof) {
     if (main_folded) {
       for (int i = 0; i < K; i++) sums[i] = msm_finish_host(hs[i]);
     } else {
-      std::vector<std::thread> th2;
+      ThreadGroup th2;
       const int nt = K < 16 ? K : 16;
       for (int w = 0; w < nt; w++) th2.emplace_back([&, w] { for (int i = w; i < K; i += nt) sums[i] = msm_finish_host(hs[i]); });
       for (auto& x : th2) x.join();
@@ -1371,7 +1407,7 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   if (hflags) return flags_to_status(hflags, "sonic_prover_prepare");
   std::vector<G1Affine> cq(Q);
   {
-    std::vector<std::thread> th;
+    ThreadGroup th;
     const int nt = (int)std::min<long>(Q, 16);
     for (int w = 0; w < nt; w++)
       th.emplace_back([&, w] { for (long q = w; q < Q; q += nt) cq[q] = g1_to_affine(msm_finish_host(hs[q])); });
@@ -1382,7 +1418,7 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   if (Q <= CQ_TAB_MAX_Q) {
     // tab[w * Q + q] = 2^shift(w) C_q: 255 doublings per C_q, once per circuit, on the host
     std::vector<G1XYZZ> tx((size_t)CQ_TAB_W * Q);
-    std::vector<std::thread> th;
+    ThreadGroup th;
     const int nt = (int)std::min<long>(Q, 16);
     for (int t = 0; t < nt; t++)
       th.emplace_back([&, t] {
@@ -1498,7 +1534,7 @@ int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, con
     if (folded) {
       for (long i = 0; i < K; i++) sums[i] = msm_finish_host(hs[i]);
     } else {
-      std::vector<std::thread> th;
+      ThreadGroup th;
       const int nt = (int)std::min<long>(K, 16);
       for (int w = 0; w < nt; w++) th.emplace_back([&, w] { for (long i = w; i < K; i += nt) sums[i] = msm_finish_host(hs[i]); });
       for (auto& x : th) x.join();
@@ -1757,7 +1793,7 @@ int sonic_prove_many(const sonic_srs_t* const* srs, int n_srs, int64_t n, int64_
     }
   };
   {
-    std::vector<std::thread> th;
+    ThreadGroup th;
     for (int t = 1; t < T && t < K; t++) th.emplace_back(body, t);
     body(0);
     for (auto& x : th) x.join();
@@ -1806,7 +1842,7 @@ int sonic_prove_shared(sonic_prover_t* const* provers, int world, const uint8_t*
     rcs[(size_t)r] = rc;
   };
   {
-    std::vector<std::thread> th;
+    ThreadGroup th;
     for (int r = 1; r < world; r++) th.emplace_back(body, r);
     body(0);                                                       // the calling thread is rank 0's
     for (auto& t : th) t.join();
@@ -1844,7 +1880,7 @@ int sonic_prove_batch(sonic_prover_t* const* provers, int n_provers, int64_t K, 
     }
   };
   {
-    std::vector<std::thread> th;
+    ThreadGroup th;
     for (int h = 1; h < n_provers && h < K; h++) th.emplace_back(body, h);
     body(0);
     for (auto& t : th) t.join();

@@ -124,7 +124,7 @@ int run_checks(const sonic_srs* srs, const VerifierKey& vk, const std::vector<Pc
     for (size_t i = w; i < checks.size(); i += stride)
       ok[i] = pc_v_equation(vk, elems[which[i]], checks[i].F, checks[i].z, checks[i].val, checks[i].W) ? 1 : 0;
   };
-  std::vector<std::thread> th;
+  ThreadGroup th;
   int started = 0;
   try {
     for (; started < nt; started++) th.emplace_back(work, started, nt);

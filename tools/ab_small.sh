@@ -10,19 +10,16 @@ run() {  # label, log2n, env...
 for rep in 1 2; do
 for lg in $LGS; do
   run "default" $lg A=1
-  run "stagger off" $lg SONIC_ACCUM_STAGGER=0
-  run "priorities off" $lg SONIC_PROVE_PRIORITIES=0
-  run "stagger off, priorities off" $lg SONIC_ACCUM_STAGGER=0 SONIC_PROVE_PRIORITIES=0
-  run "accum block 64" $lg SONIC_FUSED_ACCUM_BLOCK=64
-  run "accum block 64, priorities off" $lg SONIC_FUSED_ACCUM_BLOCK=64 SONIC_PROVE_PRIORITIES=0
   run "not fused (round 5 lanes)" $lg SONIC_PROVE_FUSED=0
+  run "six lanes of their own" $lg SONIC_FUSED_LANES=6
+  run "stream priorities" $lg SONIC_PROVE_PRIORITIES=1
+  run "t group as a chain of its own" $lg SONIC_FUSED_SPLIT_T=1
   if [ $lg -le 15 ]; then
     run "table c = 17" $lg SONIC_MSM_TABLE_C=17
-    run "table c = 16" $lg SONIC_MSM_TABLE_C=16
-    run "table c = 14" $lg SONIC_MSM_TABLE_C=14
+    run "table c = 15" $lg SONIC_MSM_TABLE_C=15
   else
     run "table c = 16" $lg SONIC_MSM_TABLE_C=16
-    run "sym on" $lg SONIC_PROVE_SYM=1
+    run "C over the plain basis" $lg SONIC_PROVE_SYM=0
   fi
 done
 done

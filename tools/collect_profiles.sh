@@ -2,13 +2,19 @@
 # Collects the measurements DESIGN.md section 5 quotes, on one MI355X box:  bash tools/collect_profiles.sh r03
 # Writes gpurun_out/<tag>/...; tools/publish_profiles.sh <tag> copies the summaries into profiles/ afterwards.
 # PMC passes are separate runs with one counter group each and no tracing, as MI355X_MICROARCH.md's HBM section prescribes.
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 tools/cpu_scaling.py --log2 18 > $OUT/cpu_scaling.txt 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/microbench > $OUT/microbench.txt 2>&1
+# per-category ISA budget of one bucket-walk addition at the microbenchmark's issue rates (round 6; the static count needs no GPU, the rates are this box's)
+python3 tools/accum_isa.py $OUT/microbench.txt > $OUT/accum_isa.txt 2>&1
+# stand-alone MSMs over small SRSs: two / four lanes per bucket against one (round 6)
+{ echo "# python tools/msm_small.py: stand-alone MSMs over a SMALL SRS (one job of 2^15 / 2^16 shared buckets), scalars resident in HBM, one MSM at a time"
+  echo "## two / four lanes per bucket (k_bucket_accum_split: launches of <= 131072 / <= 65536 buckets)"; python3 tools/msm_small.py 2>/dev/null | grep "d=2"
+  echo "## SONIC_ACCUM_LANES=1: one lane per bucket (round 5)"; SONIC_ACCUM_LANES=1 python3 tools/msm_small.py 2>/dev/null | grep "d=2"; } > $OUT/msm_small.txt
 ./tools/ba_bench > $OUT/ba_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm_only -o t -- python3 bench.py --msm-only --msm-lanes 0 --no-cpu --steps 5 --warmup 1 > $OUT/msm_only.json 2> $OUT/msm_only.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python3 bench.py --no-cpu --no-sensitivities > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
@@ -42,7 +48,7 @@ rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc_valu -o t -- pytho
 python3 tools/valu_budget.py $(find $OUT/pmc_valu -name "*counter_collection.csv" | head -1) 3 > $OUT/valu_budget.txt 2>&1
 {
   echo "# python bench.py --no-cpu --log2n <k> (10 streamed proofs after 2 warm-up, Q = 2, d = 8n): ms per proof streamed / strictly sequential"
-  for lg in 10 13 14 16 17 18 19 20; do
+  for lg in 10 13 14 15 16 17 18 19 20; do
     python3 bench.py --no-cpu --no-sensitivities --strong-log2n 0 --log2n $lg --msm-log2 12 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=2^$lg  d=2^$((lg+3))  streamed %.2f  sequential %.2f' % (d['ms_per_step'], d['sequential']['ms_per_proof']))"
   done
   echo "# sensitivity to Q at n = 2^18 (7 + 4Q MSMs per proof)"
@@ -75,6 +81,10 @@ bash tools/ab_runs.sh > $OUT/runs_ab.txt 2>&1
 bash tools/ab_sym.sh > $OUT/sym_ab.txt 2>&1
 ./tools/mfma_bound > $OUT/mfma_bound.txt 2>&1
 python3 tools/criterion_shape.py > $OUT/criterion_shape.txt 2>&1
+# small proofs (round 6): one solo proof per hardware queue at n = 2^14, and how two streamed proofs hand the chip over at n = 2^16
+rocprofv3 --kernel-trace --output-format csv -d $OUT/solo14 -o t -- python3 bench.py --log2n 14 --steps 3 --warmup 2 --no-cpu --no-pipeline --prove-only --strong-log2n 0 > /dev/null 2> $OUT/solo14.err
+python3 tools/perqueue.py $(find $OUT/solo14 -name "*kernel_trace.csv" | head -1) 15 > $OUT/timeline_solo14.txt 2>&1
+bash tools/ab_small.sh "14 16" 30 > $OUT/ab_small.txt 2>&1
 python3 tools/throughput_mode.py > $OUT/throughput_mode.txt 2>&1
 python3 tools/throughput_mode.py --log2n 18 --proofs 16 >> $OUT/throughput_mode.txt 2>&1
 # timeline of one solo proof (no streaming): where the time of prove() goes

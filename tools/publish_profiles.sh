@@ -1,10 +1,10 @@
 #!/bin/bash
 # Copies the summaries of gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/ under the round's prefix, and derives
 # the two JSON files bench.py reads (kernel model, HBM traffic per kernel).   bash tools/publish_profiles.sh r03
-TAG=${1:-r05}
+TAG=${1:-r06}
 IN=gpurun_out/$TAG
 P=profiles
-for f in bench.json lds_counters.txt microbench.txt ba_bench.txt in_process_one_gpu.json prove_strong_emulated.txt mfma_bound.txt criterion_shape.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt msm_shaped.json runs_ab.txt sym_ab.txt; do
+for f in bench.json lds_counters.txt microbench.txt ba_bench.txt in_process_one_gpu.json prove_strong_emulated.txt mfma_bound.txt criterion_shape.txt msm_only.json bench_under_rocprof.json prove_sizes.txt msm_sizes.txt msm_strong_emulated.txt throughput_mode.txt timeline_solo.txt valu_budget.txt cpu_scaling.txt msm_shaped.json runs_ab.txt sym_ab.txt accum_isa.txt msm_small.txt timeline_solo14.txt; do
   [ -f $IN/$f ] && cp $IN/$f $P/${TAG}_$f
 done
 cp $(find $IN/msm_only -name "*kernel_stats.csv" | head -1) $P/${TAG}_msm_only_kernel_stats.csv
@@ -26,4 +26,5 @@ done
 read c w s < <(python3 -c "import json; j=json.load(open('$IN/bench.json'))['int_roofline']['plan'] if json.load(open('$IN/bench.json')).get('int_roofline',{}).get('plan') else {'window_bits':20,'windows':13,'bucket_sets':1}; print(j['window_bits'], j['windows'], j['bucket_sets'])")
 python3 tools/pmc_summary.py $P/${TAG}_pmc_FETCH_SIZE_counter_collection.csv $P/${TAG}_pmc_WRITE_SIZE_counter_collection.csv 1048576 $c $w $s > $P/${TAG}_pmc_msm.json
 python3 tools/kernel_model.py $TAG $P/${TAG}_microbench.txt > /dev/null
+[ -f $IN/ab_small.txt ] && cp $IN/ab_small.txt $P/${TAG}_ab_small_final.txt
 ls -la $P | grep ${TAG}_
