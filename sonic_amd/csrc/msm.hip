@@ -336,6 +336,12 @@ __global__ __launch_bounds__(256) void k_part_scatter(const MsmBatchDev batch, i
 // consecutive addresses.  LDS: records 8 B + partition id 2 B per (scalar, window) + two words per partition -- 148 KB at 13 windows
 // and 2048 partitions, one workgroup per CU (the pass is short); plans that need more than SORT_STAGE_MAX_LDS use the direct kernel.
 constexpr size_t SORT_STAGE_MAX_LDS = 156 * 1024;
+// PLANES (round 6, VERDICT r05 item 6: the split-plane layout that removed the transforms' LDS bank conflicts, tried here): the two words of
+// a record in two planes of 4-byte slots instead of one array of 8-byte records.  Measured -- profiles/r06_sort_planes_ab.txt -- and NOT the
+// default: the records are scattered to RANDOM slots (that is what a counting sort's placement is), so a wave's 64 writes meet the 64 banks
+// like 64 balls thrown at 64 bins whether a slot is one bank wide or two; the conflicts of this kernel and of k_part_sort (42-54 % of the
+// LDS-active cycles) are those of the placement and of the LDS atomics on random counters, not of a layout.
+template <bool PLANES>
 __global__ __launch_bounds__(PART_SCATTER_THREADS) void k_part_scatter_staged(const MsmBatchDev batch, int c, int W, int keystride, int mont, int fold, int P,
                                                              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ base,
                                                              uint2* __restrict__ part) {
@@ -343,6 +349,8 @@ __global__ __launch_bounds__(PART_SCATTER_THREADS) void k_part_scatter_staged(co
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem_stage);                 // [P]  running local cursor
   uint32_t* delta = cur + P;                                                // [P]  global position - local position of the partition's run
   uint2* recs = reinterpret_cast<uint2*>(delta + P);                        // [PART_TILE * W]
+  uint32_t* rec_lo = reinterpret_cast<uint32_t*>(recs);                     // (PLANES: the same bytes as two arrays of words)
+  uint32_t* rec_hi = rec_lo + (size_t)PART_TILE * W;
   uint16_t* pid = reinterpret_cast<uint16_t*>(recs + (size_t)PART_TILE * W);  // [PART_TILE * W]
   __shared__ uint32_t sc[256];
   __shared__ uint32_t total_sh;
@@ -378,14 +386,15 @@ __global__ __launch_bounds__(PART_SCATTER_THREADS) void k_part_scatter_staged(co
         const uint32_t pr = key >> PART_LOW_BITS;
         const uint32_t pos = lds_take(cur, d != 0, pr);
         if (d) {
-          recs[pos] = make_uint2(key & ((1u << PART_LOW_BITS) - 1), (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (sign << 31));
+          const uint32_t lo = key & ((1u << PART_LOW_BITS) - 1), hi = (uint32_t)i | (keystride ? 0u : (uint32_t)w << 26) | (sign << 31);
+          if (PLANES) { rec_lo[pos] = lo; rec_hi[pos] = hi; } else recs[pos] = make_uint2(lo, hi);
           pid[pos] = (uint16_t)pr;
         }
       }
     }
     __syncthreads();
     const uint32_t total = total_sh;
-    for (uint32_t i = threadIdx.x; i < total; i += T) part[delta[pid[i]] + i] = recs[i];
+    for (uint32_t i = threadIdx.x; i < total; i += T) part[delta[pid[i]] + i] = PLANES ? make_uint2(rec_lo[i], rec_hi[i]) : recs[i];
     __syncthreads();
   }
 }
@@ -1192,7 +1201,8 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     // kernels instead of failing the MSM
     DeviceCtx& dctx = current_ctx();
     if (dctx.sort_staged < 0) {
-      const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_STAGE_MAX_LDS);
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter_staged<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_STAGE_MAX_LDS);
+      if (e1 == hipSuccess) e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter_staged<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_STAGE_MAX_LDS);
       const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
       if (e1 != hipSuccess || e2 != hipSuccess) (void)hipGetLastError();
       dctx.sort_staged = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : 0;
@@ -1200,8 +1210,11 @@ void msm_enqueue_batch(hipStream_t st, MsmWorkspace& ws, const MsmPlan& pl, cons
     const bool staged_on = dctx.sort_staged == 1;
     const size_t stage_lds = (size_t)P * 8 + (size_t)PART_TILE * pl.W * 10;
     if (staged_on && stage_lds <= SORT_STAGE_MAX_LDS && P <= 65535) {
-      LAUNCH(k_part_scatter_staged, pgrid, PART_SCATTER_THREADS, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,
-             (const uint32_t*)hbase, ws.digits.as<uint2>());
+      static const bool planes = getenv("SONIC_SORT_PLANES") && atoi(getenv("SONIC_SORT_PLANES")) != 0;
+      if (planes) LAUNCH(k_part_scatter_staged<true>, pgrid, PART_SCATTER_THREADS, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,
+                         (const uint32_t*)hbase, ws.digits.as<uint2>());
+      else LAUNCH(k_part_scatter_staged<false>, pgrid, PART_SCATTER_THREADS, stage_lds, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hist,
+                  (const uint32_t*)hbase, ws.digits.as<uint2>());
     } else {
       LAUNCH(k_part_scatter, pgrid, 256, P * 4, st, batch, pl.c, pl.W, keystride, (int)scalars_mont, (int)fold, P, (const uint32_t*)hbase,
              ws.digits.as<uint2>());

@@ -215,18 +215,17 @@ struct sonic_prover {
   bool have_assignment = false;
   DevBuf wL, wR, wO, cs, aL, aR, aO;        // Montgomery, resident across proofs
   Lane lanes[N_LANES];
-  // lanes in use: all of them, or -- a handle whose proofs are ONE chain (small_plan) -- SONIC_FUSED_LANES (default 3: two for the groups'
-  // openings, one for the t group's).  The runtime multiplexes a process's streams onto 8 hardware queues in creation order; two streamed
-  // handles with ten streams each put one handle's openings behind the OTHER handle's accumulation on a shared queue (in order: 7 ms late,
-  // profiles/r06_small_proofs.txt).  More hardware queues were measured and are worse (GPU_MAX_HW_QUEUES = 12 .. 32: +1 ms on a sequential
-  // n = 2^14 / 2^16 proof, profiles/r06_ab_queues.txt), so the handles use fewer streams instead.
+  // lanes in use: all six by default.  SONIC_FUSED_LANES=k (small-proof handles): k lanes of their own; =0: NO lane of its own
+  // (few_streams) -- three streams per handle: main, transform, chain; the groups' openings ride on the streams that are waiting anyway
+  // (r(X,1)'s on the transform's stream ahead of the product, the s(X,y_j) groups' and s(u,Y)'s on the main stream behind the polynomials,
+  // t(X,y)'s behind the product) through two lanes that only borrow those streams.  Why the knob exists: the runtime multiplexes a process's
+  // streams onto 8 hardware queues, a new stream getting the least-used one, so WHICH of two streamed handles' twenty streams share a queue
+  // is luck -- one handle's openings behind the other handle's accumulation cost 10 % -- and more hardware queues are worse
+  // (GPU_MAX_HW_QUEUES = 12 .. 32: +1 ms on a sequential small proof, profiles/r06_ab_queues.txt).  Measured, 64 proofs at n = 2^16 on one
+  // box, four fresh pairs of handles each (profiles/r06_batch_mode.txt): six lanes 104-107 proofs/s; three streams 99.2-100.5, every time;
+  // one lane + the borrowed streams (four streams) 98-111 depending on the order the handles were made in.  Three streams lose the
+  // side-by-side openings (n = 2^14 streamed 3.8 against 3.45 ms, n = 2^10 1.5 against 1.2), so six lanes stay the default.
   int n_lanes = N_LANES;
-  // ... down to ONE lane by default (four streams per handle, eight for the two handles of a stream of proofs: no two share a queue): the
-  // groups' openings then go to the streams that are waiting anyway -- r(X,1)'s and s(u,Y)'s to the lane, the s(X,y_j) groups to the main
-  // stream behind the polynomials, t(X,y)'s to the transform's stream -- through two lanes that only borrow those streams.  Measured, ms per
-  // proof streamed / one at a time (profiles/r06_ab_lanes.txt): six lanes 9.35 / 10.5 at n = 2^16 and 3.37 / 3.85 at 2^14, three lanes
-  // 10.85 / 10.4 and 4.28 / 3.70 (one handle's lane behind the other handle's accumulation), one lane with ALL openings on it 9.3 / 10.9
-  // and 3.25 / 4.08.
   bool few_streams = false;
   Lane main_lane, ts_lane;                   // st = the handle's main / transform stream (not owned)
   // fused proofs (below): the proof's ONE chain runs on a stream of its own.  (Stream priorities -- the chain lowest, everything that builds
@@ -329,7 +328,9 @@ struct sonic_prover {
   // Lane N_LANES-1 carries the t(X,y) group (the largest, ready last); the other groups alternate over the rest, which
   // balances the point additions per lane (Q = 2: 55M / 51M / 48M) while one lane's sort and reduction phases run under
   // another lane's accumulation.  Streams beyond the 4 hardware queues would serialise behind each other.
+  Lane& lane_at(int i) { return few_streams ? ((i & 1) ? ts_lane : main_lane) : lanes[i % n_lanes]; }      // (prepare, hscProve: any lane)
   Lane& pick(hipEvent_t ready) {
+    if (few_streams) return main_lane;
     Lane& l = lanes[next_lane];
     next_lane = (next_lane + 1) % (n_lanes > 1 ? n_lanes - 1 : 1);
     (void)hipStreamWaitEvent(l.st, ready, 0);
@@ -511,9 +512,9 @@ int sonic_prover_new(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t
   // MSM workspaces and opening scratch grow on first use: every proof maps the same group of MSMs to the same lane
   if (p->small_plan) {
     const char* le = getenv("SONIC_FUSED_LANES");
-    const int v = le ? atoi(le) : 0;                       // 0: one lane + the borrowed streams (few_streams); k: k lanes of their own
+    const int v = le ? atoi(le) : N_LANES;                 // 0: no lane of its own (few_streams); k: k lanes
     p->few_streams = v <= 0;
-    p->n_lanes = v < 1 ? 1 : (v > N_LANES ? N_LANES : v);
+    p->n_lanes = v < 1 ? 0 : (v > N_LANES ? N_LANES : v);
     if (p->few_streams) {
       p->main_lane.st = p->st; p->ts_lane.st = p->ts;
       mkev(&p->main_lane.done); mkev(&p->main_lane.prep);
@@ -737,10 +738,10 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     else for (auto& f : after_flush) f();
     after_flush.clear();
   };
-  // (few_streams: the s(X,y_j) groups ride on the main stream, which has built every polynomial by then; the others on the one lane)
-  auto begin_group = [&](hipEvent_t e, bool on_main = false) {
+  // (few_streams: on_ts = the group rides on the transform's stream -- r(X,1)'s, queued there ahead of the product --, else on the main stream)
+  auto begin_group = [&](hipEvent_t e, bool on_ts = false) {
     flush_now();
-    if (p->few_streams && on_main) cur = &p->main_lane;
+    if (p->few_streams && on_ts) { cur = &p->ts_lane; HIP_OK(hipStreamWaitEvent(p->ts, e, 0)); }
     else cur = &p->pick(e);
     cur->njobs = 0;
   };
@@ -810,12 +811,13 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   auto group0 = [&] {
     if (!need_g0 || g0_queued) return;
     g0_queued = true;
-    begin_group(p->ev_r1);
+    begin_group(p->ev_r1, /*on_ts=*/true);
     commit(PH_R, r1, r_lo, r_len, n, 0);                                               // R            :63
     open(PH_OPEN, r1, r_lo, r_len, pZ, 0, 2);                                          // (a, W_a)     :79
     open(PH_OPEN, r1, r_lo, r_len, pYZ, 1, 3);                                         // (b, W_b)     :80
     flush_group(last_group == 0);
   };
+  if (p->few_streams && p->fused) group0();          // (its openings go on the transform's stream, ahead of the product's kernels)
   if (p->pend_circuit[0]) {
     group0();
     const uint8_t* const* c = p->pend_circuit;
@@ -864,10 +866,9 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   // ---- the MSM groups, largest first where its input allows ----
   Lane& lane_t = p->t_lane(p->ev_sy0);
   if (on(PH_OPEN) && first_piece(4)) {                                                 // s(z,y)       :83  (reported by the rank that starts W_t)
-    // (few_streams: on the lane, not behind the transform on its stream -- the evaluation needs s(X,y) only, and everything queued on the
-    // transform's stream is on the longest dependent chain of a proof)
-    Lane& le = p->few_streams ? p->lanes[0] : lane_t;
-    if (p->few_streams) HIP_OK(hipStreamWaitEvent(le.st, p->ev_sy0, 0));
+    // (few_streams: on the main stream, not behind the transform on its stream -- the evaluation needs s(X,y) only, and everything queued
+    // behind the transform is on the longest dependent chain of a proof)
+    Lane& le = p->few_streams ? p->main_lane : lane_t;
     Scratch& es = le.sc[MSM_MAX_JOBS - 1];
     es.reserve(s_len);
     es.scan.ensure(sizeof(Fr) * (s_len / 1024 + 2));
@@ -881,7 +882,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   for (long j = 0; j < Q; j++) {
     if (!need_j[(size_t)j]) continue;
     Fr* syj = p->syj[j].as<Fr>();
-    begin_group(p->ev_syj[j], /*on_main=*/true);
+    begin_group(p->ev_syj[j]);
     if (p->prepared) commit(PH_HSCS, p->diag[j].as<Fr>(), n + 1, n, d, 5 + 2 * j);   // S_j (diagonal part)   Signature.hs:42
     else if (p->runs_on) commit_runs(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j, j);    // S_j, runs through the running sums   :42
     else commit(PH_HSCS, syj, s_lo, s_len, d, 5 + 2 * j);                            // S_j                   :42
@@ -939,14 +940,14 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
     // the proof's chain(s): every lane has queued the openings of its groups by now; chunks of at most MSM_MAX_JOBS jobs (one chunk up to
     // Q = 2) on the two chain streams in turn so that two chunks overlap like two groups did
     for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipEventRecord(p->lanes[i].prep, p->lanes[i].st));
-    if (p->few_streams) { HIP_OK(hipEventRecord(p->main_lane.prep, ms)); if (need_T && !split_t) HIP_OK(hipEventRecord(p->ts_lane.prep, p->ts)); }
+    if (p->few_streams) { HIP_OK(hipEventRecord(p->main_lane.prep, ms)); if (need_T || g0_queued) HIP_OK(hipEventRecord(p->ts_lane.prep, p->ts)); }
     const int total = (int)p->fused_jobs.size();
     const int nchunks = (total + MSM_MAX_JOBS - 1) / MSM_MAX_JOBS, per = (total + nchunks - 1) / nchunks;
     for (int c = 0, at = 0; c < nchunks; c++, at += per) {
       Lane& cl = p->chain[c & 1];
       if (c < 2) {
         for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipStreamWaitEvent(cl.st, p->lanes[i].prep, 0));
-        if (p->few_streams) { HIP_OK(hipStreamWaitEvent(cl.st, p->main_lane.prep, 0)); if (need_T && !split_t) HIP_OK(hipStreamWaitEvent(cl.st, p->ts_lane.prep, 0)); }
+        if (p->few_streams) { HIP_OK(hipStreamWaitEvent(cl.st, p->main_lane.prep, 0)); if (need_T || g0_queued) HIP_OK(hipStreamWaitEvent(cl.st, p->ts_lane.prep, 0)); }
       }
       const int k = std::min(per, total - at);
       long nmax = 0;
@@ -967,7 +968,7 @@ static int prove_enqueue(sonic_prover_t* p, const uint8_t* transcript) {
   deferred_small.clear();
   for (int i = 0; i < p->n_lanes; i++) { Lane& l = p->lanes[i]; HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
   if (p->fused) for (auto& l : p->chain) if (l.st) { HIP_OK(hipEventRecord(l.done, l.st)); HIP_OK(hipStreamWaitEvent(ms, l.done, 0)); }
-  if (p->few_streams && need_T) { HIP_OK(hipEventRecord(p->ts_lane.done, p->ts_lane.st)); HIP_OK(hipStreamWaitEvent(ms, p->ts_lane.done, 0)); }
+  if (p->few_streams && (need_T || g0_queued)) { HIP_OK(hipEventRecord(p->ts_lane.done, p->ts_lane.st)); HIP_OK(hipStreamWaitEvent(ms, p->ts_lane.done, 0)); }
   Fr* frstd = p->frstd.as<Fr>();
   HIP_OK(hipMemcpyAsync(frstd, frout, sizeof(Fr) * (3 + 2 * Q), hipMemcpyDeviceToDevice, ms));
   fr_from_mont_enqueue(ms, frstd, 3 + 2 * Q);
@@ -1393,13 +1394,14 @@ int sonic_prover_prepare(sonic_prover_t* p) {
   std::vector<DevBuf> rows(std::min<long>(Q, N_LANES));
   for (auto& b : rows) b.alloc(sizeof(Fr) * (3 * n + 1));
   for (long q = 0; q < Q; q++) {
-    Lane& l = p->lanes[q % p->n_lanes];
-    Fr* row = rows[q % p->n_lanes].as<Fr>();
+    Lane& l = p->lane_at((int)(q % N_LANES));
+    Fr* row = rows[q % N_LANES].as<Fr>();
     weight_row_poly_enqueue(l.st, p->wL.as<Fr>(), p->wR.as<Fr>(), p->wO.as<Fr>(), n, q, row);
     MsmJob job = commit_job(l.st, p->srs, row, -n, 3 * n + 1, d, slots.as<MsmSlot>() + q, flags);
     run_jobs(l.st, p->srs, l.ws, &job, 1);
   }
   for (int i = 0; i < p->n_lanes; i++) HIP_OK(hipStreamSynchronize(p->lanes[i].st));
+  if (p->few_streams) { HIP_OK(hipStreamSynchronize(p->st)); HIP_OK(hipStreamSynchronize(p->ts)); }
   std::vector<MsmSlot> hs(Q);
   HIP_OK(hipMemcpy(hs.data(), slots.p, sizeof(MsmSlot) * Q, hipMemcpyDeviceToHost));
   int hflags = 0;
@@ -1490,7 +1492,7 @@ int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, con
   const Fr *pU = P0 + 2 * (2 * m), *pV = P0 + 2 * (2 * m + 1);
   MsmSlot* sl = slots.as<MsmSlot>();
   Fr* fo = frout.as<Fr>();
-  Lane& lane = p->lanes[0];
+  Lane& lane = p->lane_at(0);
   const long s_lo = -n, s_len = 3 * n + 1, u_lo = -n, u_len = 2 * n + Q + 1;
   // slots: S_j = 3j, W_j = 3j + 1, W'_j = 3j + 2;  Q_j = 3m + j;  Q_v = 4m;  C = 4m + 1.   frout: s_j = j, s'_j = m + j
   for (long j = 0; j < m; j++) {                                                       // Signature.hs:40-45, 54

@@ -11,7 +11,7 @@ for rep in 1 2; do
 for lg in $LGS; do
   run "default" $lg A=1
   run "not fused (round 5 lanes)" $lg SONIC_PROVE_FUSED=0
-  run "six lanes of their own" $lg SONIC_FUSED_LANES=6
+  run "three streams per handle" $lg SONIC_FUSED_LANES=0
   run "stream priorities" $lg SONIC_PROVE_PRIORITIES=1
   run "t group as a chain of its own" $lg SONIC_FUSED_SPLIT_T=1
   if [ $lg -le 15 ]; then

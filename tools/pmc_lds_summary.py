@@ -11,7 +11,7 @@ def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt, seen = collections.Counter(), set()
     for r in csv.DictReader(open(sys.argv[1])):
-        k = r["Kernel_Name"].split("(")[0].replace("sonic::", "")
+        k = r["Kernel_Name"].split("(")[0].replace("sonic::", "").replace("void ", "").split("<")[0]      # (template arguments dropped: k_part_scatter_staged<false> counts as k_part_scatter_staged)
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])

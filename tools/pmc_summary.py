@@ -17,7 +17,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("sonic::", "").replace("void ", "")
+        name = r["Kernel_Name"].split("(")[0].replace("sonic::", "").replace("void ", "").split("<")[0]
         vals[name].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     return {k: sorted(v) for k, v in vals.items()}
 

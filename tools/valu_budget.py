@@ -14,7 +14,7 @@ def main():
     for r in csv.DictReader(open(sys.argv[1])):
         if r["Counter_Name"] != "SQ_INSTS_VALU":
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("sonic::", "").replace("void ", "")
+        name = r["Kernel_Name"].split("(")[0].replace("sonic::", "").replace("void ", "").split("<")[0]
         tot[name] += float(r["Counter_Value"])
         cnt[name] += 1
     for setup in ("k_table_step", "k_srs_points", "k_batch_affine", "k_fb_table", "k_xyzz_to_affine", "k_ntt_twiddles", "k_fr_inv_pow2",
