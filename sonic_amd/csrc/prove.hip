@@ -11,57 +11,22 @@
 // Each reference step is done once: the reference re-evaluates evalY 1 polyR' three times
 // (Protocol.hs:63,79,80), evalY y tXY twice (:72,81) and evalY y_j sXY twice per j
 // (Signature.hs:41,54).
-#include <string.h>
-#include <algorithm>
-#include <chrono>
-#include <functional>
-#include <memory>
-#include <thread>
-#include <numeric>
-#include <string>
-#include <vector>
-#include "internal.hpp"
-#include "poly.hpp"
-#include "fs.hpp"
-#include "share_plan.hpp"
+#include "prover.hpp"
 
 namespace sonic {
 
-enum { FLAG_BAD_ENCODING = 1, FLAG_SRS_INDEX = 2 };
-// phases of a proof = the points at which the reference's prover draws (Protocol.hs:58,66,76,84-85; Signature.hs:48,60): what can be
-// computed once the draws up to there are known
-enum { PH_R = 1,      // R                                   (blinders)
-       PH_T = 2,      // T                                   (+ y)
-       PH_OPEN = 3,   // a, W_a, b, W_b, W_t, s              (+ z)
-       PH_HSCS = 4,   // S_j, s_j, W_j                       (+ y_j, z_j)
-       PH_HSCW = 5,   // C, s'_j, W'_j, Q_j                  (+ u)
-       PH_QV = 6,     // Q_v                                 (+ v)
-       PH_ALL = 0x7e };
-// Buckets per running-sum segment inside prove().  More buckets per segment = fewer small scalar multiplications (less work),
-// fewer = shorter dependent chains.  Batched groups hide their chains under other groups' accumulation, so they take the
-// work-optimal end; the group that finishes last has nothing left to hide under and takes a short chain.  Measured
-// (ms per proof, batched / last): n = 2^18 (2^19 buckets): 16/8 45.9, 32/8 44.3, 64/8 43.2, 64/16 42.6, 64/32 43.7, 128/16 44.6;
-// n = 2^16 (2^16 buckets): 4/4 15.7, 8/4 15.1, 16/4 14.95, 16/8 15.1; n = 2^14: 4/4 7.2, 8/4 6.7, 16/4 6.6.
-// window tables of the per-circuit commitments C_q (sonic_prover_prepare): 29 windows of 9 / 8 bits over 256 shared buckets
-constexpr int CQ_TAB_W = 29, CQ_TAB_C = 9;
-constexpr long CQ_TAB_MAX_Q = 1L << 16;
 static int prove_segment(const MsmPlan& pl, int k, bool last) {
   const bool big = pl.NB >= (1 << 18);
   if (last) return big ? 16 : 4;
   return k > 1 ? (big ? 64 : 16) : (big ? 8 : 4);
 }
 
-struct Scratch {
-  DevBuf D, q, scan, fz_discard;
-  void reserve(long len) { D.ensure(sizeof(Fr) * (len + 1)); q.ensure(sizeof(Fr) * (len + 1)); fz_discard.ensure(sizeof(Fr)); }
-};
-
 // commitPoly (CommitmentScheme.hs:20-33): F = sum_e c_e * A[e + d - max], A = alpha basis.
 // `poly` dense over exponents [lo, lo+len).  Terms whose shifted exponent leaves [-d, d] or hits the
 // e' = 0 hole are legal only if their coefficient is zero (the reference's normalised sparse form
 // would not contain them); otherwise FLAG_SRS_INDEX (`index` panics, CommitmentScheme.hs:70-73).
 // Queues the checks and returns the MSM that is left to run.
-static MsmJob commit_job(hipStream_t st, const sonic_srs* srs, const Fr* poly, long lo, long len, long maxm, MsmSlot* slot, int* d_flags) {
+MsmJob commit_job(hipStream_t st, const sonic_srs* srs, const Fr* poly, long lo, long len, long maxm, MsmSlot* slot, int* d_flags) {
   const long d = srs_d(srs), shift = d - maxm;
   long i0 = -d - shift - lo, i1 = d - shift - lo + 1;     // in-range i: lo + i + shift in [-d, d]
   if (i0 < 0) i0 = 0;
@@ -76,7 +41,7 @@ static MsmJob commit_job(hipStream_t st, const sonic_srs* srs, const Fr* poly, l
 
 // The MSMs that become ready together run as one batched kernel chain when the SRS has window tables (msm.hpp);
 // otherwise one after the other.
-static void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const MsmJob* jobs, int k, bool last = false, bool exposed = true) {
+void run_jobs(hipStream_t st, const sonic_srs* srs, MsmWorkspace& ws, const MsmJob* jobs, int k, bool last, bool exposed) {
   if (k <= 0) return;
   long nmax = 0;
   for (int j = 0; j < k; j++) nmax = std::max(nmax, jobs[j].n);
@@ -118,7 +83,7 @@ static void eval_prefix_enqueue(hipStream_t st, Scratch& sc, const Fr* poly, lon
 // openPoly (CommitmentScheme.hs:36-48).  Requires lo <= 0 <= lo+len-1 (callers extend the range to
 // contain X^0, where `fX - monomial 0 fz` puts -f(z)).  Quotient exponents [lo, lo+len-2], plain basis.
 // Queues evaluation + quotient and returns the MSM that is left to run (its scalars live in `sc` until then).
-static MsmJob open_job(hipStream_t st, const sonic_srs* srs, Scratch& sc, const Fr* poly, long lo, long len,
+MsmJob open_job(hipStream_t st, const sonic_srs* srs, Scratch& sc, const Fr* poly, long lo, long len,
                        const Fr* zpair, Fr* d_fz, MsmSlot* slot, int* d_flags) {
   const long d = srs_d(srs);
   sc.reserve(len);
@@ -138,7 +103,7 @@ static MsmJob open_job(hipStream_t st, const sonic_srs* srs, Scratch& sc, const 
 // openPoly at z = 0 of a polynomial without negative exponents (lo == 0): f(0) = c_0 and (f - c_0)/X is the coefficient
 // array shifted down by one (CommitmentScheme.hs:43-44 with z = 0).  The prefix-sum form above multiplies by z^{-1-j} and
 // cannot express it (0^-1 is not defined; k_fr_with_inverse returns 0 for it).
-static MsmJob open_job_at_zero(hipStream_t st, const sonic_srs* srs, const Fr* poly, long len, Fr* d_fz, MsmSlot* slot, int* d_flags) {
+MsmJob open_job_at_zero(hipStream_t st, const sonic_srs* srs, const Fr* poly, long len, Fr* d_fz, MsmSlot* slot, int* d_flags) {
   const long d = srs_d(srs);
   HIP_OK(hipMemcpyAsync(d_fz, poly, sizeof(Fr), hipMemcpyDeviceToDevice, st));
   const long qn = len - 1;                 // quotient exponents [0, len - 2]
@@ -185,188 +150,11 @@ static void open_jobs_batched(hipStream_t st, const sonic_srs* srs, const Pendin
   }
 }
 
-static bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
+bool bytes_are_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
 }  // namespace sonic
 
-using namespace sonic;
-
-// One MSM "lane": its own stream, bucket workspace and opening scratch.  The MSMs of a proof that depend on the same
-// polynomial form a group (R, W_a, W_b | T, W_t | S_j, W_j, W'_j | C, Q_j.., Q_v) that runs on one lane as ONE batched
-// kernel chain (msm_enqueue_batch); different groups run on different lanes so that one group's sort and reduction
-// phases run under another's accumulation.
-struct Lane {
-  hipStream_t st = nullptr;
-  hipEvent_t done = nullptr;
-  hipEvent_t prep = nullptr;     // fused proofs: the lane's openings (evaluation, quotient) are queued; the proof's ONE chain waits for it
-  MsmWorkspace ws;
-  Scratch sc[MSM_MAX_JOBS];       // one per opening of the group in flight (grown on first use)
-  MsmJob jobs[MSM_MAX_JOBS];
-  int njobs = 0;
-};
-constexpr int N_LANES = 6;
-
-struct sonic_prover {
-  const sonic_srs* srs = nullptr;
-  int device = 0;                            // the SRS's GPU: the handle's streams, buffers and every call on it live there
-  long n = 0, Q = 0;
-  hipStream_t st = nullptr;
-  hipStream_t ts = nullptr;                  // the t(X,y) product (NTT) runs beside the hscProve polynomials
-  bool have_assignment = false;
-  DevBuf wL, wR, wO, cs, aL, aR, aO;        // Montgomery, resident across proofs
-  Lane lanes[N_LANES];
-  // lanes in use: all six by default.  SONIC_FUSED_LANES=k (small-proof handles): k lanes of their own; =0: NO lane of its own
-  // (few_streams) -- three streams per handle: main, transform, chain; the groups' openings ride on the streams that are waiting anyway
-  // (r(X,1)'s on the transform's stream ahead of the product, the s(X,y_j) groups' and s(u,Y)'s on the main stream behind the polynomials,
-  // t(X,y)'s behind the product) through two lanes that only borrow those streams.  Why the knob exists: the runtime multiplexes a process's
-  // streams onto 8 hardware queues, a new stream getting the least-used one, so WHICH of two streamed handles' twenty streams share a queue
-  // is luck -- one handle's openings behind the other handle's accumulation cost 10 % -- and more hardware queues are worse
-  // (GPU_MAX_HW_QUEUES = 12 .. 32: +1 ms on a sequential small proof, profiles/r06_ab_queues.txt).  Measured, 64 proofs at n = 2^16 on one
-  // box, four fresh pairs of handles each (profiles/r06_batch_mode.txt): six lanes 104-107 proofs/s; three streams 99.2-100.5, every time;
-  // one lane + the borrowed streams (four streams) 98-111 depending on the order the handles were made in.  Three streams lose the
-  // side-by-side openings (n = 2^14 streamed 3.8 against 3.45 ms, n = 2^10 1.5 against 1.2), so six lanes stay the default.
-  int n_lanes = N_LANES;
-  bool few_streams = false;
-  Lane main_lane, ts_lane;                   // st = the handle's main / transform stream (not owned)
-  // fused proofs (below): the proof's ONE chain runs on a stream of its own.  (Stream priorities -- the chain lowest, everything that builds
-  // polynomials and openings highest, so that the next streamed proof's preparation would get wave slots beside a running accumulation --
-  // were measured and made things WORSE on this runtime: n = 2^16 streamed 10.6 against 9.75 ms, n = 2^14 4.1 against 3.55,
-  // profiles/r06_ab_small.txt; SONIC_PROVE_PRIORITIES=1 still asks for them.)
-  Lane chain[2];
-  bool small_plan = false;                   // decided when the handle is made: the SRS plans 2^17 buckets or fewer for this n
-  int next_lane = 0;
-  const NttTables* ntt = nullptr;            // the device's shared tables for 2^log2m points (device_ntt_tables)
-  DevBuf S, PAIRS, r1, sy0, su, pw, kpow, fa, fb, slots, frout, flags, tmp;
-  std::vector<DevBuf> syj;
-  // sonic_prover_prepare: Commit(P_q) per constraint row (affine, Montgomery) and per-j scalar buffers
-  // pinned host staging (fixed addresses: the whole enqueue of a proof can be captured once and replayed as a hipGraph)
-  uint8_t* h_tr = nullptr;
-  Fr* h_pairs = nullptr;         // {v, v^-1} of the evaluation points, computed on the host (prove_enqueue)
-  MsmSlot* h_slots = nullptr;
-  uint8_t* h_fr = nullptr;
-  int* h_flags = nullptr;                  // [0] the proof's flags, [1] those of a circuit uploaded inside the proof (pend_circuit)
-  // one-shot calls into a parked shell (sonic_prove): the circuit of THIS call, still in the caller's host buffers.  prove_enqueue
-  // uploads it after it has queued the group of MSMs that needs the assignment only (R, W_a, W_b), so the 2 Q n + Q weights cross
-  // PCIe under those kernels instead of in front of the proof
-  const uint8_t* pend_circuit[4] = {nullptr, nullptr, nullptr, nullptr};
-  // the same for the ASSIGNMENT of this call (round 6: sonic_prove_batch with per-proof assignments, sonic_prove): uploaded at the head of
-  // the proof's own queue instead of by a sonic_prover_set_assignment that waits for the device before the proof may even be queued -- beside
-  // another handle's accumulation that wait was ~1 ms per proof (config5: 99 against 113 proofs/s, profiles/r06_bench.json)
-  const uint8_t* pend_asg[3] = {nullptr, nullptr, nullptr};
-  // runs of equal coefficients in the S_j of a handle that is not prepared (poly.hip, k_run_tiles): per j the masked copy of s(X, y_j),
-  // the tile records and the (scalar, running-sum point) slots of the small MSM that stands for the runs; its sum lands in slot
-  // (7 + 4Q) + j, where a prepared handle keeps sum_q y_j^{n+q} C_q, and the host adds it the same way
-  // The small MSM runs on the handle's MAIN stream, which has built all polynomials by then and only waits for the lanes: behind the
-  // batch of the lane that reads the masked copy its ~13 short launches and the chained sums of its per-window buckets added 0.6-1.3 ms
-  // to a proof's latency; a stream of its own (two more streams per handle than the 8 hardware queues the runtime is given) cost
-  // 1-5 ms per streamed proof.
-  struct RunBufs {
-    DevBuf masked, val, uniform, scal, pts;
-    hipEvent_t masked_ev = nullptr;
-  };
-  MsmWorkspace runs_ws;
-  std::vector<RunBufs> runs;
-  bool runs_on = false;
-  // does this circuit HAVE runs?  Sampled on the host from the weights as they are handed over (circuit_runs_hint): a circuit without
-  // repeated rows would pay the masked copy, the tile scan and a small MSM per S_j and get nothing back (measured with
-  // uniformly random weights at n = 2^18: profiles/r06_runs_dense_ab.txt).  A hint only: the path is exact for any input.
-  bool circuit_has_runs = true;
-  // C = commitPoly(s(u, Y)) through the SRS's symmetric sums (srs.hip, srs_build_sym): s(u, Y) has the same coefficient at Y^i and Y^-i
-  // (i <= n), so n terms over A[i] + A[-i] and a Q-term MSM for Y^{n+1} .. Y^{n+Q} stand for its 2n + Q + 1 terms; the Q-term sum lands
-  // in slot 7 + 5Q and the host adds it
-  bool sym_on = false;
-  // Small proofs (round 6): ALL the MSMs of a proof as ONE batched kernel chain.  With 2^16 shared buckets and fewer (c <= 18: d < 2^20,
-  // n <= 2^16) a group of two or three MSMs is 2048-3072 one-thread-per-bucket waves -- one round of the chip's 2048 wave slots, half
-  // empty on its second -- and a proof is five such chains whose sorts, heavy-bucket launches and reductions (each ~15 launches of
-  // 5-20 us, plus ~1.4 ms of latency-bound running sums) queue behind each other's accumulation for wave slots: n = 2^14 measured 5.5 ms
-  // per proof for 1.8 ms of additions at the full-chip rate, n = 2^16 11.1 ms for 7.2 (profiles/r06_small_proofs.txt).  Fused, the lanes
-  // only prepare the openings (evaluation, prefix sums, quotient: they still run side by side); their jobs are collected here and run as
-  // one chain of up to MSM_MAX_JOBS jobs on the t lane: one sort, ONE accumulation launch that keeps every wave slot filled until its
-  // tail, one butterfly over all bucket sets.  Larger plans (2^19 buckets per set) fill the chip per group and keep the lanes
-  // (packing their groups was measured slower in round 3).  SONIC_PROVE_FUSED=0 / 1: never / whenever the plan batches.
-  bool fused = false;
-  std::vector<MsmJob> fused_jobs;
-  std::vector<std::unique_ptr<Scratch>> fused_sc;      // one per opening of the proof: a quotient lives until the chain has read it
-  size_t fused_sc_next = 0;
-  Scratch& fused_scratch() {
-    if (fused_sc_next == fused_sc.size()) fused_sc.emplace_back(new Scratch());
-    return *fused_sc[fused_sc_next++];
-  }
-  // SONIC_PROVE_GRAPH=1 (read when the handle is made): capture the enqueue of the second proof and replay it.  Off by default:
-  // on ROCm 7.2 the replay of this ~220-node, 7-stream graph is slower than the direct launches (n = 2^10: 9.0 vs 4.9 ms per proof,
-  // n = 2^14: 9.6 vs 6.5 ms).
-  bool use_graph = false;
-  hipGraphExec_t graph = nullptr;
-  bool graph_tried = false;
-  long proofs_done = 0;
-  bool in_flight = false;                    // between sonic_prover_submit and sonic_prover_collect
-  // Which steps of the proof an enqueue runs (bit = phase; PH_ALL normally).  The Fiat-Shamir mode (sonic_prover_prove_fs) proves in
-  // six passes, each running exactly the MSMs whose challenges have become known: results of earlier passes stay in `slots` / `frout`.
-  uint32_t phases = 0x7e;
-  DevBuf frstd;                              // frout in standard form (frout itself stays Montgomery across passes)
-  std::chrono::steady_clock::time_point t_begin, t_enq;
-  bool prepared = false;
-  DevBuf cq;
-  // window tables of the C_q (CQ_TAB_W x Q points, table w = 2^shift(w) C_q): their Q-term MSM then shares one bucket set and
-  // leaves ONE window sum like every other MSM of a proof, instead of 64 that the host folds with 255 doublings (126 us each)
-  DevBuf cq_tab;
-  std::vector<DevBuf> diag, yq;
-  hipEvent_t ev_r1 = nullptr, ev_sy0 = nullptr, ev_t = nullptr, ev_su = nullptr;
-  std::vector<hipEvent_t> ev_syj;
-  int log2m = 0;
-  std::mutex mu;
-  // ONE proof over several GPUs (sonic_prover_set_share, share_plan.hpp): this handle runs rank share_rank's pieces of the proof's
-  // MSMs and reports un-normalised partial sums (sonic_prover_collect_share); share_world <= 1: the whole proof
-  int share_rank = 0, share_world = 0;
-  SharePlan share;
-  bool share_planned_prepared = false, share_planned = false;
-  int32_t share_plan_tag = 0;                // hash of the plan's inputs (share header: ranks must have planned alike)
-  std::vector<uint8_t> slot_ran;             // per slot (7 + 5Q): the last enqueue queued an MSM for it
-  std::vector<uint8_t> fr_valid;             // per evaluation (3 + 2Q): the last enqueue computed it
-  uint8_t witness_digest[32] = {0};          // SHA-256 of the assignment (Fiat-Shamir blinders, fs.hpp), made on first use
-  bool have_witness_digest = false;
-  // Lane N_LANES-1 carries the t(X,y) group (the largest, ready last); the other groups alternate over the rest, which
-  // balances the point additions per lane (Q = 2: 55M / 51M / 48M) while one lane's sort and reduction phases run under
-  // another lane's accumulation.  Streams beyond the 4 hardware queues would serialise behind each other.
-  Lane& lane_at(int i) { return few_streams ? ((i & 1) ? ts_lane : main_lane) : lanes[i % n_lanes]; }      // (prepare, hscProve: any lane)
-  Lane& pick(hipEvent_t ready) {
-    if (few_streams) return main_lane;
-    Lane& l = lanes[next_lane];
-    next_lane = (next_lane + 1) % (n_lanes > 1 ? n_lanes - 1 : 1);
-    (void)hipStreamWaitEvent(l.st, ready, 0);
-    return l;
-  }
-  Lane& t_lane(hipEvent_t ready) {
-    // (few_streams: the transform's own stream, which has waited for `ready` when it took the polynomials in -- a second wait for the same
-    // event, or one for an event of the stream itself, becomes a duplicate edge when the enqueue is captured as a hipGraph, and the
-    // runtime's capture code crashed on it)
-    if (few_streams) return ts_lane;
-    Lane& l = lanes[n_lanes - 1];
-    (void)hipStreamWaitEvent(l.st, ready, 0);
-    return l;
-  }
-  ~sonic_prover() {
-    for (auto& l : lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); if (l.prep) (void)hipEventDestroy(l.prep); }
-    for (auto& l : chain) { if (l.st) (void)hipStreamDestroy(l.st); if (l.done) (void)hipEventDestroy(l.done); if (l.prep) (void)hipEventDestroy(l.prep); }
-    for (Lane* l : {&main_lane, &ts_lane}) { if (l->done) (void)hipEventDestroy(l->done); if (l->prep) (void)hipEventDestroy(l->prep); }
-    for (auto& r : runs) if (r.masked_ev) (void)hipEventDestroy(r.masked_ev);
-    for (hipEvent_t e : {ev_r1, ev_sy0, ev_t, ev_su}) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ev_syj) if (e) (void)hipEventDestroy(e);
-    if (st) (void)hipStreamDestroy(st);
-    if (ts) (void)hipStreamDestroy(ts);
-    if (graph) (void)hipGraphExecDestroy(graph);
-    for (void* h : {(void*)h_tr, (void*)h_pairs, (void*)h_slots, (void*)h_fr, (void*)h_flags}) if (h) (void)hipHostFree(h);
-  }
-};
-
-#define API_BEGIN_ON(dev) try { ::sonic::DeviceScope _scope(dev);
-#define API_BEGIN API_BEGIN_ON(-1)
-#define API_END                                                        \
-  } catch (const HipFail& f) { return f.code; }                        \
-  catch (const std::exception& e) { set_error("%s", e.what()); return SONIC_ERR_HIP; } \
-  return SONIC_OK;
-
-static int upload_fr_mont(hipStream_t st, DevBuf& dst, const uint8_t* src, long count, int* d_flags) {
+int upload_fr_mont(hipStream_t st, DevBuf& dst, const uint8_t* src, long count, int* d_flags) {
   dst.ensure(sizeof(Fr) * (count > 0 ? count : 1));
   if (count > 0) {
     HIP_OK(hipMemcpyAsync(dst.p, src, 32 * count, hipMemcpyHostToDevice, st));
@@ -375,14 +163,14 @@ static int upload_fr_mont(hipStream_t st, DevBuf& dst, const uint8_t* src, long 
   return 0;
 }
 
-static int read_flags(hipStream_t st, DevBuf& flags) {
+int read_flags(hipStream_t st, DevBuf& flags) {
   int h = 0;
   HIP_OK(hipMemcpyAsync(&h, flags.p, 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   return h;
 }
 
-static int flags_to_status(int f, const char* who) {
+int flags_to_status(int f, const char* who) {
   if (f & FLAG_BAD_ENCODING) { set_error("%s: non-canonical field element in input", who); return SONIC_ERR_BAD_ENCODING; }
   if (f & FLAG_SRS_INDEX) { set_error("%s: a non-zero coefficient needs an SRS element outside [-d, d] or the omitted g^alpha (index -1)", who); return SONIC_ERR_SRS_INDEX; }
   return SONIC_OK;
@@ -393,7 +181,7 @@ static int flags_to_status(int f, const char* who) {
 // 32 tiles of RUN_TILE consecutive gate indices, spread over [0, n): a tile counts when every row of wL AND of wR repeats one value across
 // it -- then s(X, y) has a run of equal coefficients there (u_i = sum_q wL[q][i] y^{n+q}, Constraints.hs:39-49) -- and the circuit "has
 // runs" when at least a quarter of the sampled tiles do.  ~0.5 MB read at Q = 2, microseconds.
-static bool circuit_runs_hint(const uint8_t* wL, const uint8_t* wR, long n, long Q) {
+bool circuit_runs_hint(const uint8_t* wL, const uint8_t* wR, long n, long Q) {
   const long ntiles = n / RUN_TILE;
   if (ntiles < 1) return false;
   const long samples = ntiles < 32 ? ntiles : 32;
@@ -1194,7 +982,7 @@ int sonic_prover_prove(sonic_prover_t* p, const uint8_t* transcript, uint8_t* ou
 }
 
 // prove with the assignment of THIS call still in the caller's host buffers (uploaded inside the proof's queue: pend_asg)
-static int prove_with_assignment(sonic_prover_t* p, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript, uint8_t* out_proof) {
+int prove_with_assignment(sonic_prover_t* p, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript, uint8_t* out_proof) {
   std::lock_guard<std::mutex> g(p->mu);
   if (p->in_flight) { set_error("prove: a submitted proof has not been collected yet"); return SONIC_ERR_INVALID_ARG; }
   int rc = whole_proof_only(p, "prove");
@@ -1549,521 +1337,6 @@ int sonic_prover_hsc_prove(sonic_prover_t* p, int64_t m, const uint8_t* yzs, con
   for (long j = 0; j < m; j++) { putG(3 * j); putF(&hfr[32 * j]); putG(3 * j + 1); }                 // hscS
   for (long j = 0; j < m; j++) { putF(&hfr[32 * (m + j)]); putG(3 * j + 2); putG(3 * m + j); }       // hscW
   putG(4 * m); putG(4 * m + 1); putF(u); putF(v);                                                   // Qv, C, u, v
-  API_END
-}
-
-// hscProve :: SRS -> BiVLaurent Fr -> [(Fr, Fr)] -> m HscProof (Signature.hs:32-72) for ANY sparse bivariate Laurent polynomial
-// s(X,Y) = sum_i c_i X^{ex_i} Y^{ey_i} (the reference's own signature; sonic_prover_hsc_prove above is the same sub-protocol for the
-// s(X,Y) of a circuit handle).  evalY y_j / evalX u (Utils.hs:17-21) scale every term by a power of the evaluation point and sum
-// the terms that share the remaining exponent; the commitments and openings are the usual MSM groups.
-struct BivTerms {
-  long nt = 0, lo = 0, len = 0;       // dense range of the variable that is kept
-  DevBuf keep, other, coeff;          // per term, sorted by the kept exponent: kept exponent, substituted exponent, coefficient (Montgomery)
-};
-static int biv_upload(hipStream_t st, int64_t nt, const int64_t* keep, const int64_t* other, const uint8_t* coeffs, BivTerms& out, int* d_flags) {
-  out.nt = nt;
-  long lo = 0, hi = 0;                // the range always holds exponent 0 (openPoly puts -f(z) there, CommitmentScheme.hs:43)
-  for (int64_t i = 0; i < nt; i++) { lo = std::min<long>(lo, keep[i]); hi = std::max<long>(hi, keep[i]); }
-  out.lo = lo; out.len = hi - lo + 1;
-  std::vector<int64_t> order(nt), k(nt), o(nt);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return keep[a] < keep[b]; });
-  std::vector<uint8_t> c(32 * (size_t)(nt ? nt : 1));
-  for (int64_t i = 0; i < nt; i++) { k[i] = keep[order[i]]; o[i] = other[order[i]]; memcpy(&c[32 * (size_t)i], coeffs + 32 * order[i], 32); }
-  out.keep.alloc(8 * (size_t)(nt ? nt : 1)); out.other.alloc(8 * (size_t)(nt ? nt : 1)); out.coeff.alloc(32 * (size_t)(nt ? nt : 1));
-  if (nt) {
-    HIP_OK(hipMemcpyAsync(out.keep.p, k.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(out.other.p, o.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(out.coeff.p, c.data(), 32 * (size_t)nt, hipMemcpyHostToDevice, st));
-    fr_to_mont_enqueue(st, out.coeff.as<Fr>(), nt, d_flags);
-  }
-  HIP_OK(hipStreamSynchronize(st));   // host staging goes out of scope
-  return SONIC_OK;
-}
-// dense[e - lo] = sum over the terms with kept exponent e of c * b^{other exponent}
-static void biv_eval_enqueue(hipStream_t st, const BivTerms& t, const Fr* pair, DevBuf& scaled, Fr* dense) {
-  HIP_OK(hipMemsetAsync(dense, 0, sizeof(Fr) * t.len, st));
-  scaled.ensure(sizeof(Fr) * (size_t)(t.nt ? t.nt : 1));
-  scale_terms_enqueue(st, t.other.as<int64_t>(), t.coeff.as<Fr>(), t.nt, pair, scaled.as<Fr>());
-  sparse_to_dense_enqueue(st, t.keep.as<int64_t>(), scaled.as<Fr>(), t.nt, t.lo, dense);
-}
-
-int sonic_hsc_prove_poly(const sonic_srs_t* srs, int64_t n_terms, const int64_t* x_exps, const int64_t* y_exps, const uint8_t* coeffs,
-                         int64_t m, const uint8_t* yzs, const uint8_t u[32], const uint8_t v[32], uint8_t* out) {
-  API_BEGIN_ON(srs_device(srs))
-  if (!srs || n_terms < 0 || (n_terms > 0 && (!x_exps || !y_exps || !coeffs)) || m < 0 || (m > 0 && !yzs) || !u || !v || !out) return SONIC_ERR_INVALID_ARG;
-  CallLease lease;
-  hipStream_t st = lease.st();
-  const long d = srs_d(srs);
-  bool neg_x = false, neg_y = false;
-  for (int64_t i = 0; i < n_terms; i++) {
-    neg_x = neg_x || x_exps[i] < 0; neg_y = neg_y || y_exps[i] < 0;
-    if (x_exps[i] < -8 * (d + 8) || x_exps[i] > 8 * (d + 8) || y_exps[i] < -8 * (d + 8) || y_exps[i] > 8 * (d + 8)) {
-      set_error("hscProve: exponent (%ld, %ld) is far outside the SRS", (long)x_exps[i], (long)y_exps[i]); return SONIC_ERR_SRS_INDEX; }
-  }
-  // `pow x e` with negative e (Utils.hs:18,21): substituting 0 divides by zero; so does opening at 0 a polynomial with negative exponents
-  for (int64_t j = 0; j < m; j++) {
-    if (bytes_are_zero(yzs + 64 * j, 32) && neg_y) { set_error("hscProve: y_%ld = 0 and s(X,Y) has negative powers of Y", (long)j); return SONIC_ERR_INEXACT_DIVISION; }
-    if (bytes_are_zero(yzs + 64 * j + 32, 32) && neg_x) { set_error("hscProve: z_%ld = 0 and s(X,Y) has negative powers of X", (long)j); return SONIC_ERR_INEXACT_DIVISION; }
-  }
-  if ((bytes_are_zero(u, 32) && neg_x) || (bytes_are_zero(v, 32) && neg_y)) { set_error("hscProve: u or v is zero and s(X,Y) has negative powers"); return SONIC_ERR_INEXACT_DIVISION; }
-  const long NS = 2 * m + 2, K = 4 * m + 2;
-  DevBuf S(sizeof(Fr) * NS), PR(sizeof(Fr) * 2 * NS), slots(sizeof(MsmSlot) * K), frout(sizeof(Fr) * (2 * m + 1)), flags(4), scaled;
-  int* fl = flags.as<int>();
-  HIP_OK(hipMemsetAsync(fl, 0, 4, st));
-  HIP_OK(hipMemsetAsync(frout.p, 0, sizeof(Fr) * (2 * m + 1), st));
-  BivTerms byx, byy;
-  biv_upload(st, n_terms, x_exps, y_exps, coeffs, byx, fl);      // keeps X: s(X, y_j)
-  biv_upload(st, n_terms, y_exps, x_exps, coeffs, byy, fl);      // keeps Y: s(u, Y)
-  {
-    std::vector<uint8_t> h(32 * (size_t)NS);
-    for (long j = 0; j < m; j++) { memcpy(&h[32 * j], yzs + 64 * j, 32); memcpy(&h[32 * (m + j)], yzs + 64 * j + 32, 32); }
-    memcpy(&h[32 * (2 * m)], u, 32); memcpy(&h[32 * (2 * m + 1)], v, 32);
-    HIP_OK(hipMemcpyAsync(S.p, h.data(), h.size(), hipMemcpyHostToDevice, st));
-    HIP_OK(hipStreamSynchronize(st));
-  }
-  fr_to_mont_enqueue(st, S.as<Fr>(), NS, fl);
-  fr_with_inverse_enqueue(st, S.as<Fr>(), (int)NS, PR.as<Fr>());
-  const Fr* P0 = PR.as<Fr>();
-  auto pY = [&](long j) { return P0 + 2 * j; };
-  auto pZ = [&](long j) { return P0 + 2 * (m + j); };
-  const Fr *pU = P0 + 2 * (2 * m), *pV = P0 + 2 * (2 * m + 1);
-  auto is_zero_pt = [&](const uint8_t* b) { return bytes_are_zero(b, 32); };
-  MsmSlot* sl = slots.as<MsmSlot>();
-  Fr* fo = frout.as<Fr>();
-  DevBuf sy(sizeof(Fr) * byx.len), su(sizeof(Fr) * byy.len);
-  Scratch sc[MSM_MAX_JOBS];
-  MsmWorkspace& ws = lease.ws();
-  // an opening at 0 is only defined without negative exponents (checked above), where it is a shift (open_job_at_zero)
-  auto open_any = [&](Scratch& s_, const Fr* poly, long lo, long len, const Fr* zp, bool zero, Fr* fz, MsmSlot* slot) {
-    return zero ? open_job_at_zero(st, srs, poly, len, fz ? fz : s_.fz_discard.as<Fr>(), slot, fl)
-                : open_job(st, srs, s_, poly, lo, len, zp, fz, slot, fl);
-  };
-  for (auto& s_ : sc) s_.fz_discard.ensure(sizeof(Fr));
-  // slots: S_j = 3j, W_j = 3j + 1, W'_j = 3j + 2;  Q_j = 3m + j;  Q_v = 4m;  C = 4m + 1.   frout: s_j = j, s'_j = m + j
-  for (long j = 0; j < m; j++) {                                                       // Signature.hs:40-45, 54
-    biv_eval_enqueue(st, byx, pY(j), scaled, sy.as<Fr>());                             // evalY y_j sXY
-    MsmJob jobs[3];
-    jobs[0] = commit_job(st, srs, sy.as<Fr>(), byx.lo, byx.len, d, &sl[3 * j], fl);
-    jobs[1] = open_any(sc[1], sy.as<Fr>(), byx.lo, byx.len, pZ(j), is_zero_pt(yzs + 64 * j + 32), &fo[j], &sl[3 * j + 1]);
-    jobs[2] = open_any(sc[2], sy.as<Fr>(), byx.lo, byx.len, pU, is_zero_pt(u), nullptr, &sl[3 * j + 2]);
-    run_jobs(st, srs, ws, jobs, 3);
-  }
-  biv_eval_enqueue(st, byy, pU, scaled, su.as<Fr>());                                  // evalX u sXY          :51
-  {
-    MsmJob jobs[MSM_MAX_JOBS];
-    int k = 0;
-    auto flush = [&] { run_jobs(st, srs, ws, jobs, k); k = 0; };
-    jobs[k++] = commit_job(st, srs, su.as<Fr>(), byy.lo, byy.len, d, &sl[4 * m + 1], fl);                              // C    :52
-    for (long j = 0; j < m; j++) {                                                                                     // Q_j  :55
-      if (k == MSM_MAX_JOBS) flush();
-      jobs[k] = open_any(sc[k], su.as<Fr>(), byy.lo, byy.len, pY(j), is_zero_pt(yzs + 64 * j), &fo[m + j], &sl[3 * m + j]);
-      k++;
-    }
-    if (k == MSM_MAX_JOBS) flush();
-    jobs[k] = open_any(sc[k], su.as<Fr>(), byy.lo, byy.len, pV, is_zero_pt(v), &fo[2 * m], &sl[4 * m]);                // Q_v  :63
-    k++;
-    flush();
-  }
-  fr_from_mont_enqueue(st, fo, 2 * m + 1);
-  std::vector<MsmSlot> hs((size_t)K);
-  std::vector<uint8_t> hfr(32 * (size_t)(2 * m + 1));
-  HIP_OK(hipMemcpyAsync(hs.data(), sl, sizeof(MsmSlot) * K, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(hfr.data(), fo, hfr.size(), hipMemcpyDeviceToHost, st));
-  int hflags = read_flags(st, flags);
-  if (hflags) return flags_to_status(hflags, "hscProve");
-  std::vector<uint8_t> pts(96 * (size_t)K);
-  {
-    std::vector<G1XYZZ> sums((size_t)K);
-    for (long i = 0; i < K; i++) sums[i] = msm_finish_host(hs[i]);
-    g1_canonical_bytes_host_batch(sums.data(), (int)K, pts.data());
-  }
-  uint8_t* o = out;
-  auto putG = [&](long i) { memcpy(o, &pts[96 * (size_t)i], 96); o += 96; };
-  auto putF = [&](const uint8_t* b) { memcpy(o, b, 32); o += 32; };
-  for (long j = 0; j < m; j++) { putG(3 * j); putF(&hfr[32 * j]); putG(3 * j + 1); }                 // hscS
-  for (long j = 0; j < m; j++) { putF(&hfr[32 * (m + j)]); putG(3 * j + 2); putG(3 * m + j); }       // hscW
-  putG(4 * m); putG(4 * m + 1); putF(u); putF(v);                                                   // Qv, C, u, v
-  API_END
-}
-
-// prove :: SRS -> Assignment Fr -> ArithCircuit Fr -> m (Proof, RndOracle) with the reference's own shape: everything handed over per
-// call (Protocol.hs:47-52).  A handle costs streams, events, ~20 workspace allocations that grow on the first proof and the twiddle
-// tables -- tens of milliseconds against a 32-ms proof -- so the device parks the shell of a finished one-shot call and the next call
-// with the same SRS handle and (n, Q) only uploads its circuit and assignment into it (round 5; bench.py `one_shot`).  Several host
-// threads inside sonic_prove on one GPU each take a parked shell or make one; at most ONE_SHOT_SHELLS stay parked per device.
-}  // extern "C"
-namespace {
-constexpr size_t ONE_SHOT_SHELLS = 4;
-}
-namespace sonic {
-void drop_one_shot_of(const sonic_srs* s) {
-  DeviceCtx& c = current_ctx();
-  std::vector<OneShotShell*> gone;
-  {
-    std::lock_guard<std::mutex> g(c.one_shot_mu);
-    for (size_t i = 0; i < c.one_shot.size();) {
-      OneShotShell* sh = static_cast<OneShotShell*>(c.one_shot[i]);
-      if (sh->srs == s) { gone.push_back(sh); c.one_shot.erase(c.one_shot.begin() + (long)i); } else i++;
-    }
-  }
-  for (OneShotShell* sh : gone) { delete sh->p; delete sh; }
-}
-}
-extern "C" {
-// frees the parked one-shot shells of every device this process has used (or of one device: device >= 0).  A parked shell holds all the
-// workspaces of a proof of its shape -- several GB at n = 2^20 -- until another shape evicts it or its SRS is freed; a host that has
-// finished a burst of sonic_prove / sonic_prove_many calls gives the memory back with this.  Returns the number of shells freed.
-int sonic_one_shot_trim(int device) {
-  int freed = 0;
-  try {
-    int ndev = 0;
-    if (sonic_device_count(&ndev) != SONIC_OK) return 0;
-    for (int d = 0; d < ndev; d++) {
-      if (device >= 0 && d != device) continue;
-      DeviceScope scope(d);
-      DeviceCtx& c = scope.ctx();
-      std::vector<void*> gone;
-      { std::lock_guard<std::mutex> g(c.one_shot_mu); gone.swap(c.one_shot); }
-      for (void* v : gone) { OneShotShell* sh = static_cast<OneShotShell*>(v); delete sh->p; delete sh; freed++; }
-    }
-  } catch (const HipFail&) {}
-  return freed;
-}
-
-int sonic_prove(const sonic_srs_t* srs, int64_t n, int64_t Q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
-                const uint8_t* cs, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* transcript,
-                uint8_t* out_proof) {
-  API_BEGIN_ON(srs_device(srs))
-  if (!srs || n < 1 || Q < 1 || !wL || !wR || !wO || !cs || !aL || !aR || !aO || !transcript || !out_proof) { set_error("sonic_prove: bad argument (need n >= 1, Q >= 1)"); return SONIC_ERR_INVALID_ARG; }
-  DeviceCtx& ctx = current_ctx();
-  OneShotShell* sh = nullptr;
-  {
-    std::lock_guard<std::mutex> g(ctx.one_shot_mu);
-    for (size_t i = ctx.one_shot.size(); i-- > 0;) {                 // newest first
-      OneShotShell* c = static_cast<OneShotShell*>(ctx.one_shot[i]);
-      if (c->srs == srs && c->p->n == n && c->p->Q == Q) { sh = c; ctx.one_shot.erase(ctx.one_shot.begin() + (long)i); break; }
-    }
-  }
-  int rc = SONIC_OK;
-  if (sh) {   // uploaded inside the proof
-    sh->p->pend_circuit[1] = wR; sh->p->pend_circuit[2] = wO; sh->p->pend_circuit[3] = cs; sh->p->pend_circuit[0] = wL;
-    sh->p->circuit_has_runs = circuit_runs_hint(wL, wR, n, Q);
-  }
-  else {
-    sonic_prover_t* p = nullptr;
-    rc = sonic_prover_new(srs, n, Q, wL, wR, wO, cs, &p);
-    if (rc) return rc;
-    sh = new OneShotShell{srs, p};
-  }
-  if (!rc) rc = prove_with_assignment(sh->p, aL, aR, aO, transcript, out_proof);
-  sh->p->pend_circuit[0] = nullptr;           // (a call that failed before its upload: the caller's buffers end with the call)
-  // park the shell (also after a failed call: the next one loads its own circuit and assignment); the oldest parked shell makes room
-  OneShotShell* evict = nullptr;
-  {
-    std::lock_guard<std::mutex> g(ctx.one_shot_mu);
-    if (ctx.one_shot.size() >= ONE_SHOT_SHELLS) { evict = static_cast<OneShotShell*>(ctx.one_shot.front()); ctx.one_shot.erase(ctx.one_shot.begin()); }
-    ctx.one_shot.push_back(sh);
-  }
-  if (evict) { delete evict->p; delete evict; }
-  return rc;
-  API_END
-}
-
-// mapM (\(assignment, circuit) -> prove srs assignment circuit) over K INDEPENDENT statements of one shape (n, Q), spread over the SRS
-// replicas -- one per GPU -- with two host threads per replica (statement i on thread i mod 2 n_srs; two one-shot calls in flight per
-// GPU stream it: one call's upload and host tail under the other's kernels).  BASELINE's "batch of 64 independent proofs streamed over 8
-// GPUs" with every proof its own circuit and witness; no collective.  Returns the first non-zero status in list order; all are attempted.
-int sonic_prove_many(const sonic_srs_t* const* srs, int n_srs, int64_t n, int64_t Q, const sonic_statement_t* statements, int64_t K,
-                     uint8_t* out_proofs, int* out_status) {
-  if (!srs || n_srs < 1 || n_srs > 512 || n < 1 || Q < 1 || K < 0 || (K > 0 && (!statements || !out_proofs))) return SONIC_ERR_INVALID_ARG;
-  for (int i = 0; i < n_srs; i++) if (!srs[i]) return SONIC_ERR_INVALID_ARG;
-  const size_t psz = sonic_proof_size(Q);
-  const int T = 2 * n_srs;
-  std::vector<int> status((size_t)K, SONIC_OK);
-  std::vector<std::string> errs((size_t)T);
-  auto body = [&](int t) {
-    const sonic_srs_t* s = srs[t % n_srs];
-    for (int64_t i = t; i < K; i += T) {
-      int rc = SONIC_ERR_HIP;
-      try {
-        const sonic_statement_t& st = statements[i];
-        rc = sonic_prove(s, n, Q, st.wL, st.wR, st.wO, st.cs, st.aL, st.aR, st.aO, st.transcript, out_proofs + psz * (size_t)i);
-        if (rc && errs[(size_t)t].empty()) { char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)t] = b; }
-      } catch (...) { rc = SONIC_ERR_HIP; }                            // (nothing may leave a thread's body: std::terminate)
-      status[(size_t)i] = rc;
-    }
-  };
-  {
-    ThreadGroup th;
-    for (int t = 1; t < T && t < K; t++) th.emplace_back(body, t);
-    body(0);
-    for (auto& x : th) x.join();
-  }
-  if (out_status) for (int64_t i = 0; i < K; i++) out_status[i] = status[(size_t)i];
-  for (int64_t i = 0; i < K; i++)
-    if (status[(size_t)i]) {
-      const int t = (int)(i % T);
-      set_error("sonic_prove_many, statement %ld (device %d): %s", (long)i, srs_device(srs[t % n_srs]), errs[(size_t)t].c_str());
-      return status[(size_t)i];
-    }
-  return SONIC_OK;
-}
-
-// ---- N GPUs from ONE host process: one proof shared by several handles, a batch of proofs over several handles ------------------
-// (include/sonic_hip.h).  One host thread per handle; a handle carries its device, so the threads need no set-up of their own.
-int sonic_prover_device(const sonic_prover_t* p) { return p ? p->device : -1; }
-
-int sonic_prove_shared(sonic_prover_t* const* provers, int world, const uint8_t* transcript, uint8_t* out_proof) {
-  if (!provers || world < 1 || world > 1024 || !transcript || !out_proof) return SONIC_ERR_INVALID_ARG;
-  for (int r = 0; r < world; r++) {
-    if (!provers[r]) return SONIC_ERR_INVALID_ARG;
-    if (provers[r]->n != provers[0]->n || provers[r]->Q != provers[0]->Q) { set_error("sonic_prove_shared: handle %d proves another circuit shape (n, Q) than handle 0", r); return SONIC_ERR_INVALID_ARG; }
-    for (int q = 0; q < r; q++) if (provers[q] == provers[r]) { set_error("sonic_prove_shared: handle %d appears twice (one handle runs one share at a time)", r); return SONIC_ERR_INVALID_ARG; }
-  }
-  if (world == 1) {
-    // one handle: the whole proof (a handle left in share mode by an earlier call goes back first)
-    if (provers[0]->share_world > 1) { int rc = sonic_prover_set_share(provers[0], 0, 1); if (rc) return rc; }
-    return sonic_prover_prove(provers[0], transcript, out_proof);
-  }
-  const long Q = provers[0]->Q;
-  const size_t ssz = sonic_proof_share_size(Q);
-  std::vector<uint8_t> shares(ssz * (size_t)world);
-  std::vector<int> rcs((size_t)world, SONIC_OK);
-  std::vector<std::string> errs((size_t)world);
-  auto body = [&](int r) {
-    sonic_prover_t* p = provers[r];
-    int rc = SONIC_OK;
-    try {
-      bool placed;
-      { std::lock_guard<std::mutex> g(p->mu); placed = p->share_world == world && p->share_rank == r; }
-      if (!placed) rc = sonic_prover_set_share(p, r, world);          // (clears the slots of pieces the handle no longer runs; once per change)
-      if (!rc) rc = sonic_prover_prove_share(p, transcript, &shares[ssz * (size_t)r]);
-      if (rc) { char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)r] = b; }
-    } catch (...) { rc = SONIC_ERR_HIP; }                            // (nothing may leave a thread's body: std::terminate)
-    rcs[(size_t)r] = rc;
-  };
-  {
-    ThreadGroup th;
-    for (int r = 1; r < world; r++) th.emplace_back(body, r);
-    body(0);                                                       // the calling thread is rank 0's
-    for (auto& t : th) t.join();
-  }
-  for (int r = 0; r < world; r++)
-    if (rcs[(size_t)r]) { set_error("sonic_prove_shared, rank %d (device %d): %s", r, provers[r]->device, errs[(size_t)r].c_str()); return rcs[(size_t)r]; }
-  return sonic_proof_from_shares(Q, world, shares.data(), transcript, out_proof);
-}
-
-int sonic_prove_batch(sonic_prover_t* const* provers, int n_provers, int64_t K, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO,
-                      const uint8_t* transcripts, uint8_t* out_proofs, int* out_status) {
-  if (!provers || n_provers < 1 || n_provers > 1024 || K < 0 || (K > 0 && (!transcripts || !out_proofs))) return SONIC_ERR_INVALID_ARG;
-  const bool per_proof = aL || aR || aO;
-  if (per_proof && !(aL && aR && aO)) { set_error("sonic_prove_batch: aL, aR, aO must be given together (or all NULL: the handles' resident assignments)"); return SONIC_ERR_INVALID_ARG; }
-  for (int i = 0; i < n_provers; i++) {
-    if (!provers[i]) return SONIC_ERR_INVALID_ARG;
-    if (provers[i]->n != provers[0]->n || provers[i]->Q != provers[0]->Q) { set_error("sonic_prove_batch: handle %d proves another circuit shape (n, Q) than handle 0", i); return SONIC_ERR_INVALID_ARG; }
-    if (provers[i]->share_world > 1) { set_error("sonic_prove_batch: handle %d runs one rank's share of a proof (sonic_prover_set_share)", i); return SONIC_ERR_INVALID_ARG; }
-    for (int q = 0; q < i; q++) if (provers[q] == provers[i]) { set_error("sonic_prove_batch: handle %d appears twice", i); return SONIC_ERR_INVALID_ARG; }
-  }
-  const long n = provers[0]->n, Q = provers[0]->Q;
-  const size_t psz = sonic_proof_size(Q), tsz = 32 * (size_t)(8 + 2 * Q), asz = 32 * (size_t)n;
-  std::vector<int> status((size_t)K, SONIC_OK);
-  std::vector<std::string> errs((size_t)n_provers);
-  std::vector<int64_t> first_bad((size_t)n_provers, -1);
-  auto body = [&](int h) {
-    for (int64_t i = h; i < K; i += n_provers) {
-      int rc = SONIC_OK;
-      try {
-        if (per_proof) rc = prove_with_assignment(provers[h], aL + asz * (size_t)i, aR + asz * (size_t)i, aO + asz * (size_t)i, transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
-        else rc = sonic_prover_prove(provers[h], transcripts + tsz * (size_t)i, out_proofs + psz * (size_t)i);
-        if (rc && first_bad[(size_t)h] < 0) { first_bad[(size_t)h] = i; char b[512]; sonic_last_error(b, sizeof b); errs[(size_t)h] = b; }
-      } catch (...) { rc = SONIC_ERR_HIP; }                          // (nothing may leave a thread's body: std::terminate)
-      status[(size_t)i] = rc;
-    }
-  };
-  {
-    ThreadGroup th;
-    for (int h = 1; h < n_provers && h < K; h++) th.emplace_back(body, h);
-    body(0);
-    for (auto& t : th) t.join();
-  }
-  if (out_status) for (int64_t i = 0; i < K; i++) out_status[i] = status[(size_t)i];
-  for (int64_t i = 0; i < K; i++)
-    if (status[(size_t)i]) {
-      const int h = (int)(i % n_provers);
-      set_error("sonic_prove_batch, proof %ld (handle %d, device %d): %s", (long)i, h, provers[h]->device, errs[(size_t)h].c_str());
-      return status[(size_t)i];
-    }
-  return SONIC_OK;
-}
-
-// ---- commitPoly / openPoly on caller-supplied sparse polynomials ------------------------------
-struct DensePoly { DevBuf c; long lo = 0, len = 0; };
-
-static int densify(hipStream_t st, const sonic_srs* srs, int64_t nt, const int64_t* exps, const uint8_t* coeffs, bool include_zero,
-                   DensePoly& out, int* d_flags) {
-  long lo = include_zero ? 0 : (nt ? exps[0] : 0), hi = lo;
-  for (int64_t i = 0; i < nt; i++) { if (exps[i] < lo) lo = exps[i]; if (exps[i] > hi) hi = exps[i]; }
-  const long d = srs_d(srs);
-  if (hi - lo + 1 > 8 * (2 * d + 1) + 64) { set_error("polynomial exponent range [%ld, %ld] is far outside the SRS", lo, hi); return SONIC_ERR_SRS_INDEX; }
-  out.lo = lo; out.len = hi - lo + 1;
-  out.c.alloc(sizeof(Fr) * out.len);
-  HIP_OK(hipMemsetAsync(out.c.p, 0, sizeof(Fr) * out.len, st));
-  if (nt == 0) return SONIC_OK;
-  std::vector<int64_t> order(nt);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return exps[a] < exps[b]; });
-  std::vector<int64_t> se(nt);
-  std::vector<uint8_t> sc(32 * (size_t)nt);
-  for (int64_t i = 0; i < nt; i++) { se[i] = exps[order[i]]; memcpy(&sc[32 * (size_t)i], coeffs + 32 * order[i], 32); }
-  DevBuf de(8 * (size_t)nt), dc(32 * (size_t)nt);
-  HIP_OK(hipMemcpyAsync(de.p, se.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpyAsync(dc.p, sc.data(), 32 * (size_t)nt, hipMemcpyHostToDevice, st));
-  fr_to_mont_enqueue(st, dc.as<Fr>(), nt, d_flags);
-  sparse_to_dense_enqueue(st, de.as<int64_t>(), dc.as<Fr>(), nt, lo, out.c.as<Fr>());
-  HIP_OK(hipStreamSynchronize(st));   // host staging vectors and de/dc go out of scope
-  return SONIC_OK;
-}
-
-int sonic_commit_poly(const sonic_srs_t* srs, int64_t max, int64_t n_terms, const int64_t* exps, const uint8_t* coeffs, uint8_t out_g1[96]) {
-  API_BEGIN_ON(srs_device(srs))
-  if (!srs || n_terms < 0 || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
-  CallLease lease;
-  hipStream_t st = lease.st();
-  DevBuf flags(4), slot(sizeof(MsmSlot));
-  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
-  DensePoly f;
-  int rc = densify(st, srs, n_terms, exps, coeffs, false, f, flags.as<int>());
-  if (rc) return rc;
-  MsmJob job = commit_job(st, srs, f.c.as<Fr>(), f.lo, f.len, max, slot.as<MsmSlot>(), flags.as<int>());
-  run_jobs(st, srs, lease.ws(), &job, 1);
-  MsmSlot h;
-  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));
-  int fl = read_flags(st, flags);
-  if (fl) return flags_to_status(fl, "commitPoly");
-  g1_canonical_bytes_host(msm_finish_host(h), out_g1);
-  API_END
-}
-
-int sonic_open_poly(const sonic_srs_t* srs, const uint8_t z[32], int64_t n_terms, const int64_t* exps, const uint8_t* coeffs,
-                    uint8_t out_fz[32], uint8_t out_g1[96]) {
-  API_BEGIN_ON(srs_device(srs))
-  if (!srs || !z || n_terms < 0 || !out_fz || !out_g1 || (n_terms > 0 && (!exps || !coeffs))) return SONIC_ERR_INVALID_ARG;
-  CallLease lease;
-  hipStream_t st = lease.st();
-  DevBuf flags(4), slot(sizeof(MsmSlot)), zin(sizeof(Fr)), zpair(2 * sizeof(Fr)), fz(sizeof(Fr));
-  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
-  DensePoly f;
-  int rc = densify(st, srs, n_terms, exps, coeffs, true, f, flags.as<int>());
-  if (rc) return rc;
-  if (f.lo < 0 && bytes_are_zero(z, 32)) { set_error("openPoly: evaluation at z = 0 of a polynomial with negative exponents"); return SONIC_ERR_INEXACT_DIVISION; }
-  HIP_OK(hipMemcpyAsync(zin.p, z, 32, hipMemcpyHostToDevice, st));
-  fr_to_mont_enqueue(st, zin.as<Fr>(), 1, flags.as<int>());
-  fr_with_inverse_enqueue(st, zin.as<Fr>(), 1, zpair.as<Fr>());
-  Scratch sc;
-  MsmJob job = bytes_are_zero(z, 32)
-                   ? open_job_at_zero(st, srs, f.c.as<Fr>(), f.len, fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>())
-                   : open_job(st, srs, sc, f.c.as<Fr>(), f.lo, f.len, zpair.as<Fr>(), fz.as<Fr>(), slot.as<MsmSlot>(), flags.as<int>());
-  run_jobs(st, srs, lease.ws(), &job, 1);
-  fr_from_mont_enqueue(st, fz.as<Fr>(), 1);
-  MsmSlot h;
-  HIP_OK(hipMemcpyAsync(&h, slot.p, sizeof h, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(out_fz, fz.p, 32, hipMemcpyDeviceToHost, st));
-  int fl = read_flags(st, flags);
-  if (fl) return flags_to_status(fl, "openPoly");
-  g1_canonical_bytes_host(msm_finish_host(h), out_g1);
-  API_END
-}
-
-// ---- NTT / dense product -----------------------------------------------------------------------
-// the twiddle tables of the stand-alone transforms: one set per device, used under that device's call mutex
-static NttTables& shared_ntt() { DeviceCtx& c = current_ctx(); if (!c.ntt) c.ntt = new NttTables(); return *c.ntt; }
-
-int sonic_ntt_fr(uint8_t* data, int log2n, int inverse) {
-  API_BEGIN
-  if (!data || log2n < 0 || log2n > 28) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
-  const long n = 1L << log2n;
-  DevBuf d(sizeof(Fr) * n), flags(4);
-  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
-  HIP_OK(hipMemcpyAsync(d.p, data, 32 * n, hipMemcpyHostToDevice, st));
-  fr_to_mont_enqueue(st, d.as<Fr>(), n, flags.as<int>());
-  if (log2n > 0) {
-    shared_ntt().ensure(st, log2n);
-    if (!inverse) { ntt_forward_enqueue(st, shared_ntt(), d.as<Fr>(), log2n); fr_bitrev_permute_enqueue(st, d.as<Fr>(), log2n); }
-    else { fr_bitrev_permute_enqueue(st, d.as<Fr>(), log2n); ntt_inverse_enqueue(st, shared_ntt(), d.as<Fr>(), log2n); }
-  }
-  fr_from_mont_enqueue(st, d.as<Fr>(), n);
-  int fl = read_flags(st, flags);
-  if (fl) return flags_to_status(fl, "sonic_ntt_fr");
-  HIP_OK(hipMemcpy(data, d.p, 32 * n, hipMemcpyDeviceToHost));
-  API_END
-}
-
-int sonic_poly_mul_fr(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, uint8_t* out) {
-  API_BEGIN
-  if (!a || !b || !out || na < 1 || nb < 1) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
-  const long rl = na + nb - 1;
-  int lg = 0;
-  while ((1L << lg) < rl) lg++;
-  const long M = 1L << lg;
-  DevBuf fa(sizeof(Fr) * M), fb(sizeof(Fr) * M), flags(4);
-  HIP_OK(hipMemsetAsync(flags.p, 0, 4, st));
-  HIP_OK(hipMemsetAsync(fa.p, 0, sizeof(Fr) * M, st));
-  HIP_OK(hipMemsetAsync(fb.p, 0, sizeof(Fr) * M, st));
-  HIP_OK(hipMemcpyAsync(fa.p, a, 32 * na, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpyAsync(fb.p, b, 32 * nb, hipMemcpyHostToDevice, st));
-  fr_to_mont_enqueue(st, fa.as<Fr>(), na, flags.as<int>());
-  fr_to_mont_enqueue(st, fb.as<Fr>(), nb, flags.as<int>());
-  if (lg > 0) {
-    shared_ntt().ensure(st, lg);
-    ntt_forward_enqueue(st, shared_ntt(), fa.as<Fr>(), lg);
-    ntt_forward_enqueue(st, shared_ntt(), fb.as<Fr>(), lg);
-  }
-  if (lg > 0) ntt_inverse_of_product_enqueue(st, shared_ntt(), fa.as<Fr>(), fb.as<Fr>(), lg);
-  else fr_pointwise_mul_enqueue(st, fa.as<Fr>(), fb.as<Fr>(), M);
-  fr_from_mont_enqueue(st, fa.as<Fr>(), rl);
-  int fl = read_flags(st, flags);
-  if (fl) return flags_to_status(fl, "sonic_poly_mul_fr");
-  HIP_OK(hipMemcpy(out, fa.p, 32 * rl, hipMemcpyDeviceToHost));
-  API_END
-}
-
-// the same product with both operands and the result resident in HBM (canonical Fr, device pointers; d_out: na + nb - 1
-// elements): what bench.py times for the NTT roofline -- the three transforms and the pointwise product alone on the chip
-int sonic_poly_mul_fr_dev(const void* d_a, int64_t na, const void* d_b, int64_t nb, void* d_out) {
-  API_BEGIN
-  if (!d_a || !d_b || !d_out || na < 1 || nb < 1) return SONIC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> g(call_mutex());
-  hipStream_t st = default_stream();
-  const long rl = na + nb - 1;
-  int lg = 0;
-  while ((1L << lg) < rl) lg++;
-  const long M = 1L << lg;
-  DeviceCtx& dctx = current_ctx();
-  DevBuf *fa = &dctx.mul_a, *fb = &dctx.mul_b, *flags = &dctx.mul_flags;       // the device's product scratch (under its call mutex)
-  fa->ensure(sizeof(Fr) * M); fb->ensure(sizeof(Fr) * M); flags->ensure(4);
-  HIP_OK(hipMemsetAsync(flags->p, 0, 4, st));
-  HIP_OK(hipMemsetAsync(fa->p, 0, sizeof(Fr) * M, st));
-  HIP_OK(hipMemsetAsync(fb->p, 0, sizeof(Fr) * M, st));
-  HIP_OK(hipMemcpyAsync(fa->p, d_a, 32 * na, hipMemcpyDeviceToDevice, st));
-  HIP_OK(hipMemcpyAsync(fb->p, d_b, 32 * nb, hipMemcpyDeviceToDevice, st));
-  fr_to_mont_enqueue(st, fa->as<Fr>(), na, flags->as<int>());
-  fr_to_mont_enqueue(st, fb->as<Fr>(), nb, flags->as<int>());
-  if (lg > 0) {
-    shared_ntt().ensure(st, lg);
-    ntt_forward_enqueue(st, shared_ntt(), fa->as<Fr>(), lg);
-    ntt_forward_enqueue(st, shared_ntt(), fb->as<Fr>(), lg);
-  }
-  if (lg > 0) ntt_inverse_of_product_enqueue(st, shared_ntt(), fa->as<Fr>(), fb->as<Fr>(), lg);
-  else fr_pointwise_mul_enqueue(st, fa->as<Fr>(), fb->as<Fr>(), M);
-  fr_from_mont_enqueue(st, fa->as<Fr>(), rl);
-  HIP_OK(hipMemcpyAsync(d_out, fa->p, 32 * rl, hipMemcpyDeviceToDevice, st));
-  int fl = read_flags(st, *flags);
-  if (fl) return flags_to_status(fl, "sonic_poly_mul_fr_dev");
   API_END
 }
 
