@@ -157,9 +157,10 @@ struct sonic_prover {
     if (fused_sc_next == fused_sc.size()) fused_sc.emplace_back(new Scratch());
     return *fused_sc[fused_sc_next++];
   }
-  // SONIC_PROVE_GRAPH=1 (read when the handle is made): capture the enqueue of the second proof and replay it.  Off by default:
-  // on ROCm 7.2 the replay of this ~220-node, 7-stream graph is slower than the direct launches (n = 2^10: 9.0 vs 4.9 ms per proof,
-  // n = 2^14: 9.6 vs 6.5 ms).
+  // SONIC_PROVE_GRAPH=1 (read when the handle is made): capture the enqueue of the second proof and replay it.  Off by default: in round 3
+  // the replay of a ~220-node, 7-stream proof was slower than the direct launches (n = 2^10: 9.0 vs 4.9 ms per proof, n = 2^14: 9.6 vs 6.5);
+  // with one chain per proof (round 6) it is 4-8 % faster streamed from one host thread (n = 2^14: 3.18 vs 3.47 ms), 5-20 % slower one at a
+  // time, and no faster through sonic_prove_batch at BASELINE configs[4] (profiles/r06_ab_graph.txt).
   bool use_graph = false;
   hipGraphExec_t graph = nullptr;
   bool graph_tried = false;
