@@ -873,6 +873,7 @@ class Bench:
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
+    t_main = time.time()
     args = parse_args(argv)
     b = Bench(args, argv)
     rank, world, K, W = b.rank, b.world, b.K, b.W
@@ -1011,6 +1012,7 @@ def main(argv=None):
         "in_process": in_process,
         "status": "failed legs: " + ", ".join(sorted(b.leg_errors)) if b.leg_errors else "ok",
         "leg_errors": b.leg_errors or None,
+        "wall_s": round(time.time() - t_main, 1),       # the whole run, SRS generation and the CPU legs included
     }
     print(json.dumps(line), flush=True)
     if b.pg:
